@@ -1,0 +1,72 @@
+/*
+ * ggml_mi355x.h — the drop-in boundary: a ggml backend plugin for AMD Instinct MI355X (gfx950).
+ *
+ * `libggml-mi355x.so` is loaded by an UNMODIFIED whisper.cpp / ggml through ggml's own plugin loader:
+ *     GGML_BACKEND_PATH=/path/to/libggml-mi355x.so whisper-bench -m model.bin
+ * (ggml/src/ggml-backend-reg.cpp:562-593 `ggml_backend_load_all`, :220-264 `load_backend`, which dlsym()s the two
+ * C symbols below).  Everything else crosses the boundary through the C function-pointer tables of
+ * ggml/src/ggml-backend-impl.h (api_version GGML_BACKEND_API_VERSION == 2):
+ *     ggml_backend_reg_i          :214-224   get_name, get_device_count, get_device, get_proc_address
+ *     ggml_backend_device_i       :160-202   get_type -> GPU, init_backend, get_buffer_type, supports_op, supports_buft ...
+ *     ggml_backend_buffer_type_i  :17-29     alloc_buffer (hipMalloc), get_alignment, get_alloc_size
+ *     ggml_backend_buffer_i       :41-62     get_base, set_tensor / get_tensor (planar re-layout of quantized
+ *                                            weights happens here), cpy_tensor, clear, memset_tensor
+ *     ggml_backend_i              :105-140   graph_compute (fusion planner + HIP kernels), synchronize
+ * No reference source file or build flag changes; whisper.h / whisper_full() are untouched.
+ *
+ * The declarations below use `void *` where ggml uses its opaque handle typedefs so that this header can be
+ * included without ggml's headers.
+ */
+#ifndef GGML_MI355X_H
+#define GGML_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGML_MI355X_API __attribute__((visibility("default")))
+
+/* ---- the two symbols ggml's loader binds (ggml-backend-impl.h:229-235) --------------------------- */
+
+/* returns ggml_backend_reg_t (struct ggml_backend_reg *) with api_version == 2; NULL if no gfx950 device */
+GGML_MI355X_API void * ggml_backend_init(void);
+
+/* 0 = "not usable on this system" (no gfx950 GPU), otherwise a positive score */
+GGML_MI355X_API int    ggml_backend_score(void);
+
+/* ---- backend-private entry points, also reachable via ggml_backend_reg_get_proc_address(reg, name) --- */
+
+/* ggml_backend_reg_t for explicit (non-dlopen) registration: ggml_backend_register(ggml_backend_mi355x_reg()) */
+GGML_MI355X_API void * ggml_backend_mi355x_reg(void);
+
+/* "ggml_backend_get_features": array of {name, value} string pairs terminated by {NULL, NULL}
+ * (printed by whisper_print_system_info, src/whisper.cpp:4351) */
+struct ggml_mi355x_feature { const char * name; const char * value; };
+GGML_MI355X_API struct ggml_mi355x_feature * ggml_backend_mi355x_get_features(void * reg);
+
+/* Per-kernel profile of one backend (ggml_backend_t): enables hipEvent bracketing of every launch on the
+ * backend's stream (graph replay is disabled while profiling).  Rows as in mi355x_prof_row. */
+struct ggml_mi355x_prof_row { const char * name; uint64_t calls; double total_ms; double algo_bytes; double algo_flops; };
+GGML_MI355X_API void ggml_backend_mi355x_prof_enable(void * backend, int on);
+GGML_MI355X_API void ggml_backend_mi355x_prof_reset(void * backend);
+GGML_MI355X_API int  ggml_backend_mi355x_prof_report(void * backend, struct ggml_mi355x_prof_row * rows, int cap);
+
+/* Multi-GPU weight distribution: device-to-device copy of every WEIGHTS buffer allocated on
+ * `src_device` into the identically laid out buffers on `dst_device` of the same process (xGMI peer copy).
+ * Across processes the same buffers are broadcast with RCCL by the host harness through
+ * ggml_backend_mi355x_weight_buffers (base pointers + sizes in allocation order). */
+GGML_MI355X_API int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap);
+
+/* Runtime switches (environment):
+ *   GGML_MI355X_FUSE=0       run every ggml node as its own kernel (debug / parity bisect)
+ *   GGML_MI355X_GRAPHS=0     do not build / replay hipGraphs
+ *   GGML_MI355X_DEBUG=1      log unsupported ops and kernel-library errors to stderr
+ */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGML_MI355X_H */

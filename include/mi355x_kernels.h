@@ -1,0 +1,226 @@
+/*
+ * mi355x_kernels.h — C ABI of the MI355X (gfx950 / CDNA4) kernel library `libmi355x_kernels.so`.
+ *
+ * This is the "thin C-ABI" between the C++ host side of the ggml backend plugin (libggml-mi355x.so,
+ * see ggml_mi355x.h) and the hand-written HIP kernels.  Plain pointers and sizes only: no ggml, torch
+ * or C++ types cross this boundary, so the same entry points are bound from ctypes in tests/ and bench.py.
+ *
+ * Every op mirrors the semantics of one ggml op on the whisper.cpp hot path; the reference definition
+ * each one replaces is cited per function (paths relative to the reference tree).
+ *
+ * Data layout contract
+ * --------------------
+ *  - F32 / F16 / I32 tensors: ggml layout (ne[] element counts, nb[] BYTE strides), any strides the
+ *    reference CPU kernel accepts unless stated otherwise.
+ *  - Block-quantized tensors (Q4_0, Q5_0, Q8_0, Q4_K) live in HBM in a PLANAR ("struct of arrays")
+ *    re-arrangement of ggml's block structs (ggml/src/ggml-common.h:194-199, :229-235, :251-256, :327-338)
+ *    so that a wavefront reads them with aligned 16-byte loads.  For a tensor with NB blocks, in row-major
+ *    block order, the tensor's bytes [0, nbytes) hold:
+ *        Q4_0 : qs[NB][16]               | d[NB] (f16)
+ *        Q5_0 : qs[NB][16] | qh[NB] (u32) | d[NB] (f16)
+ *        Q8_0 : qs[NB][32]               | d[NB] (f16)
+ *        Q4_K : qs[NB][128] | scales[NB][12] | dm[NB] (f16 d, f16 dmin)
+ *    The byte count is identical to ggml's (18/22/34/144 bytes per block); mi355x_repack_to_planar /
+ *    mi355x_repack_from_planar convert on the host.  nb[] of a quantized tensor keeps ggml's values and
+ *    is only used to derive row/batch INDICES; such tensors must be contiguous.
+ *
+ * Return convention: 0 = ok, MI355X_E_UNSUPPORTED (-1) = shape/type not handled (caller falls back),
+ * any positive value = hipError_t from the runtime.  A missing GPU makes mi355x_ctx_create return NULL.
+ */
+#ifndef MI355X_KERNELS_H
+#define MI355X_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_API __attribute__((visibility("default")))
+
+#define MI355X_E_UNSUPPORTED (-1)
+
+/* numeric values == enum ggml_type (ggml/include/ggml.h:389-433) */
+enum mi355x_type {
+    MI355X_TYPE_F32  = 0,
+    MI355X_TYPE_F16  = 1,
+    MI355X_TYPE_Q4_0 = 2,
+    MI355X_TYPE_Q5_0 = 6,
+    MI355X_TYPE_Q8_0 = 8,
+    MI355X_TYPE_Q4_K = 12,
+    MI355X_TYPE_I32  = 26,
+};
+
+/* mirrors the fields of struct ggml_tensor (ggml/include/ggml.h:673-705) a kernel needs */
+typedef struct mi355x_tensor {
+    void *  data;      /* device pointer */
+    int32_t type;      /* enum mi355x_type */
+    int32_t reserved;
+    int64_t ne[4];     /* elements per dim */
+    int64_t nb[4];     /* byte strides */
+} mi355x_tensor;
+
+typedef struct mi355x_ctx mi355x_ctx;
+
+/* ---- context: one HIP stream + scratch arena + constant tables (GELU f16 LUT) ------------------- */
+MI355X_API int          mi355x_device_count(void);                      /* gfx950 devices visible; 0 if none */
+MI355X_API mi355x_ctx * mi355x_ctx_create(int device);                  /* NULL on failure */
+MI355X_API void         mi355x_ctx_destroy(mi355x_ctx * ctx);
+MI355X_API void *       mi355x_ctx_stream(mi355x_ctx * ctx);            /* hipStream_t */
+MI355X_API int          mi355x_ctx_synchronize(mi355x_ctx * ctx);
+MI355X_API const char * mi355x_last_error(void);
+
+/* launch recording: between begin/end no kernel is launched; launches are appended to the context's
+ * plan instead (used by the backend to build / patch a hipGraph).  See ggml_mi355x.h. */
+typedef struct mi355x_launch {
+    const void * func;          /* device function handle for hipLaunchKernel / hipGraphAddKernelNode */
+    uint32_t     grid[3];
+    uint32_t     block[3];
+    uint32_t     shmem;
+    uint32_t     arg_size;
+    uint64_t     arg_offset;    /* byte offset of this launch's single by-value argument struct in the blob */
+    const char * name;          /* static string: kernel family, for profiling */
+    double       algo_bytes;    /* algorithmic HBM bytes of this launch (roofline numerator) */
+    double       algo_flops;
+} mi355x_launch;
+
+MI355X_API void mi355x_record_begin(mi355x_ctx * ctx);
+/* returns the number of recorded launches, or -1 if the record is unusable (scratch arena had to grow) */
+MI355X_API int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size);
+
+/* profiling: when enabled every eager launch is bracketed by hipEvents on the context's stream and
+ * accumulated per kernel name.  mi355x_prof_report fills up to `cap` rows; returns the row count. */
+typedef struct mi355x_prof_row {
+    const char * name;
+    uint64_t     calls;
+    double       total_ms;
+    double       algo_bytes;   /* summed */
+    double       algo_flops;   /* summed */
+} mi355x_prof_row;
+MI355X_API void mi355x_prof_enable(mi355x_ctx * ctx, int on);
+MI355X_API int  mi355x_prof_report(mi355x_ctx * ctx, mi355x_prof_row * rows, int cap);  /* syncs the stream */
+MI355X_API void mi355x_prof_reset(mi355x_ctx * ctx);
+
+/* ---- host-side weight re-layout (ggml block structs <-> planar), see header comment -------------- */
+MI355X_API int    mi355x_type_is_quantized(int type);
+MI355X_API size_t mi355x_type_row_bytes(int type, int64_t ne0);      /* == ggml_row_size */
+MI355X_API int    mi355x_repack_to_planar  (int type, const void * ggml_blocks, void * planar, int64_t nelements);
+MI355X_API int    mi355x_repack_from_planar(int type, const void * planar, void * ggml_blocks, int64_t nelements);
+
+/* ---- fused epilogue of a mul_mat (each field optional) -------------------------------------------
+ * Applied in the order the whisper graphs apply the separate ggml ops (src/whisper.cpp:2119-2235,
+ * :2550-2827): dst = act( (W·x + bias) * scale ) + residual, every step rounded to f32 like the
+ * separate ggml_add / ggml_scale / ggml_gelu / ggml_add nodes. */
+typedef struct mi355x_epilogue {
+    const float * bias;            /* [N] broadcast over columns (ggml_add with a [N] or [N,1] src1) */
+    float         scale;           /* used when has_scale */
+    int32_t       has_scale;
+    int32_t       gelu;            /* 1: ggml_gelu (f16-table GELU, ggml-cpu/vec.h:987-1000) */
+    const float * residual;        /* [N,T] f32, same strides as dst; NULL = none */
+    int64_t       residual_nb1;    /* byte stride between columns of residual */
+} mi355x_epilogue;
+
+/* ---- ops ------------------------------------------------------------------------------------------ */
+
+/* ggml_mul_mat (ggml/src/ggml.c:3278; CPU kernel ggml-cpu/ggml-cpu.c:1254-1452).
+ * dst[n,t] = sum_k w[k,n] * x[k,t].  w: Q4_0/Q5_0/Q8_0/Q4_K (planar) or F16/F32; x: F32 (or F16);
+ * dst: F32 (or F16 when dst->type == F16: fused ggml_cpy into an F16 KV cache).
+ * Like the CPU path, x is first rounded to the weight type's vec_dot_type (Q8_0 / Q8_K blocks,
+ * ggml-cpu/ggml-cpu.c:1322-1357, arch/x86/quants.c:302-398; F16 for F16 weights). */
+MI355X_API int mi355x_mul_mat(mi355x_ctx * ctx, const mi355x_tensor * w, const mi355x_tensor * x,
+                              const mi355x_tensor * dst, const mi355x_epilogue * ep /* nullable */);
+
+/* Two-step form of mul_mat for T > 8 (lets the caller share one prepared activation between several
+ * weights, e.g. Q/K/V): mi355x_prep_act rounds x [K,T] (F32 or F16, row stride x_nb1 bytes) to the weight
+ * type's vec_dot_type and stores it as f16 [T][K]: mode 0 = F16 weights (plain f16), 1 = Q4_0/Q5_0/Q8_0
+ * weights (Q8_0 round trip), 2 = Q4_K weights (Q8_K round trip).  mi355x_gemm_f16act is the MFMA GEMM. */
+MI355X_API int mi355x_prep_act(mi355x_ctx * ctx, const void * x, int64_t x_nb1, int x_is_f16, void * act_f16, int K, int64_t T, int mode);
+MI355X_API int mi355x_gemm_f16act(mi355x_ctx * ctx, const mi355x_tensor * w, const void * act_f16, int64_t ld, int64_t T,
+                                  void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep /* nullable */);
+
+/* Decoder-step fusion (T <= 8 columns): [optional LayerNorm(x)*ln_w+ln_b] -> quantize -> up to 3
+ * mat-vec products sharing x (Q,K,V) each with its own epilogue/destination.  Same arithmetic as the
+ * unfused node sequence norm,mul,add,mul_mat,add,scale,cpy (src/whisper.cpp:2529-2598). */
+typedef struct mi355x_gemv_seg {
+    const void *  w;               /* planar quantized or f16 weight [K, N] */
+    int32_t       wtype;
+    int32_t       N;
+    mi355x_epilogue ep;
+    void *        dst;             /* [N, T] */
+    int32_t       dst_type;        /* F32 or F16 */
+    int32_t       reserved;
+    int64_t       dst_nb1;         /* byte stride between columns */
+} mi355x_gemv_seg;
+
+typedef struct mi355x_gemv_desc {
+    const float * x;               /* [K, T] f32 */
+    int64_t       x_nb1;
+    int32_t       K;
+    int32_t       T;
+    int32_t       has_norm;        /* 1: x <- norm(x, eps) * ln_w + ln_b  (ggml_norm, ggml-cpu/ops.cpp:3698-3765) */
+    float         eps;
+    const float * ln_w;
+    const float * ln_b;
+    int32_t       nseg;
+    int32_t       reserved;
+    mi355x_gemv_seg seg[3];
+} mi355x_gemv_desc;
+MI355X_API int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
+
+/* ggml_flash_attn_ext (ggml/src/ggml.c:5418-5460; CPU ggml-cpu/ops.cpp:8479-8715).
+ * q: F32 [D, T, H] (any nb1/nb2), k/v: F16 [D, n_kv, H] views, mask: F16 [n_kv, >=T] or NULL,
+ * dst: F32 [D, H, T].  D must be 64 (all Whisper models).  softmax(scale*q.k + mask) . v */
+MI355X_API int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k,
+                                     const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */,
+                                     const mi355x_tensor * dst, float scale);
+
+/* ggml_norm (ggml/src/ggml.c:3139; CPU ggml-cpu/ops.cpp:3698-3765) with optional fused affine
+ * (the ggml_mul + ggml_add that always follow it in whisper, src/whisper.cpp:2109-2114). */
+MI355X_API int mi355x_norm(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst, float eps,
+                           const float * w /* nullable [ne0] */, const float * b /* nullable [ne0] */);
+
+/* ggml_add / ggml_mul with broadcasting of src1 (CPU ggml-cpu/binary-ops.cpp:140-148). op: 0 add, 1 mul */
+MI355X_API int mi355x_binary(mi355x_ctx * ctx, int op, const mi355x_tensor * a, const mi355x_tensor * b, const mi355x_tensor * dst);
+
+/* ggml_scale: dst = x*s + b (CPU ggml-cpu/ops.cpp:4568-4620) */
+MI355X_API int mi355x_scale(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst, float s, float b);
+
+/* ggml_gelu (ggml/src/ggml.c:2781; CPU ggml_vec_gelu_f32, ggml-cpu/vec.h:987-1000: f16 lookup table) */
+MI355X_API int mi355x_gelu(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst);
+
+/* ggml_cpy / ggml_cont / ggml_dup / ggml_cast between F32 and F16 (CPU ggml-cpu/ops.cpp:17-654) */
+MI355X_API int mi355x_cpy(mi355x_ctx * ctx, const mi355x_tensor * src, const mi355x_tensor * dst);
+
+/* ggml_get_rows (ggml/src/ggml.c:3891; CPU ggml-cpu/ops.cpp:4850-5017): src F32/F16/quantized(planar), idx I32 */
+MI355X_API int mi355x_get_rows(mi355x_ctx * ctx, const mi355x_tensor * src, const mi355x_tensor * idx, const mi355x_tensor * dst);
+
+/* ggml_im2col, 1-D case used by ggml_conv_1d (ggml/src/ggml.c:4468-4565; CPU ggml-cpu/ops.cpp:6437-6517).
+ * x: F32 [IW, IC, N], dst: F16 or F32 [IC*KW, OW, N] */
+MI355X_API int mi355x_im2col_1d(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst,
+                                int kw, int s0, int p0, int d0);
+
+/* ggml_soft_max_ext (ggml/src/ggml.c:4093; CPU ggml-cpu/ops.cpp:5455-5565): rows of ne0, mask F32/F16 or NULL */
+MI355X_API int mi355x_soft_max(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * mask /* nullable */,
+                               const mi355x_tensor * dst, float scale, float max_bias);
+
+/* ggml_rope_ext, modes NORMAL(0) and NEOX(2) incl. YaRN parameters (ggml/src/ggml.c:4168; CPU
+ * ggml-cpu/ops.cpp:5822-6131).  Not on whisper's graph; standalone op. */
+typedef struct mi355x_rope_params {
+    int32_t n_dims, mode, n_ctx_orig;
+    float   freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+} mi355x_rope_params;
+MI355X_API int mi355x_rope(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * pos /* I32 [ne2] */,
+                           const float * freq_factors /* nullable */, const mi355x_tensor * dst,
+                           const mi355x_rope_params * p);
+
+/* ggml_concat along `dim` for F32 (CPU ggml-cpu/ops.cpp concat; dtw timestamps only, src/whisper.cpp:2741) */
+MI355X_API int mi355x_concat(mi355x_ctx * ctx, const mi355x_tensor * a, const mi355x_tensor * b, const mi355x_tensor * dst, int dim);
+
+/* memset / memcpy helpers on the context stream */
+MI355X_API int mi355x_memset(mi355x_ctx * ctx, void * dptr, int value, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_KERNELS_H */

@@ -1,0 +1,888 @@
+// ggml backend plugin for AMD Instinct MI355X (gfx950).  Host side only: registration, buffers, graph walk +
+// fusion planner, hipGraph replay.  All device work goes through the C ABI of libmi355x_kernels.so
+// (include/mi355x_kernels.h).  Boundary documentation: include/ggml_mi355x.h.
+//
+// Reference interface being implemented: ggml/src/ggml-backend-impl.h (vtables), loader
+// ggml/src/ggml-backend-reg.cpp:220-264, scheduler call sites ggml/src/ggml-backend.cpp:1594-1780.
+#include "ggml.h"
+#include "ggml-backend.h"
+#include "ggml-backend-impl.h"
+#include "ggml-impl.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include "ggml_mi355x.h"
+#include "mi355x_kernels.h"
+
+#include <atomic>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define MI_MAX_DEVICES 16
+#define MI_ALIGNMENT   256      // tensor alignment inside buffers (hipMalloc itself is 256-B aligned or better)
+
+static bool env_flag(const char * name, bool def) {
+    const char * v = getenv(name);
+    if (!v || !*v) return def;
+    return !(v[0] == '0' || v[0] == 'n' || v[0] == 'N' || v[0] == 'f' || v[0] == 'F');
+}
+static bool g_debug() { static bool d = env_flag("GGML_MI355X_DEBUG", false); return d; }
+#define MI_LOG(...) do { if (g_debug()) { fprintf(stderr, "ggml-mi355x: " __VA_ARGS__); fputc('\n', stderr); } } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// device / registry state
+// ---------------------------------------------------------------------------------------------------
+struct mi_device_ctx {
+    int         index;
+    std::string name;          // "MI355X0"
+    std::string description;   // from hipDeviceProp
+    ggml_backend_buffer_type buft;
+};
+
+struct mi_buffer_ctx {
+    int    device;
+    void * base;
+    size_t size;
+};
+
+struct mi_weight_rec { int device; void * base; size_t size; ggml_backend_buffer_t buf; };
+static std::mutex                 g_weights_mtx;
+static std::vector<mi_weight_rec> g_buffers;       // every live device buffer, in allocation order
+
+static ggml_backend_reg           g_reg;
+static ggml_backend_device        g_devices[MI_MAX_DEVICES];
+static mi_device_ctx              g_device_ctx[MI_MAX_DEVICES];
+static int                        g_n_devices = -1;
+
+static bool is_quant_type(ggml_type t) { return mi355x_type_is_quantized((int) t) != 0; }
+
+// ---------------------------------------------------------------------------------------------------
+// buffer
+// ---------------------------------------------------------------------------------------------------
+static void mi_buffer_free(ggml_backend_buffer_t buffer) {
+    mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    {
+        std::lock_guard<std::mutex> lk(g_weights_mtx);
+        for (size_t i = 0; i < g_buffers.size(); i++) if (g_buffers[i].base == ctx->base) { g_buffers.erase(g_buffers.begin() + i); break; }
+    }
+    (void) hipSetDevice(ctx->device);
+    (void) hipDeviceSynchronize();
+    (void) hipFree(ctx->base);
+    delete ctx;
+}
+
+static void * mi_buffer_get_base(ggml_backend_buffer_t buffer) { return ((mi_buffer_ctx *) buffer->context)->base; }
+
+// quantized tensors are stored planar (include/mi355x_kernels.h); whole-tensor transfers re-layout on the host,
+// partial ones go through read-modify-write of the whole tensor (never happens in whisper.cpp: W:1934-1938)
+static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    (void) hipSetDevice(ctx->device);
+    if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
+        const size_t nbytes = ggml_nbytes(tensor);
+        std::vector<uint8_t> planar(nbytes);
+        if (offset == 0 && size == nbytes) {
+            mi355x_repack_to_planar((int) tensor->type, data, planar.data(), ggml_nelements(tensor));
+        } else {
+            std::vector<uint8_t> blocks(nbytes);
+            (void) hipMemcpy(planar.data(), tensor->data, nbytes, hipMemcpyDeviceToHost);
+            mi355x_repack_from_planar((int) tensor->type, planar.data(), blocks.data(), ggml_nelements(tensor));
+            memcpy(blocks.data() + offset, data, size);
+            mi355x_repack_to_planar((int) tensor->type, blocks.data(), planar.data(), ggml_nelements(tensor));
+        }
+        hipError_t e = hipMemcpy(tensor->data, planar.data(), nbytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) GGML_LOG_ERROR("ggml-mi355x: set_tensor failed: %s\n", hipGetErrorString(e));
+        return;
+    }
+    hipError_t e = hipMemcpy((char *) tensor->data + offset, data, size, hipMemcpyHostToDevice);
+    if (e != hipSuccess) GGML_LOG_ERROR("ggml-mi355x: set_tensor failed: %s\n", hipGetErrorString(e));
+}
+
+static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    (void) hipSetDevice(ctx->device);
+    if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
+        const size_t nbytes = ggml_nbytes(tensor);
+        std::vector<uint8_t> planar(nbytes), blocks(nbytes);
+        (void) hipMemcpy(planar.data(), tensor->data, nbytes, hipMemcpyDeviceToHost);
+        mi355x_repack_from_planar((int) tensor->type, planar.data(), blocks.data(), ggml_nelements(tensor));
+        memcpy(data, blocks.data() + offset, size);
+        return;
+    }
+    hipError_t e = hipMemcpy(data, (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) GGML_LOG_ERROR("ggml-mi355x: get_tensor failed: %s\n", hipGetErrorString(e));
+}
+
+static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
+    mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    (void) hipSetDevice(ctx->device);
+    (void) hipMemset((char *) tensor->data + offset, value, size);
+    (void) hipDeviceSynchronize();
+}
+
+static void mi_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    (void) hipSetDevice(ctx->device);
+    (void) hipMemset(ctx->base, value, ctx->size);
+    (void) hipDeviceSynchronize();
+}
+
+static bool mi_buffer_is_ours(ggml_backend_buffer_t buffer) { return buffer && buffer->iface.get_base == mi_buffer_get_base; }
+
+static bool mi_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * src, ggml_tensor * dst) {
+    ggml_backend_buffer_t sbuf = src->view_src ? src->view_src->buffer : src->buffer;
+    if (!mi_buffer_is_ours(sbuf)) return false;
+    mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    (void) hipSetDevice(ctx->device);
+    // same layout on both sides (ggml_are_same_layout is asserted by the caller) => raw bytes, planar included
+    hipError_t e = hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice);
+    (void) hipDeviceSynchronize();
+    return e == hipSuccess;
+}
+
+static const ggml_backend_buffer_i mi_buffer_iface = {
+    /* .free_buffer   = */ mi_buffer_free,
+    /* .get_base      = */ mi_buffer_get_base,
+    /* .init_tensor   = */ nullptr,
+    /* .memset_tensor = */ mi_buffer_memset_tensor,
+    /* .set_tensor    = */ mi_buffer_set_tensor,
+    /* .get_tensor    = */ mi_buffer_get_tensor,
+    /* .set_tensor_2d = */ nullptr,
+    /* .get_tensor_2d = */ nullptr,
+    /* .cpy_tensor    = */ mi_buffer_cpy_tensor,
+    /* .clear         = */ mi_buffer_clear,
+    /* .reset         = */ nullptr,
+};
+
+// ---------------------------------------------------------------------------------------------------
+// buffer type
+// ---------------------------------------------------------------------------------------------------
+static const char * mi_buft_get_name(ggml_backend_buffer_type_t buft) { return ((mi_device_ctx *) buft->context)->name.c_str(); }
+
+static ggml_backend_buffer_t mi_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    mi_device_ctx * dev = (mi_device_ctx *) buft->context;
+    if (hipSetDevice(dev->index) != hipSuccess) return nullptr;
+    void * base = nullptr;
+    const size_t asize = size + 1024;          // slack: kernels may read whole 16-byte vectors at the tail
+    hipError_t e = hipMalloc(&base, asize);
+    if (e != hipSuccess) {
+        GGML_LOG_ERROR("ggml-mi355x: hipMalloc of %.2f MiB on device %d failed: %s\n", asize / 1048576.0, dev->index, hipGetErrorString(e));
+        return nullptr;
+    }
+    mi_buffer_ctx * ctx = new mi_buffer_ctx{ dev->index, base, asize };
+    ggml_backend_buffer_t buf = ggml_backend_buffer_init(buft, mi_buffer_iface, ctx, size);
+    {
+        std::lock_guard<std::mutex> lk(g_weights_mtx);
+        g_buffers.push_back({ dev->index, base, size, buf });
+    }
+    return buf;
+}
+static size_t mi_buft_get_alignment(ggml_backend_buffer_type_t) { return MI_ALIGNMENT; }
+static size_t mi_buft_get_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * tensor) { return ggml_nbytes(tensor); }
+static bool   mi_buft_is_host(ggml_backend_buffer_type_t) { return false; }
+
+static const ggml_backend_buffer_type_i mi_buft_iface = {
+    /* .get_name       = */ mi_buft_get_name,
+    /* .alloc_buffer   = */ mi_buft_alloc_buffer,
+    /* .get_alignment  = */ mi_buft_get_alignment,
+    /* .get_max_size   = */ nullptr,
+    /* .get_alloc_size = */ mi_buft_get_alloc_size,
+    /* .is_host        = */ mi_buft_is_host,
+};
+
+// ---------------------------------------------------------------------------------------------------
+// backend (stream)
+// ---------------------------------------------------------------------------------------------------
+struct mi_graph_cache {
+    hipGraph_t                 graph = nullptr;
+    hipGraphExec_t             exec  = nullptr;
+    std::vector<hipGraphNode_t> nodes;
+    std::vector<mi355x_launch>  launches;
+    std::vector<uint8_t>        blob;
+    uint64_t                    hits = 0;
+};
+
+struct mi_backend_ctx {
+    int          device;
+    mi355x_ctx * k;
+    std::string  name;
+    bool         fuse, graphs, prof;
+    // f16 activation scratch for the MFMA path, shared by consecutive mul_mats with the same src1
+    void *       act = nullptr; size_t act_size = 0;
+    const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
+    // hipGraph replay, keyed by number of launches (decoder step / encoder graphs differ in length)
+    std::vector<mi_graph_cache> gcache;
+    uint64_t n_graph_compute = 0, n_replay = 0, n_update = 0, n_rebuild = 0;
+    bool     recording = false, record_abort = false;
+};
+
+static mi355x_tensor to_mt(const ggml_tensor * t) {
+    mi355x_tensor m;
+    m.data = t->data; m.type = (int32_t) t->type; m.reserved = 0;
+    for (int i = 0; i < 4; i++) { m.ne[i] = t->ne[i]; m.nb[i] = (int64_t) t->nb[i]; }
+    return m;
+}
+
+static bool op_is_empty(const ggml_tensor * t) {
+    return t->op == GGML_OP_NONE || t->op == GGML_OP_RESHAPE || t->op == GGML_OP_VIEW || t->op == GGML_OP_PERMUTE || t->op == GGML_OP_TRANSPOSE;
+}
+
+static int use_count(const ggml_cgraph * g, const ggml_tensor * t) {
+    if (!g->use_counts || !g->visited_hash_set.keys) return 1 << 20;
+    const size_t pos = ggml_hash_find(&g->visited_hash_set, t);
+    if (pos == GGML_HASHSET_FULL || !ggml_bitset_get(g->visited_hash_set.used, pos)) return 1 << 20;
+    return g->use_counts[pos];
+}
+// may `t` be elided (computed only inside a fused kernel) given that exactly `n` fused consumers read it?
+static bool can_elide(const ggml_cgraph * g, const ggml_tensor * t, int n) {
+    return use_count(g, t) == n && !t->view_src && !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
+}
+
+static bool overlap(const void * a, size_t na, const void * b, size_t nb) {
+    const char * pa = (const char *) a, * pb = (const char *) b;
+    return pa < pb + nb && pb < pa + na;
+}
+static bool t_overlap(const ggml_tensor * a, const ggml_tensor * b) { return overlap(a->data, ggml_nbytes(a), b->data, ggml_nbytes(b)); }
+
+static bool is_vec_f32(const ggml_tensor * t, int64_t n) {     // contiguous f32 vector of n elements (any trailing 1-dims)
+    return t->type == GGML_TYPE_F32 && ggml_nelements(t) == n && t->ne[0] == n && t->nb[0] == 4;
+}
+
+// next node index after `i` that is not an empty op (or n_nodes)
+static int next_real(const ggml_cgraph * g, int i) {
+    int j = i + 1;
+    while (j < g->n_nodes && (op_is_empty(g->nodes[j]) || !(g->nodes[j]->flags & GGML_TENSOR_FLAG_COMPUTE))) j++;
+    return j;
+}
+
+// ---- mul_mat chain:  mul_mat [-> add bias] [-> scale] [-> gelu] [-> add residual] [-> cpy to f16] ----
+struct mm_chain {
+    const ggml_tensor * mm = nullptr;
+    const ggml_tensor * last = nullptr;     // tensor whose memory receives the result
+    mi355x_epilogue ep{};
+    int end = 0;                            // index of the last fused node
+};
+
+static bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c) {
+    const ggml_tensor * mm = g->nodes[i];
+    if (mm->op != GGML_OP_MUL_MAT) return false;
+    c = mm_chain(); c.mm = mm; c.last = mm; c.end = i;
+    if (!fuse) return true;
+    const ggml_tensor * w = mm->src[0], * x = mm->src[1];
+    if (ggml_n_dims(w) > 2 || x->ne[2] != 1 || x->ne[3] != 1 || mm->type != GGML_TYPE_F32) return true;
+    const int64_t N = mm->ne[0];
+    const ggml_tensor * cur = mm;
+    int stage = 0;   // 0: bias allowed, 1: scale, 2: gelu, 3: residual, 4: cpy
+    int j = next_real(g, i);
+    while (j < g->n_nodes && stage < 5) {
+        const ggml_tensor * n = g->nodes[j];
+        if (!can_elide(g, cur, 1)) break;
+        bool took = false;
+        if (n->op == GGML_OP_ADD && (n->src[0] == cur || n->src[1] == cur) && ggml_are_same_shape(n, cur) && n->type == GGML_TYPE_F32) {
+            const ggml_tensor * o = n->src[0] == cur ? n->src[1] : n->src[0];
+            if (stage <= 0 && is_vec_f32(o, N) && o != cur) { c.ep.bias = (const float *) o->data; stage = 1; took = true; }
+            else if (stage <= 3 && o->type == GGML_TYPE_F32 && ggml_are_same_shape(o, cur) && o->nb[0] == 4 && o != cur) {
+                c.ep.residual = (const float *) o->data; c.ep.residual_nb1 = (int64_t) o->nb[1]; stage = 4; took = true;
+            }
+        } else if (n->op == GGML_OP_SCALE && n->src[0] == cur && stage <= 1 && ggml_get_op_params_f32(n, 1) == 0.0f) {
+            c.ep.scale = ggml_get_op_params_f32(n, 0); c.ep.has_scale = 1; stage = 2; took = true;
+        } else if (n->op == GGML_OP_UNARY && ggml_get_unary_op(n) == GGML_UNARY_OP_GELU && n->src[0] == cur && stage <= 2) {
+            c.ep.gelu = 1; stage = 3; took = true;
+        } else if (n->op == GGML_OP_CPY && n->src[0] == cur && n->type == GGML_TYPE_F16 && ggml_is_contiguous(n) &&
+                   ggml_nelements(n) == ggml_nelements(cur) && ggml_is_contiguous(cur)) {
+            stage = 5; took = true;
+        }
+        if (!took) break;
+        cur = n; c.last = n; c.end = j;
+        j = next_real(g, j);
+    }
+    // memory hazards: the result must not land on anything the kernel still reads
+    const ggml_tensor * res_t = nullptr;
+    if (c.last != mm) {
+        bool bad = t_overlap(c.last, x) || t_overlap(c.last, w);
+        if (c.ep.residual) {
+            // identical aliasing (in-place add) is fine: every element is read before it is written by the same lane
+            const char * r = (const char *) c.ep.residual;
+            const size_t rn = (size_t) c.ep.residual_nb1 * (size_t) mm->ne[1];
+            if (overlap(c.last->data, ggml_nbytes(c.last), r, rn) && !(r == (const char *) c.last->data && c.ep.residual_nb1 == (int64_t) c.last->nb[1])) bad = true;
+        }
+        if (c.ep.bias && overlap(c.last->data, ggml_nbytes(c.last), c.ep.bias, N*4)) bad = true;
+        (void) res_t;
+        if (bad) { c = mm_chain(); c.mm = mm; c.last = mm; c.end = i; }
+    }
+    return true;
+}
+
+static int mode_for(ggml_type t) { return t == GGML_TYPE_Q4_K ? 2 : (is_quant_type(t) ? 1 : 0); }
+
+static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
+    const ggml_tensor * mm = c.mm, * w = mm->src[0], * x = mm->src[1];
+    mi355x_tensor mw = to_mt(w), mx = to_mt(x);
+    // destination: the chain's last tensor, seen as [N, T] with the dtype of that tensor
+    mi355x_tensor md = to_mt(mm);
+    md.data = c.last->data; md.type = (int32_t) c.last->type;
+    if (c.last->type == GGML_TYPE_F16) { md.nb[0] = 2; md.nb[1] = mm->ne[0]*2; md.nb[2] = md.nb[1]*mm->ne[1]; md.nb[3] = md.nb[2]; }
+    else if (c.last != mm)              { md.nb[0] = 4; md.nb[1] = (int64_t) c.last->nb[1]; md.nb[2] = (int64_t) c.last->nb[2]; md.nb[3] = (int64_t) c.last->nb[3]; }
+    const bool has_ep = c.ep.bias || c.ep.has_scale || c.ep.gelu || c.ep.residual;
+    const int64_t K = w->ne[0], T = x->ne[1];
+    const bool two_d = ggml_n_dims(w) <= 2 && x->ne[2] == 1 && x->ne[3] == 1;
+
+    // MFMA path with shared prepared activation
+    if (two_d && T > 8 && K % 8 == 0 && x->nb[0] == ggml_type_size(x->type) && (x->nb[1] % 16 == 0) && ((uintptr_t) x->data % 16 == 0) &&
+        (x->type == GGML_TYPE_F32 || x->type == GGML_TYPE_F16) &&
+        ((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && w->nb[0] == 2 && w->nb[1] % 16 == 0))) {
+        const int mode = mode_for(w->type);
+        if (!((mode == 1 && K % 32) || (mode == 2 && K % 256))) {
+            const void * act; int64_t ld;
+            if (x->type == GGML_TYPE_F16 && mode == 0) { act = x->data; ld = (int64_t) x->nb[1] / 2; }
+            else {
+                const size_t need = (size_t) T * K * 2;
+                if (need > b->act_size) {
+                    if (b->recording) { b->record_abort = true; return 0; }     // re-run eagerly, which grows the buffer
+                    mi355x_ctx_synchronize(b->k);
+                    if (b->act) (void) hipFree(b->act);
+                    b->act = nullptr; b->act_size = 0;
+                    size_t sz = need + (need >> 2);
+                    if (hipMalloc(&b->act, sz) != hipSuccess) return (int) hipErrorOutOfMemory;
+                    b->act_size = sz; b->act_src = nullptr;
+                }
+                if (!(b->act_src == x->data && b->act_K == K && b->act_T == T && b->act_mode == mode && b->act_nb1 == (int64_t) x->nb[1])) {
+                    const int rc = mi355x_prep_act(b->k, x->data, (int64_t) x->nb[1], x->type == GGML_TYPE_F16, b->act, (int) K, T, mode);
+                    if (rc) return rc;
+                    b->act_src = x->data; b->act_K = K; b->act_T = T; b->act_mode = mode; b->act_nb1 = (int64_t) x->nb[1];
+                }
+                act = b->act; ld = K;
+            }
+            const int rc = mi355x_gemm_f16act(b->k, &mw, act, ld, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
+            if (rc != MI355X_E_UNSUPPORTED) return rc;
+        }
+    }
+    return mi355x_mul_mat(b->k, &mw, &mx, &md, has_ep ? &c.ep : nullptr);
+}
+
+// ---- norm [-> mul w -> add b] ---------------------------------------------------------------------
+struct ln_chain { const ggml_tensor * norm = nullptr, * last = nullptr; const float * w = nullptr, * b = nullptr; int end = 0; };
+
+static void parse_ln_chain(const ggml_cgraph * g, int i, bool fuse, ln_chain & c) {
+    const ggml_tensor * nrm = g->nodes[i];
+    c = ln_chain(); c.norm = nrm; c.last = nrm; c.end = i;
+    if (!fuse || nrm->type != GGML_TYPE_F32) return;
+    const int64_t n = nrm->ne[0];
+    int j = next_real(g, i);
+    if (j >= g->n_nodes || !can_elide(g, nrm, 1)) return;
+    const ggml_tensor * m = g->nodes[j];
+    if (m->op != GGML_OP_MUL || !ggml_are_same_shape(m, nrm)) return;
+    const ggml_tensor * wv = m->src[0] == nrm ? m->src[1] : (m->src[1] == nrm ? m->src[0] : nullptr);
+    if (!wv || !is_vec_f32(wv, n)) return;
+    int j2 = next_real(g, j);
+    if (j2 >= g->n_nodes || !can_elide(g, m, 1)) return;
+    const ggml_tensor * a = g->nodes[j2];
+    if (a->op != GGML_OP_ADD || !ggml_are_same_shape(a, m)) return;
+    const ggml_tensor * bv = a->src[0] == m ? a->src[1] : (a->src[1] == m ? a->src[0] : nullptr);
+    if (!bv || !is_vec_f32(bv, n)) return;
+    const ggml_tensor * x = nrm->src[0];
+    // result memory may alias x exactly (row-wise in-place), but must not partially overlap it
+    if (t_overlap(a, x) && !(a->data == x->data && a->nb[1] == x->nb[1] && a->nb[2] == x->nb[2] && a->nb[3] == x->nb[3])) return;
+    if (t_overlap(a, wv) || t_overlap(a, bv)) return;
+    c.last = a; c.w = (const float *) wv->data; c.b = (const float *) bv->data; c.end = j2;
+}
+
+static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c) {
+    float eps; memcpy(&eps, c.norm->op_params, sizeof(float));
+    mi355x_tensor mx = to_mt(c.norm->src[0]), md = to_mt(c.last);
+    return mi355x_norm(b->k, &mx, &md, eps, c.w, c.b);
+}
+
+// decoder step: LayerNorm fused into the mat-vec products that consume it (Q/K/V, cross-Q, fc1)
+static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chain & ln, int & end_out, int & rc_out) {
+    if (!ln.w || !ln.b) return false;
+    const ggml_tensor * x = ln.norm->src[0], * lnout = ln.last;
+    const int64_t K = x->ne[0], T = ggml_nrows(x);
+    if (T > 8 || K > 2048 || K % 4 || x->ne[2] != 1 || x->ne[3] != 1 || x->nb[0] != 4 || (x->nb[1] % 16) || ((uintptr_t) x->data % 16)) return false;
+    if (((uintptr_t) ln.w % 16) || ((uintptr_t) ln.b % 16)) return false;
+    const int nuse = use_count(g, lnout);
+    if (nuse < 1 || nuse > 3 || lnout->view_src || (lnout->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    mm_chain ch[3];
+    int j = next_real(g, ln.end), n = 0;
+    while (n < nuse && j < g->n_nodes) {
+        const ggml_tensor * t = g->nodes[j];
+        if (t->op != GGML_OP_MUL_MAT || t->src[1] != lnout) return false;
+        if (!parse_mm_chain(g, j, true, ch[n])) return false;
+        j = next_real(g, ch[n].end);
+        n++;
+    }
+    if (n != nuse) return false;
+    mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
+    d.x = (const float *) x->data; d.x_nb1 = (int64_t) x->nb[1]; d.K = (int) K; d.T = (int) T;
+    d.has_norm = 1; memcpy(&d.eps, ln.norm->op_params, sizeof(float)); d.ln_w = ln.w; d.ln_b = ln.b; d.nseg = n;
+    for (int s = 0; s < n; s++) {
+        const ggml_tensor * w = ch[s].mm->src[0];
+        if (w->type != ch[0].mm->src[0]->type || ggml_n_dims(w) > 2 || w->ne[0] != K) return false;
+        if (!((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && ggml_is_contiguous(w)))) return false;
+        if (t_overlap(ch[s].last, x)) return false;
+        for (int s2 = 0; s2 < s; s2++) if (t_overlap(ch[s].last, ch[s2].last)) return false;
+        mi355x_gemv_seg & sg = d.seg[s];
+        sg.w = w->data; sg.wtype = (int32_t) w->type; sg.N = (int32_t) w->ne[1]; sg.ep = ch[s].ep;
+        sg.dst = ch[s].last->data; sg.dst_type = (int32_t) ch[s].last->type;
+        sg.dst_nb1 = ch[s].last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch[s].last == ch[s].mm ? (int64_t) ch[s].mm->nb[1] : (int64_t) ch[s].last->nb[1]);
+    }
+    const int rc = mi355x_gemv_fused(b->k, &d);
+    if (rc == MI355X_E_UNSUPPORTED) return false;
+    rc_out = rc; end_out = ch[n - 1].end;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// supports_op / single-node dispatch
+// ---------------------------------------------------------------------------------------------------
+static bool whole_quant_ok(const ggml_tensor * t) {   // quantized operands must be whole contiguous tensors (planar layout)
+    return !is_quant_type(t->type) || (ggml_is_contiguous(t) && (!t->view_src || (t->view_offs == 0 && ggml_nbytes(t) == ggml_nbytes(t->view_src))));
+}
+
+static bool mi_supports_op_impl(const ggml_tensor * op) {
+    const ggml_tensor * s0 = op->src[0], * s1 = op->src[1];
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_MUL_MAT: {
+            if (op->type != GGML_TYPE_F32) return false;
+            const ggml_type wt = s0->type;
+            if (!(wt == GGML_TYPE_F32 || wt == GGML_TYPE_F16 || wt == GGML_TYPE_Q4_0 || wt == GGML_TYPE_Q5_0 || wt == GGML_TYPE_Q8_0 || wt == GGML_TYPE_Q4_K)) return false;
+            if (s1->type != GGML_TYPE_F32 && s1->type != GGML_TYPE_F16) return false;
+            if (s1->nb[0] != ggml_type_size(s1->type)) return false;
+            if (is_quant_type(wt)) return whole_quant_ok(s0) && s0->ne[0] % 32 == 0;
+            return s0->nb[0] == ggml_type_size(wt);
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            const ggml_tensor * k = s1, * v = op->src[2], * m = op->src[3];
+            if (op->src[4]) return false;                                        // sinks
+            float max_bias, softcap; memcpy(&max_bias, (const float *) op->op_params + 1, 4); memcpy(&softcap, (const float *) op->op_params + 2, 4);
+            if (max_bias != 0.0f || softcap != 0.0f) return false;
+            if (s0->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
+            if (s0->ne[0] != 64 || k->ne[0] != 64 || v->ne[0] != 64) return false;
+            if (s0->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return false;
+            if (s0->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2) return false;
+            if ((s0->nb[1] | s0->nb[2] | k->nb[1] | k->nb[2] | v->nb[1] | v->nb[2]) % 16) return false;
+            if (m && (m->type != GGML_TYPE_F16 || m->ne[2] != 1 || m->ne[3] != 1 || m->nb[0] != 2)) return false;
+            return true;
+        }
+        case GGML_OP_ADD: case GGML_OP_MUL:
+            return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_F32 && ggml_are_same_shape(op, s0);
+        case GGML_OP_SCALE:
+            return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && ggml_is_contiguous(op) && ggml_is_contiguous(s0);
+        case GGML_OP_UNARY:
+            return ggml_get_unary_op(op) == GGML_UNARY_OP_GELU && op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && ggml_is_contiguous(op) && ggml_is_contiguous(s0);
+        case GGML_OP_NORM:
+            return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s0->nb[0] == 4 && op->nb[0] == 4;
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP:
+            return (s0->type == GGML_TYPE_F32 || s0->type == GGML_TYPE_F16) && (op->type == GGML_TYPE_F32 || op->type == GGML_TYPE_F16);
+        case GGML_OP_GET_ROWS:
+            if (op->type != GGML_TYPE_F32 || s1->type != GGML_TYPE_I32) return false;
+            if (is_quant_type(s0->type)) return whole_quant_ok(s0) && s0->ne[2] == 1 && s0->ne[3] == 1 && (op->nb[1] % 16 == 0);
+            return s0->type == GGML_TYPE_F32 || s0->type == GGML_TYPE_F16;
+        case GGML_OP_IM2COL: {
+            const bool is_2d = op->op_params[6] == 1;
+            return !is_2d && s1->type == GGML_TYPE_F32 && s1->nb[0] == 4 && (op->type == GGML_TYPE_F16 || op->type == GGML_TYPE_F32) && s1->ne[3] == 1;
+        }
+        case GGML_OP_SOFT_MAX:
+            return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && !op->src[2] && s0->nb[0] == 4 &&
+                   (!s1 || ((s1->type == GGML_TYPE_F32 || s1->type == GGML_TYPE_F16) && s1->ne[0] == s0->ne[0]));
+        case GGML_OP_ROPE: {
+            const int mode = op->op_params[2];
+            return (mode == 0 || mode == 2) && op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s0->nb[0] == 4 && op->op_params[15] == 0;
+        }
+        case GGML_OP_CONCAT:
+            return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_F32;
+        default:
+            return false;
+    }
+}
+
+static int run_node(mi_backend_ctx * b, const ggml_tensor * n) {
+    mi355x_ctx * k = b->k;
+    switch (n->op) {
+        case GGML_OP_ADD: case GGML_OP_MUL: {
+            mi355x_tensor a = to_mt(n->src[0]), c = to_mt(n->src[1]), d = to_mt(n);
+            return mi355x_binary(k, n->op == GGML_OP_ADD ? 0 : 1, &a, &c, &d);
+        }
+        case GGML_OP_SCALE: {
+            mi355x_tensor a = to_mt(n->src[0]), d = to_mt(n);
+            return mi355x_scale(k, &a, &d, ggml_get_op_params_f32(n, 0), ggml_get_op_params_f32(n, 1));
+        }
+        case GGML_OP_UNARY: {
+            mi355x_tensor a = to_mt(n->src[0]), d = to_mt(n);
+            return mi355x_gelu(k, &a, &d);
+        }
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
+            mi355x_tensor a = to_mt(n->src[0]), d = to_mt(n);
+            return mi355x_cpy(k, &a, &d);
+        }
+        case GGML_OP_GET_ROWS: {
+            mi355x_tensor a = to_mt(n->src[0]), i = to_mt(n->src[1]), d = to_mt(n);
+            return mi355x_get_rows(k, &a, &i, &d);
+        }
+        case GGML_OP_IM2COL: {
+            mi355x_tensor x = to_mt(n->src[1]), d = to_mt(n);
+            return mi355x_im2col_1d(k, &x, &d, (int) n->src[0]->ne[0], n->op_params[0], n->op_params[2], n->op_params[4]);
+        }
+        case GGML_OP_SOFT_MAX: {
+            mi355x_tensor x = to_mt(n->src[0]), d = to_mt(n), m;
+            if (n->src[1]) m = to_mt(n->src[1]);
+            return mi355x_soft_max(k, &x, n->src[1] ? &m : nullptr, &d, ggml_get_op_params_f32(n, 0), ggml_get_op_params_f32(n, 1));
+        }
+        case GGML_OP_ROPE: {
+            mi355x_rope_params p;
+            p.n_dims = n->op_params[1]; p.mode = n->op_params[2]; p.n_ctx_orig = n->op_params[4];
+            memcpy(&p.freq_base, n->op_params + 5, 4); memcpy(&p.freq_scale, n->op_params + 6, 4); memcpy(&p.ext_factor, n->op_params + 7, 4);
+            memcpy(&p.attn_factor, n->op_params + 8, 4); memcpy(&p.beta_fast, n->op_params + 9, 4); memcpy(&p.beta_slow, n->op_params + 10, 4);
+            mi355x_tensor x = to_mt(n->src[0]), pos = to_mt(n->src[1]), d = to_mt(n);
+            return mi355x_rope(k, &x, &pos, n->src[2] ? (const float *) n->src[2]->data : nullptr, &d, &p);
+        }
+        case GGML_OP_CONCAT: {
+            mi355x_tensor a = to_mt(n->src[0]), c = to_mt(n->src[1]), d = to_mt(n);
+            return mi355x_concat(k, &a, &c, &d, n->op_params[0]);
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {
+            mi355x_tensor q = to_mt(n->src[0]), kk = to_mt(n->src[1]), v = to_mt(n->src[2]), d = to_mt(n), m;
+            if (n->src[3]) m = to_mt(n->src[3]);
+            float scale; memcpy(&scale, n->op_params, 4);
+            return mi355x_flash_attn_ext(k, &q, &kk, &v, n->src[3] ? &m : nullptr, &d, scale);
+        }
+        default:
+            return MI355X_E_UNSUPPORTED;
+    }
+}
+
+// walk the graph and emit kernels (eagerly, or into the context's launch record)
+static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
+    b->act_src = nullptr;
+    for (int i = 0; i < g->n_nodes; i++) {
+        const ggml_tensor * n = g->nodes[i];
+        if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
+        int rc = MI355X_E_UNSUPPORTED;
+        if (n->op == GGML_OP_MUL_MAT) {
+            mm_chain c;
+            parse_mm_chain(g, i, b->fuse, c);
+            rc = run_mm_chain(b, c);
+            if (rc == MI355X_E_UNSUPPORTED && c.end != i) { parse_mm_chain(g, i, false, c); rc = run_mm_chain(b, c); }
+            else i = c.end;
+        } else if (n->op == GGML_OP_NORM) {
+            ln_chain c;
+            parse_ln_chain(g, i, b->fuse, c);
+            int end = 0, rc2 = 0;
+            if (b->fuse && try_ln_gemv(b, g, c, end, rc2)) { rc = rc2; i = end; }
+            else {
+                rc = run_ln_chain(b, c);
+                if (rc == MI355X_E_UNSUPPORTED && c.end != i) { parse_ln_chain(g, i, false, c); rc = run_ln_chain(b, c); }
+                else i = c.end;
+                b->act_src = nullptr;
+            }
+        } else {
+            rc = run_node(b, n);
+            b->act_src = nullptr;
+        }
+        if (rc != 0) {
+            GGML_LOG_ERROR("ggml-mi355x: op %s (%s) failed: rc=%d %s\n", ggml_op_name(n->op), n->name, rc, mi355x_last_error());
+            return rc;
+        }
+    }
+    return 0;
+}
+
+// ---- hipGraph replay ----------------------------------------------------------------------------------
+static bool same_shape(const mi355x_launch & a, const mi355x_launch & b) {
+    return a.func == b.func && a.arg_size == b.arg_size && a.shmem == b.shmem &&
+           !memcmp(a.block, b.block, sizeof(a.block));
+}
+
+static int mi_run_recorded(mi_backend_ctx * b, const mi355x_launch * L, int n, const uint8_t * blob, size_t blob_size) {
+    hipStream_t stream = (hipStream_t) mi355x_ctx_stream(b->k);
+    mi_graph_cache * gc = nullptr;
+    for (auto & c : b->gcache) if ((int) c.launches.size() == n) { gc = &c; break; }
+    bool rebuild = gc == nullptr;
+    if (gc) {
+        for (int i = 0; i < n && !rebuild; i++) if (!same_shape(gc->launches[i], L[i])) rebuild = true;
+    }
+    if (rebuild) {
+        if (!gc) {
+            if (b->gcache.size() >= 8) {            // bounded cache: drop the least used entry
+                size_t worst = 0;
+                for (size_t i = 1; i < b->gcache.size(); i++) if (b->gcache[i].hits < b->gcache[worst].hits) worst = i;
+                if (b->gcache[worst].exec)  (void) hipGraphExecDestroy(b->gcache[worst].exec);
+                if (b->gcache[worst].graph) (void) hipGraphDestroy(b->gcache[worst].graph);
+                b->gcache.erase(b->gcache.begin() + worst);
+            }
+            b->gcache.emplace_back();
+            gc = &b->gcache.back();
+        } else {
+            if (gc->exec)  (void) hipGraphExecDestroy(gc->exec);
+            if (gc->graph) (void) hipGraphDestroy(gc->graph);
+            gc->exec = nullptr; gc->graph = nullptr;
+        }
+        gc->launches.assign(L, L + n);
+        gc->blob.assign(blob, blob + blob_size);
+        gc->nodes.resize(n);
+        if (hipGraphCreate(&gc->graph, 0) != hipSuccess) return -2;
+        for (int i = 0; i < n; i++) {
+            hipKernelNodeParams p; memset(&p, 0, sizeof(p));
+            void * args[1] = { (void *) (gc->blob.data() + L[i].arg_offset) };
+            p.func = (void *) L[i].func;
+            p.gridDim = dim3(L[i].grid[0], L[i].grid[1], L[i].grid[2]);
+            p.blockDim = dim3(L[i].block[0], L[i].block[1], L[i].block[2]);
+            p.sharedMemBytes = L[i].shmem; p.kernelParams = args; p.extra = nullptr;
+            hipError_t e = hipGraphAddKernelNode(&gc->nodes[i], gc->graph, i ? &gc->nodes[i - 1] : nullptr, i ? 1 : 0, &p);
+            if (e != hipSuccess) { MI_LOG("hipGraphAddKernelNode failed: %s", hipGetErrorString(e)); return -2; }
+        }
+        hipError_t e = hipGraphInstantiate(&gc->exec, gc->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { MI_LOG("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return -2; }
+        b->n_rebuild++;
+    } else {
+        // patch the kernel nodes whose arguments or grid changed since the last replay
+        for (int i = 0; i < n; i++) {
+            const mi355x_launch & o = gc->launches[i];
+            const bool same = !memcmp(o.grid, L[i].grid, sizeof(o.grid)) &&
+                              !memcmp(gc->blob.data() + o.arg_offset, blob + L[i].arg_offset, L[i].arg_size);
+            if (same) continue;
+            memcpy(gc->blob.data() + o.arg_offset, blob + L[i].arg_offset, L[i].arg_size);
+            memcpy(gc->launches[i].grid, L[i].grid, sizeof(o.grid));
+            hipKernelNodeParams p; memset(&p, 0, sizeof(p));
+            void * args[1] = { (void *) (gc->blob.data() + o.arg_offset) };
+            p.func = (void *) o.func;
+            p.gridDim = dim3(L[i].grid[0], L[i].grid[1], L[i].grid[2]);
+            p.blockDim = dim3(o.block[0], o.block[1], o.block[2]);
+            p.sharedMemBytes = o.shmem; p.kernelParams = args; p.extra = nullptr;
+            hipError_t e = hipGraphExecKernelNodeSetParams(gc->exec, gc->nodes[i], &p);
+            if (e != hipSuccess) { MI_LOG("hipGraphExecKernelNodeSetParams failed: %s", hipGetErrorString(e)); return -2; }
+            b->n_update++;
+        }
+        b->n_replay++;
+    }
+    gc->hits++;
+    hipError_t e = hipGraphLaunch(gc->exec, stream);
+    if (e != hipSuccess) { MI_LOG("hipGraphLaunch failed: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+static const char * mi_backend_get_name(ggml_backend_t backend) { return ((mi_backend_ctx *) backend->context)->name.c_str(); }
+
+static void mi_backend_free(ggml_backend_t backend) {
+    mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
+    (void) hipSetDevice(b->device);
+    mi355x_ctx_synchronize(b->k);
+    if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 " replays=%" PRIu64 " node-updates=%" PRIu64 " rebuilds=%" PRIu64 "\n",
+                           b->name.c_str(), b->n_graph_compute, b->n_replay, b->n_update, b->n_rebuild);
+    for (auto & c : b->gcache) { if (c.exec) (void) hipGraphExecDestroy(c.exec); if (c.graph) (void) hipGraphDestroy(c.graph); }
+    if (b->act) (void) hipFree(b->act);
+    mi355x_ctx_destroy(b->k);
+    delete b;
+    delete backend;
+}
+
+static void mi_backend_synchronize(ggml_backend_t backend) {
+    mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
+    (void) hipSetDevice(b->device);
+    mi355x_ctx_synchronize(b->k);
+}
+
+static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
+    mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
+    if (hipSetDevice(b->device) != hipSuccess) return GGML_STATUS_FAILED;
+    b->n_graph_compute++;
+    // graphs pay off when the launch sequence is long and launch-bound (decoder step); profiling needs eager launches
+    const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32;
+    if (use_graph) {
+        mi355x_record_begin(b->k);
+        b->recording = true; b->record_abort = false;
+        int rc = mi_emit_graph(b, cgraph);
+        b->recording = false;
+        const mi355x_launch * L; const uint8_t * blob; size_t bsz;
+        const int n = mi355x_record_end(b->k, &L, &blob, &bsz);
+        if (rc != 0) return GGML_STATUS_FAILED;
+        if (n < 0 || b->record_abort) {
+            // a scratch buffer had to grow: this call runs eagerly, the next one records again
+        } else if (n > 0) {
+            rc = mi_run_recorded(b, L, n, blob, bsz);
+            if (rc == 0) return GGML_STATUS_SUCCESS;
+            MI_LOG("graph replay unavailable (rc=%d); falling back to eager launches", rc);
+            b->graphs = false;
+        } else return GGML_STATUS_SUCCESS;
+    }
+    return mi_emit_graph(b, cgraph) == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+}
+
+static const ggml_backend_i mi_backend_iface = {
+    /* .get_name            = */ mi_backend_get_name,
+    /* .free                = */ mi_backend_free,
+    /* .set_tensor_async    = */ nullptr,
+    /* .get_tensor_async    = */ nullptr,
+    /* .set_tensor_2d_async = */ nullptr,
+    /* .get_tensor_2d_async = */ nullptr,
+    /* .cpy_tensor_async    = */ nullptr,
+    /* .synchronize         = */ mi_backend_synchronize,
+    /* .graph_plan_create   = */ nullptr,
+    /* .graph_plan_free     = */ nullptr,
+    /* .graph_plan_update   = */ nullptr,
+    /* .graph_plan_compute  = */ nullptr,
+    /* .graph_compute       = */ mi_backend_graph_compute,
+    /* .event_record        = */ nullptr,
+    /* .event_wait          = */ nullptr,
+    /* .graph_optimize      = */ nullptr,
+};
+
+static ggml_guid_t mi_guid() {
+    static ggml_guid guid = { 0x6d, 0x69, 0x33, 0x35, 0x35, 0x78, 0x2d, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x2d, 0x77, 0x31 };
+    return &guid;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------------
+static const char * mi_dev_get_name(ggml_backend_dev_t dev) { return ((mi_device_ctx *) dev->context)->name.c_str(); }
+static const char * mi_dev_get_description(ggml_backend_dev_t dev) { return ((mi_device_ctx *) dev->context)->description.c_str(); }
+static void mi_dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
+    mi_device_ctx * d = (mi_device_ctx *) dev->context;
+    *free = 0; *total = 0;
+    if (hipSetDevice(d->index) == hipSuccess) (void) hipMemGetInfo(free, total);
+}
+static enum ggml_backend_dev_type mi_dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+static void mi_dev_get_props(ggml_backend_dev_t dev, ggml_backend_dev_props * props) {
+    props->name = mi_dev_get_name(dev); props->description = mi_dev_get_description(dev);
+    mi_dev_get_memory(dev, &props->memory_free, &props->memory_total);
+    props->type = GGML_BACKEND_DEVICE_TYPE_GPU; props->device_id = nullptr;
+    props->caps = { /* async */ false, /* host_buffer */ false, /* buffer_from_host_ptr */ false, /* events */ false, /* mmap */ false };
+}
+static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) {
+    mi_device_ctx * d = (mi_device_ctx *) dev->context;
+    mi355x_ctx * k = mi355x_ctx_create(d->index);
+    if (!k) { GGML_LOG_ERROR("ggml-mi355x: failed to create kernel context on device %d: %s\n", d->index, mi355x_last_error()); return nullptr; }
+    mi_backend_ctx * b = new mi_backend_ctx();
+    b->device = d->index; b->k = k; b->name = d->name;
+    b->fuse = env_flag("GGML_MI355X_FUSE", true); b->graphs = env_flag("GGML_MI355X_GRAPHS", true); b->prof = env_flag("GGML_MI355X_PROF", false);
+    if (b->prof) mi355x_prof_enable(k, 1);
+    return new ggml_backend{ mi_guid(), mi_backend_iface, dev, b };
+}
+static ggml_backend_buffer_type_t mi_dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi_device_ctx *) dev->context)->buft; }
+static bool mi_dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
+    const bool ok = mi_supports_op_impl(op);
+    if (!ok) MI_LOG("unsupported op %s (%s) type=%s", ggml_op_name(op->op), op->name, ggml_type_name(op->type));
+    return ok;
+}
+static bool mi_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    return buft->iface.get_name == mi_buft_get_name && buft->context == dev->context;
+}
+
+static const ggml_backend_device_i mi_dev_iface = {
+    /* .get_name             = */ mi_dev_get_name,
+    /* .get_description      = */ mi_dev_get_description,
+    /* .get_memory           = */ mi_dev_get_memory,
+    /* .get_type             = */ mi_dev_get_type,
+    /* .get_props            = */ mi_dev_get_props,
+    /* .init_backend         = */ mi_dev_init_backend,
+    /* .get_buffer_type      = */ mi_dev_get_buffer_type,
+    /* .get_host_buffer_type = */ nullptr,
+    /* .buffer_from_host_ptr = */ nullptr,
+    /* .supports_op          = */ mi_dev_supports_op,
+    /* .supports_buft        = */ mi_dev_supports_buft,
+    /* .offload_op           = */ nullptr,
+    /* .event_new            = */ nullptr,
+    /* .event_free           = */ nullptr,
+    /* .event_synchronize    = */ nullptr,
+};
+
+// ---------------------------------------------------------------------------------------------------
+// registry
+// ---------------------------------------------------------------------------------------------------
+static void mi_init_devices() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int n = mi355x_device_count();
+        if (n > MI_MAX_DEVICES) n = MI_MAX_DEVICES;
+        g_n_devices = n;
+        for (int i = 0; i < n; i++) {
+            hipDeviceProp_t p;
+            mi_device_ctx & d = g_device_ctx[i];
+            d.index = i; d.name = "MI355X" + std::to_string(i);
+            d.description = hipGetDeviceProperties(&p, i) == hipSuccess ? std::string(p.name) + " (" + p.gcnArchName + ")" : "AMD Instinct (gfx950)";
+            g_devices[i] = { mi_dev_iface, &g_reg, &d };
+            d.buft = { mi_buft_iface, &g_devices[i], &d };
+        }
+    });
+}
+
+static const char * mi_reg_get_name(ggml_backend_reg_t) { return "MI355X"; }
+static size_t mi_reg_get_device_count(ggml_backend_reg_t) { mi_init_devices(); return (size_t) g_n_devices; }
+static ggml_backend_dev_t mi_reg_get_device(ggml_backend_reg_t, size_t index) {
+    mi_init_devices();
+    GGML_ASSERT((int) index < g_n_devices);
+    return &g_devices[index];
+}
+
+static ggml_mi355x_feature g_features[] = {
+    { "ARCH", "gfx950" }, { "MFMA_F16", "1" }, { "DOT4_I8", "1" }, { "PLANAR_QUANT", "1" }, { "HIP_GRAPHS", "1" }, { nullptr, nullptr },
+};
+
+static mi_backend_ctx * as_ctx(void * backend) {
+    ggml_backend_t b = (ggml_backend_t) backend;
+    if (!b || b->iface.get_name != mi_backend_get_name) return nullptr;
+    return (mi_backend_ctx *) b->context;
+}
+
+extern "C" {
+
+ggml_mi355x_feature * ggml_backend_mi355x_get_features(void *) { return g_features; }
+
+void ggml_backend_mi355x_prof_enable(void * backend, int on) {
+    mi_backend_ctx * b = as_ctx(backend); if (!b) return;
+    b->prof = on != 0; mi355x_prof_enable(b->k, on);
+}
+void ggml_backend_mi355x_prof_reset(void * backend) { mi_backend_ctx * b = as_ctx(backend); if (b) mi355x_prof_reset(b->k); }
+int ggml_backend_mi355x_prof_report(void * backend, ggml_mi355x_prof_row * rows, int cap) {
+    mi_backend_ctx * b = as_ctx(backend); if (!b) return 0;
+    static_assert(sizeof(ggml_mi355x_prof_row) == sizeof(mi355x_prof_row), "row layout");
+    return mi355x_prof_report(b->k, (mi355x_prof_row *) rows, cap);
+}
+
+int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    int n = 0;
+    for (auto & r : g_buffers) {
+        if (r.device != device || r.buf->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) continue;
+        if (n < cap) { bases[n] = r.base; sizes[n] = r.size; }
+        n++;
+    }
+    return n;
+}
+
+static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    if (!strcmp(name, "ggml_backend_get_features"))           return (void *) ggml_backend_mi355x_get_features;
+    if (!strcmp(name, "ggml_backend_mi355x_prof_enable"))     return (void *) ggml_backend_mi355x_prof_enable;
+    if (!strcmp(name, "ggml_backend_mi355x_prof_reset"))      return (void *) ggml_backend_mi355x_prof_reset;
+    if (!strcmp(name, "ggml_backend_mi355x_prof_report"))     return (void *) ggml_backend_mi355x_prof_report;
+    if (!strcmp(name, "ggml_backend_mi355x_weight_buffers"))  return (void *) ggml_backend_mi355x_weight_buffers;
+    return nullptr;
+}
+
+static const ggml_backend_reg_i mi_reg_iface = {
+    /* .get_name         = */ mi_reg_get_name,
+    /* .get_device_count = */ mi_reg_get_device_count,
+    /* .get_device       = */ mi_reg_get_device,
+    /* .get_proc_address = */ mi_reg_get_proc_address,
+};
+
+void * ggml_backend_mi355x_reg(void) {
+    static std::once_flag once;
+    std::call_once(once, [] { g_reg = { GGML_BACKEND_API_VERSION, mi_reg_iface, nullptr }; });
+    return &g_reg;
+}
+
+void * ggml_backend_init(void) { return ggml_backend_mi355x_reg(); }
+
+int ggml_backend_score(void) { return mi355x_device_count() > 0 ? 100 : 0; }
+
+} // extern "C"

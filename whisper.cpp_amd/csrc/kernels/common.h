@@ -1,0 +1,237 @@
+// Internal header of libmi355x_kernels.so: context, launch emission, device helpers.
+// gfx950 only (wave64, MFMA, v_dot4_i32_i8).  No CUDA compatibility layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "mi355x_kernels.h"
+
+#define WAVE 64
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float    floatx4  __attribute__((ext_vector_type(4)));
+typedef float    floatx16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct prof_acc { uint64_t calls = 0; double ms = 0, bytes = 0, flops = 0; };
+
+struct mi355x_ctx {
+    int         device   = 0;
+    hipStream_t stream   = nullptr;
+    // constant tables
+    uint16_t *  gelu_tab = nullptr;      // 65536 x f16 (device)
+    // scratch arena (grown on demand; only touched from this ctx's stream, so reuse is stream-ordered)
+    void *      scratch      = nullptr;
+    size_t      scratch_size = 0;
+    size_t      scratch_used = 0;        // bump pointer, reset per op group
+    // recording
+    bool                        recording = false;
+    bool                        record_invalid = false;
+    std::vector<mi355x_launch>  plan;
+    std::vector<uint8_t>        blob;
+    // profiling
+    bool                                 prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    struct pending { const char * name; int ev; double bytes, flops; };
+    std::vector<pending>                 ev_pending;
+    std::map<std::string, prof_acc>      prof_rows;
+    int                                  n_cu = 256;
+};
+
+void   mi355x_set_error(const char * fmt, ...);
+// scratch: returns a device pointer valid until the NEXT mi355x_scratch_reset on this ctx
+void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes);
+void   mi355x_scratch_reset(mi355x_ctx * ctx);
+
+// emit one kernel launch (eager: hipLaunchKernel on ctx->stream; recording: append to plan)
+int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 grid, dim3 block, uint32_t shmem,
+                const void * args, uint32_t arg_size, double algo_bytes, double algo_flops);
+
+template <typename Args>
+static inline int emit(mi355x_ctx * ctx, const char * name, void (*kernel)(Args), dim3 grid, dim3 block, uint32_t shmem,
+                       const Args & a, double bytes = 0, double flops = 0) {
+    return mi355x_emit(ctx, name, (const void *) kernel, grid, block, shmem, &a, (uint32_t) sizeof(Args), bytes, flops);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tensor helpers (host)
+// ---------------------------------------------------------------------------------------------
+static inline int64_t t_nelements(const mi355x_tensor * t) { return t->ne[0]*t->ne[1]*t->ne[2]*t->ne[3]; }
+static inline int64_t t_nrows(const mi355x_tensor * t)     { return t->ne[1]*t->ne[2]*t->ne[3]; }
+static inline int     type_block(int type) {
+    switch (type) { case MI355X_TYPE_Q4_0: case MI355X_TYPE_Q5_0: case MI355X_TYPE_Q8_0: return 32; case MI355X_TYPE_Q4_K: return 256; default: return 1; }
+}
+static inline int     type_size(int type) {   // bytes per block
+    switch (type) {
+        case MI355X_TYPE_F32: case MI355X_TYPE_I32: return 4;
+        case MI355X_TYPE_F16: return 2;
+        case MI355X_TYPE_Q4_0: return 18; case MI355X_TYPE_Q5_0: return 22; case MI355X_TYPE_Q8_0: return 34; case MI355X_TYPE_Q4_K: return 144;
+        default: return 0;
+    }
+}
+static inline bool t_is_contiguous(const mi355x_tensor * t) {
+    int64_t nb = type_size(t->type);
+    if (t->nb[0] != nb) return false;
+    nb = nb * (t->ne[0] / type_block(t->type));
+    for (int i = 1; i < 4; i++) { if (t->ne[i] != 1 && t->nb[i] != nb) return false; nb *= t->ne[i]; }
+    return true;
+}
+static inline bool t_same_shape(const mi355x_tensor * a, const mi355x_tensor * b) {
+    return a->ne[0]==b->ne[0] && a->ne[1]==b->ne[1] && a->ne[2]==b->ne[2] && a->ne[3]==b->ne[3];
+}
+
+// device-side compact tensor view (by value in kernel args)
+struct dtensor {
+    char *  data;
+    int64_t ne[4];
+    int64_t nb[4];
+};
+static inline dtensor to_d(const mi355x_tensor * t) {
+    dtensor d; d.data = (char *) t->data;
+    for (int i = 0; i < 4; i++) { d.ne[i] = t->ne[i]; d.nb[i] = t->nb[i]; }
+    return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ float h2f(uint16_t h) { half_t x; __builtin_memcpy(&x, &h, 2); return (float) x; }
+__device__ __forceinline__ uint16_t f2h(float f) { half_t x = (half_t) f; uint16_t h; __builtin_memcpy(&h, &x, 2); return h; }
+__device__ __forceinline__ float round_f16(float f) { return (float) (half_t) f; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// spread the low 4 bits of b to bit 4 of each byte of a dword: bit k -> byte k, bit 4
+__device__ __forceinline__ uint32_t spread4_to_bit4(uint32_t b) {
+    return (((b & 0xFu) * 0x00204081u) & 0x01010101u) << 4;
+}
+
+// f16-table GELU exactly as ggml_vec_gelu_f32 (ggml-cpu/vec.h:987-1000)
+__device__ __forceinline__ float gelu_lut(float x, const uint16_t * __restrict__ tab) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >=  10.0f) return x;
+    return h2f(tab[f2h(x)]);
+}
+
+// ---- planar quantized layouts (see mi355x_kernels.h) -------------------------------------------
+// nbt = total number of blocks in the tensor
+template <int TYPE> struct qplanes;
+template <> struct qplanes<MI355X_TYPE_Q4_0> {
+    const uint8_t * qs; const uint16_t * d;
+    __device__ __forceinline__ qplanes(const void * base, int64_t nbt) { qs = (const uint8_t *) base; d = (const uint16_t *) (qs + nbt*16); }
+};
+template <> struct qplanes<MI355X_TYPE_Q5_0> {
+    const uint8_t * qs; const uint32_t * qh; const uint16_t * d;
+    __device__ __forceinline__ qplanes(const void * base, int64_t nbt) { qs = (const uint8_t *) base; qh = (const uint32_t *) (qs + nbt*16); d = (const uint16_t *) (qs + nbt*20); }
+};
+template <> struct qplanes<MI355X_TYPE_Q8_0> {
+    const uint8_t * qs; const uint16_t * d;
+    __device__ __forceinline__ qplanes(const void * base, int64_t nbt) { qs = (const uint8_t *) base; d = (const uint16_t *) (qs + nbt*32); }
+};
+template <> struct qplanes<MI355X_TYPE_Q4_K> {
+    const uint8_t * qs; const uint8_t * sc; const uint32_t * dm;
+    __device__ __forceinline__ qplanes(const void * base, int64_t nbt) { qs = (const uint8_t *) base; sc = qs + nbt*128; dm = (const uint32_t *) (qs + nbt*140); }
+};
+
+// Q4_K 6-bit scale/min extraction (get_scale_min_k4, ggml/src/ggml-quants.c:880-887); q = 12 scale bytes
+__device__ __forceinline__ void q4k_scale_min(int j, const uint8_t * q, int & sc, int & m) {
+    if (j < 4) { sc = q[j] & 63; m = q[j + 4] & 63; }
+    else       { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
+}
+
+// dequantize element-block helpers: write 32 floats of block `ib` (32-element granularity for all types;
+// for Q4_K `ib` indexes 32-element sub-blocks: super-block ib/8, sub-block ib%8)
+template <int TYPE>
+__device__ __forceinline__ void dequant_block32(const qplanes<TYPE> & p, int64_t ib, float * out);
+
+template <>
+__device__ __forceinline__ void dequant_block32<MI355X_TYPE_Q4_0>(const qplanes<MI355X_TYPE_Q4_0> & p, int64_t ib, float * out) {
+    const uint4 q = *(const uint4 *) (p.qs + ib*16);
+    const float d = h2f(p.d[ib]);
+    const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        #pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int byte = (w[i] >> (8*b)) & 0xFF;
+            out[4*i + b]      = (float) ((byte & 0xF) - 8) * d;     // dequantize_row_q4_0, ggml-quants.c:459-477
+            out[4*i + b + 16] = (float) ((byte >> 4)  - 8) * d;
+        }
+    }
+}
+template <>
+__device__ __forceinline__ void dequant_block32<MI355X_TYPE_Q5_0>(const qplanes<MI355X_TYPE_Q5_0> & p, int64_t ib, float * out) {
+    const uint4 q = *(const uint4 *) (p.qs + ib*16);
+    const uint32_t qh = p.qh[ib];
+    const float d = h2f(p.d[ib]);
+    const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        #pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int j = 4*i + b;
+            const int byte = (w[i] >> (8*b)) & 0xFF;
+            const int h0 = ((qh >> j) & 1) << 4;                     // dequantize_row_q5_0, ggml-quants.c:500-524
+            const int h1 = ((qh >> (j + 16)) & 1) << 4;
+            out[j]      = (float) (((byte & 0xF) | h0) - 16) * d;
+            out[j + 16] = (float) (((byte >> 4)  | h1) - 16) * d;
+        }
+    }
+}
+template <>
+__device__ __forceinline__ void dequant_block32<MI355X_TYPE_Q8_0>(const qplanes<MI355X_TYPE_Q8_0> & p, int64_t ib, float * out) {
+    const uint4 q0 = *(const uint4 *) (p.qs + ib*32);
+    const uint4 q1 = *(const uint4 *) (p.qs + ib*32 + 16);
+    const float d = h2f(p.d[ib]);
+    const uint32_t w[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        #pragma unroll
+        for (int b = 0; b < 4; b++) out[4*i + b] = (float) (int8_t) ((w[i] >> (8*b)) & 0xFF) * d;   // ggml-quants.c:553-567
+    }
+}
+template <>
+__device__ __forceinline__ void dequant_block32<MI355X_TYPE_Q4_K>(const qplanes<MI355X_TYPE_Q4_K> & p, int64_t ib, float * out) {
+    const int64_t sb = ib >> 3; const int j = (int) (ib & 7);
+    const uint32_t dm = p.dm[sb];
+    const float d = h2f((uint16_t) (dm & 0xFFFF)), dmin = h2f((uint16_t) (dm >> 16));
+    int sc, m; q4k_scale_min(j, p.sc + sb*12, sc, m);
+    const float d1 = d * sc, m1 = dmin * m;                          // dequantize_row_q4_K, ggml-quants.c:1529-1551
+    const uint8_t * qs = p.qs + sb*128 + (j >> 1)*32;
+    const uint4 q0 = *(const uint4 *) qs, q1 = *(const uint4 *) (qs + 16);
+    const uint32_t w[8] = { q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w };
+    const int sh = (j & 1) * 4;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        #pragma unroll
+        for (int b = 0; b < 4; b++) out[4*i + b] = d1 * (float) ((w[i] >> (8*b + sh)) & 0xF) - m1;
+    }
+}
+
+#endif // __HIPCC__

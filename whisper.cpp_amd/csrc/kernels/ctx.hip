@@ -1,0 +1,225 @@
+// Context, launch emission, profiling, host-side re-layout of quantized blocks.
+#include "common.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+static thread_local char g_err[512] = "";
+
+void mi355x_set_error(const char * fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+    if (getenv("GGML_MI355X_DEBUG")) fprintf(stderr, "mi355x: %s\n", g_err);
+}
+extern "C" const char * mi355x_last_error(void) { return g_err; }
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mi355x_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return (int) e_; } } while (0)
+
+extern "C" int mi355x_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) != hipSuccess) continue;
+        if (strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+        else return ok;   // devices are homogeneous on the target nodes; stop at the first foreign one
+    }
+    return ok;
+}
+
+// f32 GELU exactly as ggml_gelu_f32 (ggml-cpu/vec.h:968-970); evaluated on the HOST so that the table is
+// produced by the same libm tanhf as the reference's ggml_table_gelu_f16 (ggml-cpu/ggml-cpu.c table init)
+static inline float gelu_f32_host(float x) {
+    const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    return 0.5f*x*(1.0f + tanhf(SQRT_2_OVER_PI*x*(1.0f + GELU_COEF_A*x*x)));
+}
+
+extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { mi355x_set_error("no HIP device %d", device); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    mi355x_ctx * ctx = new mi355x_ctx();
+    ctx->device = device;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) ctx->n_cu = p.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    std::vector<uint16_t> tab(65536);
+    for (int i = 0; i < 65536; i++) {
+        uint16_t h = (uint16_t) i; _Float16 x; memcpy(&x, &h, 2);
+        _Float16 y = (_Float16) gelu_f32_host((float) x);
+        memcpy(&tab[i], &y, 2);
+    }
+    if (hipMalloc((void **) &ctx->gelu_tab, 65536*2) != hipSuccess ||
+        hipMemcpy(ctx->gelu_tab, tab.data(), 65536*2, hipMemcpyHostToDevice) != hipSuccess) {
+        mi355x_set_error("gelu table upload failed"); (void) hipStreamDestroy(ctx->stream); delete ctx; return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    for (auto & e : ctx->ev_pool) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
+    if (ctx->scratch)  (void) hipFree(ctx->scratch);
+    if (ctx->gelu_tab) (void) hipFree(ctx->gelu_tab);
+    (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" void * mi355x_ctx_stream(mi355x_ctx * ctx) { return (void *) ctx->stream; }
+
+static void prof_drain(mi355x_ctx * ctx) {
+    for (auto & p : ctx->ev_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[p.ev].first, ctx->ev_pool[p.ev].second) == hipSuccess) {
+            prof_acc & a = ctx->prof_rows[p.name];
+            a.calls++; a.ms += ms; a.bytes += p.bytes; a.flops += p.flops;
+        }
+    }
+    ctx->ev_pending.clear();
+}
+
+extern "C" int mi355x_ctx_synchronize(mi355x_ctx * ctx) {
+    (void) hipSetDevice(ctx->device);
+    HIP_OK(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) prof_drain(ctx);
+    return 0;
+}
+
+// ---- scratch -----------------------------------------------------------------------------------
+void mi355x_scratch_reset(mi355x_ctx * ctx) { ctx->scratch_used = 0; }
+
+void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t) 255;
+    if (ctx->scratch_used + bytes > ctx->scratch_size) {
+        // grow: allocate a new arena; the old one may still be in use by enqueued kernels, so drain first.
+        // (happens a handful of times during warm-up, never in steady state)
+        size_t want = ctx->scratch_used + bytes;
+        size_t nsz = ctx->scratch_size ? ctx->scratch_size : ((size_t) 64 << 20);
+        while (nsz < want) nsz *= 2;
+        (void) hipStreamSynchronize(ctx->stream);
+        void * nptr = nullptr;
+        if (hipMalloc(&nptr, nsz) != hipSuccess) { mi355x_set_error("scratch alloc of %zu bytes failed", nsz); return nullptr; }
+        if (ctx->scratch) (void) hipFree(ctx->scratch);
+        ctx->scratch = nptr; ctx->scratch_size = nsz; ctx->scratch_used = 0;
+        if (ctx->recording) { mi355x_set_error("scratch grew while recording; plan invalid"); ctx->record_invalid = true; }
+    }
+    void * p = (char *) ctx->scratch + ctx->scratch_used;
+    ctx->scratch_used += bytes;
+    return p;
+}
+
+// ---- emission ----------------------------------------------------------------------------------
+int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 grid, dim3 block, uint32_t shmem,
+                const void * args, uint32_t arg_size, double algo_bytes, double algo_flops) {
+    if (grid.x == 0 || grid.y == 0 || grid.z == 0) return 0;
+    if (ctx->recording) {
+        mi355x_launch l;
+        l.func = func; l.grid[0] = grid.x; l.grid[1] = grid.y; l.grid[2] = grid.z;
+        l.block[0] = block.x; l.block[1] = block.y; l.block[2] = block.z;
+        l.shmem = shmem; l.arg_size = arg_size;
+        size_t off = (ctx->blob.size() + 15) & ~(size_t) 15;
+        ctx->blob.resize(off + arg_size);
+        memcpy(ctx->blob.data() + off, args, arg_size);
+        l.arg_offset = off; l.name = name; l.algo_bytes = algo_bytes; l.algo_flops = algo_flops;
+        ctx->plan.push_back(l);
+        return 0;
+    }
+    int ev = -1;
+    if (ctx->prof) {
+        ev = (int) ctx->ev_pending.size();
+        if (ev >= (int) ctx->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+            ctx->ev_pool.push_back({a, b});
+        }
+        HIP_OK(hipEventRecord(ctx->ev_pool[ev].first, ctx->stream));
+    }
+    void * kargs[1] = { (void *) args };
+    hipError_t e = hipLaunchKernel(func, grid, block, kargs, shmem, ctx->stream);
+    if (e != hipSuccess) { mi355x_set_error("launch of %s failed: %s", name, hipGetErrorString(e)); return (int) e; }
+    if (ctx->prof) {
+        HIP_OK(hipEventRecord(ctx->ev_pool[ev].second, ctx->stream));
+        ctx->ev_pending.push_back({name, ev, algo_bytes, algo_flops});
+        if (ctx->ev_pending.size() >= 4096) { HIP_OK(hipStreamSynchronize(ctx->stream)); prof_drain(ctx); }
+    }
+    return 0;
+}
+
+extern "C" void mi355x_record_begin(mi355x_ctx * ctx) { ctx->recording = true; ctx->record_invalid = false; ctx->plan.clear(); ctx->blob.clear(); }
+extern "C" int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size) {
+    ctx->recording = false;
+    if (ctx->record_invalid) { *launches = nullptr; *arg_blob = nullptr; *blob_size = 0; return -1; }
+    *launches = ctx->plan.data(); *arg_blob = ctx->blob.data(); *blob_size = ctx->blob.size();
+    return (int) ctx->plan.size();
+}
+
+extern "C" void mi355x_prof_enable(mi355x_ctx * ctx, int on) { ctx->prof = on != 0; }
+extern "C" void mi355x_prof_reset(mi355x_ctx * ctx) { (void) hipStreamSynchronize(ctx->stream); prof_drain(ctx); ctx->prof_rows.clear(); }
+extern "C" int  mi355x_prof_report(mi355x_ctx * ctx, mi355x_prof_row * rows, int cap) {
+    (void) hipStreamSynchronize(ctx->stream);
+    prof_drain(ctx);
+    int n = 0;
+    for (auto & kv : ctx->prof_rows) {
+        if (n >= cap) break;
+        rows[n].name = kv.first.c_str(); rows[n].calls = kv.second.calls; rows[n].total_ms = kv.second.ms;
+        rows[n].algo_bytes = kv.second.bytes; rows[n].algo_flops = kv.second.flops;
+        n++;
+    }
+    return n;
+}
+
+extern "C" int mi355x_memset(mi355x_ctx * ctx, void * dptr, int value, size_t n) {
+    (void) hipSetDevice(ctx->device);
+    HIP_OK(hipMemsetAsync(dptr, value, n, ctx->stream));
+    return 0;
+}
+
+// ---- host re-layout ------------------------------------------------------------------------------
+extern "C" int mi355x_type_is_quantized(int type) {
+    return type == MI355X_TYPE_Q4_0 || type == MI355X_TYPE_Q5_0 || type == MI355X_TYPE_Q8_0 || type == MI355X_TYPE_Q4_K;
+}
+extern "C" size_t mi355x_type_row_bytes(int type, int64_t ne0) {
+    const int bs = type_block(type), ts = type_size(type);
+    if (!ts || ne0 % bs) return 0;
+    return (size_t) (ne0 / bs) * ts;
+}
+
+// ggml block structs (ggml/src/ggml-common.h): q4_0 {f16 d; u8 qs[16]}, q5_0 {f16 d; u8 qh[4]; u8 qs[16]},
+// q8_0 {f16 d; i8 qs[32]}, q4_K {f16 d; f16 dmin; u8 scales[12]; u8 qs[128]}
+template <bool TO_PLANAR>
+static int repack(int type, const uint8_t * a, uint8_t * b, int64_t nelements) {
+    const int bs = type_block(type);
+    if (bs == 1 || nelements % bs) return MI355X_E_UNSUPPORTED;
+    const int64_t nb = nelements / bs;
+    // `blk` points into the ggml-struct side, plane pointers into the planar side
+    const uint8_t * src = a; uint8_t * dst = b;
+    auto cp = [&](int64_t blk_off, int64_t plane_off, size_t n) {
+        if (TO_PLANAR) memcpy(dst + plane_off, src + blk_off, n);
+        else           memcpy(dst + blk_off, src + plane_off, n);
+    };
+    switch (type) {
+        case MI355X_TYPE_Q4_0:
+            for (int64_t i = 0; i < nb; i++) { cp(i*18 + 2, i*16, 16); cp(i*18, nb*16 + i*2, 2); }
+            return 0;
+        case MI355X_TYPE_Q5_0:
+            for (int64_t i = 0; i < nb; i++) { cp(i*22 + 6, i*16, 16); cp(i*22 + 2, nb*16 + i*4, 4); cp(i*22, nb*20 + i*2, 2); }
+            return 0;
+        case MI355X_TYPE_Q8_0:
+            for (int64_t i = 0; i < nb; i++) { cp(i*34 + 2, i*32, 32); cp(i*34, nb*32 + i*2, 2); }
+            return 0;
+        case MI355X_TYPE_Q4_K:
+            for (int64_t i = 0; i < nb; i++) { cp(i*144 + 16, i*128, 128); cp(i*144 + 4, nb*128 + i*12, 12); cp(i*144, nb*140 + i*4, 4); }
+            return 0;
+        default: return MI355X_E_UNSUPPORTED;
+    }
+}
+extern "C" int mi355x_repack_to_planar(int type, const void * ggml_blocks, void * planar, int64_t nelements) {
+    return repack<true>(type, (const uint8_t *) ggml_blocks, (uint8_t *) planar, nelements);
+}
+extern "C" int mi355x_repack_from_planar(int type, const void * planar, void * ggml_blocks, int64_t nelements) {
+    return repack<false>(type, (const uint8_t *) planar, (uint8_t *) ggml_blocks, nelements);
+}

@@ -1,0 +1,416 @@
+// Bandwidth-class ops of the whisper graphs: add/mul (broadcast), scale, gelu, norm(+affine), cpy/cont/cast,
+// get_rows, im2col(1-D), soft_max, rope, concat.  All HBM/L2-bound: coalesced 16-byte accesses on the
+// contiguous fast paths, wave64 reductions, no LDS except block reductions.
+#include "common.h"
+#include <math.h>
+
+// -------------------------------------------------------------------------------------------------
+// binary add/mul with ggml broadcasting of src1 (ggml-cpu/binary-ops.cpp:140-148)
+// -------------------------------------------------------------------------------------------------
+struct BinArgs { dtensor a, b, d; int op; int64_t nchunk0; };
+
+template <int OP> __device__ __forceinline__ float bin_op(float x, float y) { return OP == 0 ? x + y : x * y; }
+
+// generic: one thread per element of a row chunk; rows flattened into blockIdx.x
+__global__ void __launch_bounds__(256) k_bin_generic(const BinArgs a) {
+    const int64_t row = blockIdx.x / a.nchunk0;
+    const int64_t i0  = (blockIdx.x % a.nchunk0) * 256 + threadIdx.x;
+    if (i0 >= a.d.ne[0]) return;
+    const int64_t i1 = row % a.d.ne[1], i2 = (row / a.d.ne[1]) % a.d.ne[2], i3 = row / (a.d.ne[1]*a.d.ne[2]);
+    const float x = *(const float *) (a.a.data + i0*a.a.nb[0] + i1*a.a.nb[1] + i2*a.a.nb[2] + i3*a.a.nb[3]);
+    const float y = *(const float *) (a.b.data + (i0 % a.b.ne[0])*a.b.nb[0] + (i1 % a.b.ne[1])*a.b.nb[1] + (i2 % a.b.ne[2])*a.b.nb[2] + (i3 % a.b.ne[3])*a.b.nb[3]);
+    float * o = (float *) (a.d.data + i0*a.d.nb[0] + i1*a.d.nb[1] + i2*a.d.nb[2] + i3*a.d.nb[3]);
+    *o = a.op == 0 ? x + y : x * y;
+}
+
+// fast path: a, d contiguous f32 with ne0 % 4 == 0; b either same-shape contiguous (bmode 0) or a
+// contiguous row vector of ne0 broadcast over all rows (bmode 1)
+struct BinFastArgs { const float * a; const float * b; float * d; int64_t n4; int64_t ne0_4; int op; int bmode; };
+__global__ void __launch_bounds__(256) k_bin_fast(const BinFastArgs a) {
+    const float4 * pa = (const float4 *) a.a; const float4 * pb = (const float4 *) a.b; float4 * pd = (float4 *) a.d;
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t) gridDim.x * 256) {
+        const float4 x = pa[i];
+        const float4 y = a.bmode == 0 ? pb[i] : pb[i % a.ne0_4];
+        float4 r;
+        if (a.op == 0) { r.x = x.x + y.x; r.y = x.y + y.y; r.z = x.z + y.z; r.w = x.w + y.w; }
+        else           { r.x = x.x * y.x; r.y = x.y * y.y; r.z = x.z * y.z; r.w = x.w * y.w; }
+        pd[i] = r;
+    }
+}
+
+extern "C" int mi355x_binary(mi355x_ctx * ctx, int op, const mi355x_tensor * a, const mi355x_tensor * b, const mi355x_tensor * d) {
+    if (a->type != MI355X_TYPE_F32 || b->type != MI355X_TYPE_F32 || d->type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
+    if (!t_same_shape(a, d)) return MI355X_E_UNSUPPORTED;
+    for (int i = 0; i < 4; i++) if (b->ne[i] <= 0 || d->ne[i] % b->ne[i]) return MI355X_E_UNSUPPORTED;
+    const int64_t n = t_nelements(d);
+    if (n == 0) return 0;
+    const bool ca = t_is_contiguous(a) && t_is_contiguous(d) && (d->ne[0] % 4 == 0) &&
+                    ((uintptr_t) a->data % 16 == 0) && ((uintptr_t) d->data % 16 == 0) && ((uintptr_t) b->data % 16 == 0);
+    if (ca && t_is_contiguous(b)) {
+        int bmode = -1;
+        if (t_same_shape(a, b)) bmode = 0;
+        else if (b->ne[0] == d->ne[0] && t_nrows(b) == 1) bmode = 1;
+        if (bmode >= 0) {
+            BinFastArgs k = { (const float *) a->data, (const float *) b->data, (float *) d->data, n/4, d->ne[0]/4, op, bmode };
+            const int64_t nb = (n/4 + 255) / 256;
+            const int grid = (int) (nb < 4096 ? nb : 4096);
+            return emit(ctx, op == 0 ? "add" : "mul", k_bin_fast, dim3(grid), dim3(256), 0, k, (double) n * (bmode == 0 ? 12 : 8), 0);
+        }
+    }
+    BinArgs k = { to_d(a), to_d(b), to_d(d), op, (d->ne[0] + 255) / 256 };
+    const int64_t nblocks = k.nchunk0 * t_nrows(d);
+    if (nblocks > 0x7fffffffLL) return MI355X_E_UNSUPPORTED;
+    return emit(ctx, op == 0 ? "add" : "mul", k_bin_generic, dim3((uint32_t) nblocks), dim3(256), 0, k, (double) n * 12, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// scale (ggml-cpu/ops.cpp:4568-4620): y = x*s + b   (s*x first, then +b when b != 0 — ggml_vec_mad1_f32)
+// gelu  (ggml-cpu/vec.h:987-1000)
+// -------------------------------------------------------------------------------------------------
+struct UnaryArgs { const float * x; float * y; int64_t n; float s, b; int mode; const uint16_t * tab; };
+__global__ void __launch_bounds__(256) k_unary(const UnaryArgs a) {
+    for (int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (int64_t) gridDim.x * 1024) {
+        float v[4];
+        if (i + 4 <= a.n && ((uintptr_t) (a.x + i) % 16 == 0) && ((uintptr_t) (a.y + i) % 16 == 0)) {
+            const float4 x = *(const float4 *) (a.x + i);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            #pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = a.mode == 0 ? (a.b == 0.0f ? v[j]*a.s : v[j]*a.s + a.b) : gelu_lut(v[j], a.tab);
+            *(float4 *) (a.y + i) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int j = 0; j < 4 && i + j < a.n; j++) {
+                const float x = a.x[i + j];
+                a.y[i + j] = a.mode == 0 ? (a.b == 0.0f ? x*a.s : x*a.s + a.b) : gelu_lut(x, a.tab);
+            }
+        }
+    }
+}
+static int unary_launch(mi355x_ctx * ctx, const char * name, const mi355x_tensor * x, const mi355x_tensor * y, int mode, float s, float b) {
+    if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || !t_is_contiguous(x) || !t_is_contiguous(y) || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
+    const int64_t n = t_nelements(x);
+    if (n == 0) return 0;
+    UnaryArgs k = { (const float *) x->data, (float *) y->data, n, s, b, mode, ctx->gelu_tab };
+    const int64_t nb = (n + 1023) / 1024;
+    return emit(ctx, name, k_unary, dim3((uint32_t) (nb < 4096 ? nb : 4096)), dim3(256), 0, k, (double) n * 8, 0);
+}
+extern "C" int mi355x_scale(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y, float s, float b) { return unary_launch(ctx, "scale", x, y, 0, s, b); }
+extern "C" int mi355x_gelu(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y) { return unary_launch(ctx, "gelu", x, y, 1, 0, 0); }
+
+// -------------------------------------------------------------------------------------------------
+// norm (+ optional affine): one wave per row (ggml-cpu/ops.cpp:3698-3765)
+//   mean = sum/n ; var = sum((x-mean)^2)/n ; y = (x-mean) * (1/sqrtf(var+eps)) [* w + b as separate roundings]
+// -------------------------------------------------------------------------------------------------
+struct NormArgs { dtensor x, y; float eps; const float * w; const float * b; int64_t nrows; };
+__global__ void __launch_bounds__(256) k_norm(const NormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.nrows) return;
+    const int64_t i1 = row % a.x.ne[1], i2 = (row / a.x.ne[1]) % a.x.ne[2], i3 = row / (a.x.ne[1]*a.x.ne[2]);
+    const float * x = (const float *) (a.x.data + i1*a.x.nb[1] + i2*a.x.nb[2] + i3*a.x.nb[3]);
+    float * y = (float *) (a.y.data + i1*a.y.nb[1] + i2*a.y.nb[2] + i3*a.y.nb[3]);
+    const int n = (int) a.x.ne[0];
+    float s = 0.0f;
+    for (int i = lane; i < n; i += 64) s += x[i];
+    s = wave_sum(s);
+    const float mean = s / n;
+    float v = 0.0f;
+    for (int i = lane; i < n; i += 64) { const float d = x[i] - mean; v += d*d; }
+    v = wave_sum(v);
+    const float var = v / n;
+    const float sc = 1.0f / sqrtf(var + a.eps);
+    for (int i = lane; i < n; i += 64) {
+        float r = (x[i] - mean) * sc;
+        if (a.w) r = r * a.w[i];
+        if (a.b) r = r + a.b[i];
+        y[i] = r;
+    }
+}
+extern "C" int mi355x_norm(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y, float eps, const float * w, const float * b) {
+    if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
+    NormArgs k = { to_d(x), to_d(y), eps, w, b, t_nrows(x) };
+    if (k.nrows == 0 || x->ne[0] == 0) return 0;
+    return emit(ctx, "norm", k_norm, dim3((uint32_t) ((k.nrows + 3) / 4)), dim3(256), 0, k, (double) t_nelements(x) * 8, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// cpy / cont / dup / cast between F32 and F16 (ggml-cpu/ops.cpp:17-654): element i of src (in src's
+// logical order) goes to element i of dst (in dst's logical order); shapes may differ, counts equal.
+// -------------------------------------------------------------------------------------------------
+struct CpyArgs { dtensor s, d; int64_t n; int st, dt; };
+template <int ST, int DT>
+__global__ void __launch_bounds__(256) k_cpy_generic(const CpyArgs a) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t) gridDim.x * 256) {
+        int64_t r = i;
+        const int64_t s0 = r % a.s.ne[0]; r /= a.s.ne[0];
+        const int64_t s1 = r % a.s.ne[1]; r /= a.s.ne[1];
+        const int64_t s2 = r % a.s.ne[2]; const int64_t s3 = r / a.s.ne[2];
+        r = i;
+        const int64_t d0 = r % a.d.ne[0]; r /= a.d.ne[0];
+        const int64_t d1 = r % a.d.ne[1]; r /= a.d.ne[1];
+        const int64_t d2 = r % a.d.ne[2]; const int64_t d3 = r / a.d.ne[2];
+        const char * ps = a.s.data + s0*a.s.nb[0] + s1*a.s.nb[1] + s2*a.s.nb[2] + s3*a.s.nb[3];
+        char * pd = a.d.data + d0*a.d.nb[0] + d1*a.d.nb[1] + d2*a.d.nb[2] + d3*a.d.nb[3];
+        float v;
+        if (ST == MI355X_TYPE_F32) v = *(const float *) ps; else v = h2f(*(const uint16_t *) ps);
+        if (DT == MI355X_TYPE_F32) *(float *) pd = v;
+        else if (ST == MI355X_TYPE_F16) *(uint16_t *) pd = *(const uint16_t *) ps;
+        else *(uint16_t *) pd = f2h(v);
+    }
+}
+// contiguous fast path, 4 elements per thread
+struct CpyFastArgs { const void * s; void * d; int64_t n; };
+template <int ST, int DT>
+__global__ void __launch_bounds__(256) k_cpy_contig(const CpyFastArgs a) {
+    for (int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (int64_t) gridDim.x * 1024) {
+        float v[4]; uint16_t hraw[4];
+        const int m = (int) (a.n - i < 4 ? a.n - i : 4);
+        if (ST == MI355X_TYPE_F32) {
+            const float * s = (const float *) a.s + i;
+            if (m == 4) { const float4 x = *(const float4 *) s; v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+            else for (int j = 0; j < m; j++) v[j] = s[j];
+        } else {
+            const uint16_t * s = (const uint16_t *) a.s + i;
+            if (m == 4) { const uint2 x = *(const uint2 *) s; hraw[0] = x.x & 0xFFFF; hraw[1] = x.x >> 16; hraw[2] = x.y & 0xFFFF; hraw[3] = x.y >> 16; }
+            else for (int j = 0; j < m; j++) hraw[j] = s[j];
+            for (int j = 0; j < m; j++) v[j] = h2f(hraw[j]);
+        }
+        if (DT == MI355X_TYPE_F32) {
+            float * d = (float *) a.d + i;
+            if (m == 4) *(float4 *) d = make_float4(v[0], v[1], v[2], v[3]);
+            else for (int j = 0; j < m; j++) d[j] = v[j];
+        } else {
+            uint16_t * d = (uint16_t *) a.d + i;
+            uint16_t h[4];
+            for (int j = 0; j < m; j++) h[j] = ST == MI355X_TYPE_F16 ? hraw[j] : f2h(v[j]);
+            if (m == 4) *(uint2 *) d = make_uint2(h[0] | ((uint32_t) h[1] << 16), h[2] | ((uint32_t) h[3] << 16));
+            else for (int j = 0; j < m; j++) d[j] = h[j];
+        }
+    }
+}
+extern "C" int mi355x_cpy(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * d) {
+    const int st = s->type, dt = d->type;
+    if ((st != MI355X_TYPE_F32 && st != MI355X_TYPE_F16) || (dt != MI355X_TYPE_F32 && dt != MI355X_TYPE_F16)) return MI355X_E_UNSUPPORTED;
+    const int64_t n = t_nelements(s);
+    if (n != t_nelements(d)) return MI355X_E_UNSUPPORTED;
+    if (n == 0) return 0;
+    const double bytes = (double) n * ((st == MI355X_TYPE_F32 ? 4 : 2) + (dt == MI355X_TYPE_F32 ? 4 : 2));
+    const int64_t nb4 = (n + 1023) / 1024;
+    if (t_is_contiguous(s) && t_is_contiguous(d) && ((uintptr_t) s->data % 16 == 0) && ((uintptr_t) d->data % 16 == 0)) {
+        CpyFastArgs k = { s->data, d->data, n };
+        const dim3 g((uint32_t) (nb4 < 8192 ? nb4 : 8192));
+        if (st == MI355X_TYPE_F32 && dt == MI355X_TYPE_F32) return emit(ctx, "cpy", k_cpy_contig<MI355X_TYPE_F32, MI355X_TYPE_F32>, g, dim3(256), 0, k, bytes, 0);
+        if (st == MI355X_TYPE_F32 && dt == MI355X_TYPE_F16) return emit(ctx, "cpy", k_cpy_contig<MI355X_TYPE_F32, MI355X_TYPE_F16>, g, dim3(256), 0, k, bytes, 0);
+        if (st == MI355X_TYPE_F16 && dt == MI355X_TYPE_F32) return emit(ctx, "cpy", k_cpy_contig<MI355X_TYPE_F16, MI355X_TYPE_F32>, g, dim3(256), 0, k, bytes, 0);
+        return emit(ctx, "cpy", k_cpy_contig<MI355X_TYPE_F16, MI355X_TYPE_F16>, g, dim3(256), 0, k, bytes, 0);
+    }
+    CpyArgs k = { to_d(s), to_d(d), n, st, dt };
+    const int64_t nb = (n + 255) / 256;
+    const dim3 g((uint32_t) (nb < 16384 ? nb : 16384));
+    if (st == MI355X_TYPE_F32 && dt == MI355X_TYPE_F32) return emit(ctx, "cpy", k_cpy_generic<MI355X_TYPE_F32, MI355X_TYPE_F32>, g, dim3(256), 0, k, bytes, 0);
+    if (st == MI355X_TYPE_F32 && dt == MI355X_TYPE_F16) return emit(ctx, "cpy", k_cpy_generic<MI355X_TYPE_F32, MI355X_TYPE_F16>, g, dim3(256), 0, k, bytes, 0);
+    if (st == MI355X_TYPE_F16 && dt == MI355X_TYPE_F32) return emit(ctx, "cpy", k_cpy_generic<MI355X_TYPE_F16, MI355X_TYPE_F32>, g, dim3(256), 0, k, bytes, 0);
+    return emit(ctx, "cpy", k_cpy_generic<MI355X_TYPE_F16, MI355X_TYPE_F16>, g, dim3(256), 0, k, bytes, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// get_rows (ggml-cpu/ops.cpp:4850-5017): dst[:, i10, i11, i12] = src[:, idx[i10,i11,i12], i11, i12]
+// -------------------------------------------------------------------------------------------------
+struct GetRowsArgs { dtensor s, idx, d; int type; int64_t nbt; };
+template <int TYPE>
+__global__ void __launch_bounds__(256) k_get_rows(const GetRowsArgs a) {
+    const int64_t r = blockIdx.x;     // flattened (i10, i11, i12)
+    const int64_t i10 = r % a.idx.ne[0], i11 = (r / a.idx.ne[0]) % a.idx.ne[1], i12 = r / (a.idx.ne[0]*a.idx.ne[1]);
+    const int32_t row = *(const int32_t *) (a.idx.data + i10*a.idx.nb[0] + i11*a.idx.nb[1] + i12*a.idx.nb[2]);
+    float * dst = (float *) (a.d.data + i10*a.d.nb[1] + i11*a.d.nb[2] + i12*a.d.nb[3]);
+    const int64_t ne0 = a.s.ne[0];
+    if (row < 0 || row >= a.s.ne[1]) return;
+    if constexpr (TYPE == MI355X_TYPE_F32 || TYPE == MI355X_TYPE_F16) {
+        const char * src = a.s.data + (int64_t) row*a.s.nb[1] + i11*a.s.nb[2] + i12*a.s.nb[3];
+        for (int64_t i = threadIdx.x; i < ne0; i += 256)
+            dst[i] = TYPE == MI355X_TYPE_F32 ? ((const float *) src)[i] : h2f(((const uint16_t *) src)[i]);
+    } else {
+        const qplanes<TYPE> p(a.s.data, a.nbt);
+        const int64_t nb32 = ne0 / 32;                     // 32-element groups in a row
+        for (int64_t g = threadIdx.x; g < nb32; g += 256) {
+            float v[32];
+            dequant_block32<TYPE>(p, (int64_t) row * nb32 + g, v);
+            #pragma unroll
+            for (int j = 0; j < 32; j += 4) *(float4 *) (dst + g*32 + j) = make_float4(v[j], v[j+1], v[j+2], v[j+3]);
+        }
+    }
+}
+extern "C" int mi355x_get_rows(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx, const mi355x_tensor * d) {
+    if (idx->type != MI355X_TYPE_I32 || d->type != MI355X_TYPE_F32 || d->nb[0] != 4) return MI355X_E_UNSUPPORTED;
+    const int64_t nr = idx->ne[0]*idx->ne[1]*idx->ne[2];
+    if (nr == 0) return 0;
+    GetRowsArgs k = { to_d(s), to_d(idx), to_d(d), s->type, 0 };
+    const double bytes = (double) nr * (mi355x_type_row_bytes(s->type, s->ne[0]) + s->ne[0]*4.0);
+    const dim3 g((uint32_t) nr), b(256);
+    if (mi355x_type_is_quantized(s->type)) {
+        if (!t_is_contiguous(s) || s->ne[2] != 1 || s->ne[3] != 1 || ((uintptr_t) d->data % 16) || (d->nb[1] % 16)) return MI355X_E_UNSUPPORTED;
+        k.nbt = t_nelements(s) / type_block(s->type);
+    }
+    switch (s->type) {
+        case MI355X_TYPE_F32:  if (s->nb[0] != 4) return MI355X_E_UNSUPPORTED; return emit(ctx, "get_rows", k_get_rows<MI355X_TYPE_F32>,  g, b, 0, k, bytes, 0);
+        case MI355X_TYPE_F16:  if (s->nb[0] != 2) return MI355X_E_UNSUPPORTED; return emit(ctx, "get_rows", k_get_rows<MI355X_TYPE_F16>,  g, b, 0, k, bytes, 0);
+        case MI355X_TYPE_Q4_0: return emit(ctx, "get_rows", k_get_rows<MI355X_TYPE_Q4_0>, g, b, 0, k, bytes, 0);
+        case MI355X_TYPE_Q5_0: return emit(ctx, "get_rows", k_get_rows<MI355X_TYPE_Q5_0>, g, b, 0, k, bytes, 0);
+        case MI355X_TYPE_Q8_0: return emit(ctx, "get_rows", k_get_rows<MI355X_TYPE_Q8_0>, g, b, 0, k, bytes, 0);
+        case MI355X_TYPE_Q4_K: return emit(ctx, "get_rows", k_get_rows<MI355X_TYPE_Q4_K>, g, b, 0, k, bytes, 0);
+        default: return MI355X_E_UNSUPPORTED;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// im2col, 1-D (ggml-cpu/ops.cpp:6437-6517): dst[(n*OW + ow)*(IC*KW) + ic*KW + k] = f16(x[n][ic][ow*s0 + k*d0 - p0]) or 0
+// thread per (ow, ic): writes KW contiguous outputs; lanes along ow so the x reads are coalesced.
+// -------------------------------------------------------------------------------------------------
+struct Im2colArgs { dtensor x; char * dst; int dst_f16; int64_t IW, IC, N, OW; int KW, s0, p0, d0; };
+__global__ void __launch_bounds__(256) k_im2col_1d(const Im2colArgs a) {
+    const int64_t ow = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t ic = blockIdx.y, n = blockIdx.z;
+    if (ow >= a.OW) return;
+    const float * x = (const float *) (a.x.data + ic*a.x.nb[1] + n*a.x.nb[2]);
+    const int64_t o = ((n*a.OW + ow) * a.IC + ic) * a.KW;
+    for (int k = 0; k < a.KW; k++) {
+        const int64_t iw = ow*a.s0 + (int64_t) k*a.d0 - a.p0;
+        const float v = (iw < 0 || iw >= a.IW) ? 0.0f : x[iw];
+        if (a.dst_f16) ((uint16_t *) a.dst)[o + k] = f2h(v); else ((float *) a.dst)[o + k] = v;
+    }
+}
+extern "C" int mi355x_im2col_1d(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * d, int kw, int s0, int p0, int d0) {
+    if (x->type != MI355X_TYPE_F32 || x->nb[0] != 4 || (d->type != MI355X_TYPE_F16 && d->type != MI355X_TYPE_F32) || !t_is_contiguous(d)) return MI355X_E_UNSUPPORTED;
+    Im2colArgs k = { to_d(x), (char *) d->data, d->type == MI355X_TYPE_F16, x->ne[0], x->ne[1], x->ne[2], d->ne[1], kw, s0, p0, d0 };
+    if (d->ne[0] != k.IC*kw || d->ne[2] != k.N || k.IC > 65535 || k.N > 65535) return MI355X_E_UNSUPPORTED;
+    if (t_nelements(d) == 0) return 0;
+    return emit(ctx, "im2col", k_im2col_1d, dim3((uint32_t) ((k.OW + 255) / 256), (uint32_t) k.IC, (uint32_t) k.N), dim3(256), 0, k,
+                (double) t_nelements(x)*4 + (double) t_nelements(d) * (k.dst_f16 ? 2 : 4), 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// soft_max_ext (ggml-cpu/ops.cpp:5455-5565): y = softmax(x*scale + slope*mask), one wave per row
+// -------------------------------------------------------------------------------------------------
+struct SoftmaxArgs { dtensor x, m, y; int has_mask, mask_f16; float scale, max_bias, m0, m1; uint32_t n_head_log2; int64_t nrows; };
+__global__ void __launch_bounds__(256) k_soft_max(const SoftmaxArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.nrows) return;
+    const int64_t i1 = row % a.x.ne[1], i2 = (row / a.x.ne[1]) % a.x.ne[2], i3 = row / (a.x.ne[1]*a.x.ne[2]);
+    const float * x = (const float *) (a.x.data + i1*a.x.nb[1] + i2*a.x.nb[2] + i3*a.x.nb[3]);
+    float * y = (float *) (a.y.data + i1*a.y.nb[1] + i2*a.y.nb[2] + i3*a.y.nb[3]);
+    const char * mp = a.has_mask ? a.m.data + i1*a.m.nb[1] + (i2 % a.m.ne[2])*a.m.nb[2] + (i3 % a.m.ne[3])*a.m.nb[3] : nullptr;
+    float slope = 1.0f;
+    if (a.max_bias > 0.0f) {
+        const uint32_t h = (uint32_t) i2;
+        slope = h < a.n_head_log2 ? powf(a.m0, (float) (h + 1)) : powf(a.m1, (float) (2*(h - a.n_head_log2) + 1));
+    }
+    const int n = (int) a.x.ne[0];
+    float mx = -INFINITY;
+    for (int i = lane; i < n; i += 64) {
+        float w = x[i] * a.scale;
+        if (mp) w += slope * (a.mask_f16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i]);
+        mx = fmaxf(mx, w);
+    }
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int i = lane; i < n; i += 64) {
+        float w = x[i] * a.scale;
+        if (mp) w += slope * (a.mask_f16 ? h2f(((const uint16_t *) mp)[i]) : ((const float *) mp)[i]);
+        const float e = expf(w - mx);
+        y[i] = e; sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int i = lane; i < n; i += 64) y[i] *= inv;
+}
+extern "C" int mi355x_soft_max(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * mask, const mi355x_tensor * y, float scale, float max_bias) {
+    if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
+    if (mask && ((mask->type != MI355X_TYPE_F32 && mask->type != MI355X_TYPE_F16) || mask->ne[0] != x->ne[0] || mask->ne[1] < x->ne[1])) return MI355X_E_UNSUPPORTED;
+    SoftmaxArgs k; memset(&k, 0, sizeof(k));
+    k.x = to_d(x); k.y = to_d(y); if (mask) k.m = to_d(mask);
+    k.has_mask = mask != nullptr; k.mask_f16 = mask && mask->type == MI355X_TYPE_F16;
+    k.scale = scale; k.max_bias = max_bias;
+    const uint32_t n_head = (uint32_t) x->ne[2];
+    k.n_head_log2 = 1u << (uint32_t) floor(log2((double) n_head));
+    k.m0 = powf(2.0f, -(max_bias) / k.n_head_log2); k.m1 = powf(2.0f, -(max_bias / 2.0f) / k.n_head_log2);
+    k.nrows = t_nrows(x);
+    if (k.nrows == 0 || x->ne[0] == 0) return 0;
+    return emit(ctx, "soft_max", k_soft_max, dim3((uint32_t) ((k.nrows + 3) / 4)), dim3(256), 0, k, (double) t_nelements(x) * 8, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// rope, modes NORMAL (0) and NEOX (2), f32 (ggml-cpu/ops.cpp:5822-6131).  One thread per rotated pair.
+// theta for pair p: pos * theta_scale^p accumulated by repeated multiplication exactly as
+// ggml_rope_cache_init does (sequential product, so the rounding matches the CPU cache).
+// -------------------------------------------------------------------------------------------------
+struct RopeArgs { dtensor x, y; const int32_t * pos; const float * ff; mi355x_rope_params p; float theta_scale, corr0, corr1; };
+__global__ void __launch_bounds__(64) k_rope(const RopeArgs a) {
+    // block = one row (i1 = head, i2 = position, i3 = batch); lane loops over pairs
+    const int64_t row = blockIdx.x;
+    const int64_t i1 = row % a.x.ne[1], i2 = (row / a.x.ne[1]) % a.x.ne[2], i3 = row / (a.x.ne[1]*a.x.ne[2]);
+    const float * x = (const float *) (a.x.data + i1*a.x.nb[1] + i2*a.x.nb[2] + i3*a.x.nb[3]);
+    float * y = (float *) (a.y.data + i1*a.y.nb[1] + i2*a.y.nb[2] + i3*a.y.nb[3]);
+    const int ne0 = (int) a.x.ne[0], n_dims = a.p.n_dims;
+    const int lane = threadIdx.x;
+    // each lane computes its theta by the same sequential product the CPU uses: theta_p = (((pos*ts)*ts)...)
+    for (int pr = lane; pr < ne0/2; pr += 64) {
+        const int i0 = 2*pr;
+        if (i0 < n_dims) {
+            float theta = (float) a.pos[i2];
+            for (int q = 0; q < pr; q++) theta *= a.theta_scale;
+            const float ffv = a.ff ? a.ff[pr] : 1.0f;
+            const float theta_extrap = theta / ffv;
+            float theta_interp = a.p.freq_scale * theta_extrap;
+            float th = theta_interp, mscale = a.p.attn_factor;
+            if (a.p.ext_factor != 0.0f) {
+                const float yv = ((float) (i0 / 2) - a.corr0) / fmaxf(0.001f, a.corr1 - a.corr0);
+                const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, yv))) * a.p.ext_factor;
+                th = theta_interp * (1.0f - ramp_mix) + theta_extrap * ramp_mix;
+                mscale *= 1.0f + 0.1f * logf(1.0f / a.p.freq_scale);
+            }
+            const float c = cosf(th) * mscale, s = sinf(th) * mscale;
+            int ia, ib;
+            if (a.p.mode == 0) { ia = i0; ib = i0 + 1; } else { ia = pr; ib = pr + n_dims/2; }
+            const float x0 = x[ia], x1 = x[ib];
+            y[ia] = x0*c - x1*s;
+            y[ib] = x0*s + x1*c;
+        } else {
+            y[i0] = x[i0]; y[i0 + 1] = x[i0 + 1];
+        }
+    }
+}
+extern "C" int mi355x_rope(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * pos, const float * ff, const mi355x_tensor * y, const mi355x_rope_params * p) {
+    if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
+    if ((p->mode != 0 && p->mode != 2) || pos->type != MI355X_TYPE_I32 || pos->ne[0] < x->ne[2] || (p->n_dims & 1) || p->n_dims > x->ne[0] || (x->ne[0] & 1)) return MI355X_E_UNSUPPORTED;
+    RopeArgs k; k.x = to_d(x); k.y = to_d(y); k.pos = (const int32_t *) pos->data; k.ff = ff; k.p = *p;
+    k.theta_scale = powf(p->freq_base, -2.0f / p->n_dims);
+    // ggml_rope_yarn_corr_dims (ggml/src/ggml.c:4371-4383)
+    auto corr_dim = [&](float n_rot) { return p->n_dims * logf(p->n_ctx_orig / (n_rot * 2 * (float) M_PI)) / (2 * logf(p->freq_base)); };
+    const float start = floorf(corr_dim(p->beta_fast)), end = ceilf(corr_dim(p->beta_slow));
+    k.corr0 = fmaxf(0.0f, start); k.corr1 = fminf((float) (p->n_dims - 1), end);
+    const int64_t nr = t_nrows(x);
+    if (nr == 0) return 0;
+    return emit(ctx, "rope", k_rope, dim3((uint32_t) nr), dim3(64), 0, k, (double) t_nelements(x) * 8, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// concat f32 along dim
+// -------------------------------------------------------------------------------------------------
+struct ConcatArgs { dtensor a, b, d; int dim; int64_t n; };
+__global__ void __launch_bounds__(256) k_concat(const ConcatArgs a) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t) gridDim.x * 256) {
+        int64_t r = i, idx[4];
+        idx[0] = r % a.d.ne[0]; r /= a.d.ne[0]; idx[1] = r % a.d.ne[1]; r /= a.d.ne[1]; idx[2] = r % a.d.ne[2]; idx[3] = r / a.d.ne[2];
+        float * o = (float *) (a.d.data + idx[0]*a.d.nb[0] + idx[1]*a.d.nb[1] + idx[2]*a.d.nb[2] + idx[3]*a.d.nb[3]);
+        const dtensor * s = &a.a;
+        if (idx[a.dim] >= a.a.ne[a.dim]) { idx[a.dim] -= a.a.ne[a.dim]; s = &a.b; }
+        *o = *(const float *) (s->data + idx[0]*s->nb[0] + idx[1]*s->nb[1] + idx[2]*s->nb[2] + idx[3]*s->nb[3]);
+    }
+}
+extern "C" int mi355x_concat(mi355x_ctx * ctx, const mi355x_tensor * a, const mi355x_tensor * b, const mi355x_tensor * d, int dim) {
+    if (a->type != MI355X_TYPE_F32 || b->type != MI355X_TYPE_F32 || d->type != MI355X_TYPE_F32 || dim < 0 || dim > 3) return MI355X_E_UNSUPPORTED;
+    ConcatArgs k = { to_d(a), to_d(b), to_d(d), dim, t_nelements(d) };
+    if (k.n == 0) return 0;
+    const int64_t nb = (k.n + 255) / 256;
+    return emit(ctx, "concat", k_concat, dim3((uint32_t) (nb < 16384 ? nb : 16384)), dim3(256), 0, k, (double) k.n * 8, 0);
+}

@@ -1,0 +1,337 @@
+// ggml_flash_attn_ext for Whisper's head_dim 64 (ggml/src/ggml.c:5418-5460; CPU reference ggml-cpu/ops.cpp:8479-8715):
+//     dst[:, h, t] = softmax_k( scale * <f16(q[:, t, h]), k[:, k, h]> + mask[k, t] ) . v[:, k, h]
+// q F32 (rounded to f16 like the CPU's q_to_vec_dot), k/v F16, mask F16 or none, f32 accumulation throughout.
+//
+// Two kernels:
+//   k_fattn_mfma : T > 8 (encoder 1500 x 1536, prompt).  128 queries x 1 head per workgroup, 4 waves x 32 queries,
+//                  64-key tiles staged once per workgroup in LDS (K row-major XOR-swizzled, V transposed with a
+//                  conflict-free 136-byte row pitch).  S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_f16, so a
+//                  lane owns ONE query column: softmax statistics are per-lane scalars (one shuffle with lane^32),
+//                  the P fragment feeds the second MFMA straight from registers (the k-index permutation inside the
+//                  MFMA is applied identically to V^T), and the O rescale is a per-lane scalar multiply.
+//   k_fattn_vec  : T <= 8 (decoder step).  HBM-bound on the F16 K/V read (cross-attention: 1536 x 64 x 2 x 2 B per
+//                  head and layer), so the key range is split over workgroups (32 keys per wave, 128 per workgroup)
+//                  to cover all CUs; partial (max, sum, O) records are merged by k_fattn_combine.
+#include "common.h"
+#include <math.h>
+
+#define FA_D 64
+
+struct FattnArgs {
+    dtensor q, k, v, m, d;
+    int has_mask; float scale;
+    int T, n_kv, H, rk2, rv2;
+    float * part; int nparts;          // vec kernel: partial records [H][T][nparts][66]
+};
+
+// ---------------------------------------------------------------------------------------------------
+// MFMA kernel
+// ---------------------------------------------------------------------------------------------------
+#define KT 64                 // keys per tile
+#define VT_PITCH 136          // bytes per d-row of the transposed V tile (64 keys * 2 B + 8 B pad)
+
+__device__ __forceinline__ int k_off(int row, int slot) { return row*128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+__global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[KT*128 + FA_D*VT_PITCH];
+    char * ldsK = lds; char * ldsV = lds + KT*128;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2;
+    const int qi = blockIdx.x*128 + wave*32 + (lane & 31);          // this lane's query
+    const int hf = lane >> 5;
+    const bool q_ok = qi < a.T;
+
+    // Q^T fragments (B operand): lane (query, hf) holds d = 16*kk + 8*hf + e
+    half8_t qf[4];
+    {
+        const float * qp = (const float *) (a.q.data + (int64_t) qi*a.q.nb[1] + (int64_t) hq*a.q.nb[2]);
+        #pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            float4 x0 = make_float4(0, 0, 0, 0), x1 = x0;
+            if (q_ok) { x0 = *(const float4 *) (qp + 16*kk + 8*hf); x1 = *(const float4 *) (qp + 16*kk + 8*hf + 4); }
+            qf[kk][0] = (half_t) x0.x; qf[kk][1] = (half_t) x0.y; qf[kk][2] = (half_t) x0.z; qf[kk][3] = (half_t) x0.w;
+            qf[kk][4] = (half_t) x1.x; qf[kk][5] = (half_t) x1.y; qf[kk][6] = (half_t) x1.z; qf[kk][7] = (half_t) x1.w;
+        }
+    }
+
+    floatx16 o[2];
+    #pragma unroll
+    for (int i = 0; i < 2; i++)
+        #pragma unroll
+        for (int r = 0; r < 16; r++) o[i][r] = 0.0f;
+    float m_run = -1e30f, l_run = 0.0f;
+
+    const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2];
+    const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2];
+    const char * mrow  = a.has_mask && q_ok ? a.m.data + (int64_t) qi*a.m.nb[1] : nullptr;
+
+    // staging: thread -> (key = tid>>3 [+32], chunk = tid&7): 16 bytes = 8 d-values
+    const int skey = tid >> 3, sch = tid & 7;
+
+    for (int k0 = 0; k0 < a.n_kv; k0 += KT) {
+        uint4 kr[2], vr[2];
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int key = k0 + skey + 32*i;
+            const bool ok = key < a.n_kv;
+            kr[i] = ok ? *(const uint4 *) (kbase + (int64_t) key*a.k.nb[1] + sch*16) : make_uint4(0, 0, 0, 0);
+            vr[i] = ok ? *(const uint4 *) (vbase + (int64_t) key*a.v.nb[1] + sch*16) : make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();                                      // previous tile fully consumed
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int kl = skey + 32*i;
+            *(uint4 *) (ldsK + k_off(kl, sch)) = kr[i];
+            const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
+            #pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint16_t hv16 = (uint16_t) ((w[e >> 1] >> (16*(e & 1))) & 0xFFFF);
+                *(uint16_t *) (ldsV + (sch*8 + e)*VT_PITCH + kl*2) = hv16;
+            }
+        }
+        __syncthreads();
+
+        // S^T[key][query] for the two 32-key blocks of the tile
+        floatx16 s[2];
+        #pragma unroll
+        for (int b = 0; b < 2; b++) {
+            #pragma unroll
+            for (int r = 0; r < 16; r++) s[b][r] = 0.0f;
+            #pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const half8_t kf = *(const half8_t *) (ldsK + k_off(b*32 + (lane & 31), kk*2 + hf));
+                s[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[b], 0, 0, 0);
+            }
+        }
+        // scale, mask, running max.  register r of block b <-> key k0 + 32b + (r&3) + 8*(r>>2) + 4*hf
+        float tmax = -INFINITY;
+        #pragma unroll
+        for (int b = 0; b < 2; b++) {
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int key = k0 + 32*b + 8*g + 4*hf;
+                float mv[4] = { 0, 0, 0, 0 };
+                if (mrow && key < a.n_kv) {
+                    if (key + 3 < a.n_kv && ((a.m.nb[1] | (uintptr_t) a.m.data) % 8 == 0)) {
+                        const uint2 mm = *(const uint2 *) (mrow + key*2);
+                        mv[0] = h2f((uint16_t) (mm.x & 0xFFFF)); mv[1] = h2f((uint16_t) (mm.x >> 16)); mv[2] = h2f((uint16_t) (mm.y & 0xFFFF)); mv[3] = h2f((uint16_t) (mm.y >> 16));
+                    } else {
+                        for (int e = 0; e < 4 && key + e < a.n_kv; e++) mv[e] = h2f(*(const uint16_t *) (mrow + (key + e)*2));
+                    }
+                }
+                #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float x = s[b][4*g + e] * a.scale + mv[e];
+                    if (key + e >= a.n_kv) x = -INFINITY;
+                    s[b][4*g + e] = x;
+                    tmax = fmaxf(tmax, x);
+                }
+            }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.0f;
+        half8_t pf[4];                                         // B operand of P^T: pf[2b + kk'][e] <-> register 8kk'+e of block b
+        #pragma unroll
+        for (int b = 0; b < 2; b++) {
+            #pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float p = __expf(s[b][r] - m_new);
+                psum += p;
+                pf[2*b + (r >> 3)][r & 7] = (half_t) p;
+            }
+        }
+        l_run = l_run*alpha + psum;
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) o[i][r] *= alpha;
+        // O^T[d][query] += V^T[d][key] * P^T[key][query]
+        #pragma unroll
+        for (int c = 0; c < 4; c++) {                          // c = 2b + kk': keys 32b + 16kk' + {(e&3) + 8(e>>2) + 4hf}
+            const int kb = 16*c + 4*hf;
+            #pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const char * vp = ldsV + (i*32 + (lane & 31))*VT_PITCH + kb*2;
+                const uint2 v0 = *(const uint2 *) vp, v1 = *(const uint2 *) (vp + 16);
+                half8_t vf;
+                const uint32_t vw[4] = { v0.x, v0.y, v1.x, v1.y };
+                __builtin_memcpy(&vf, vw, 16);
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], o[i], 0, 0, 0);
+            }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot == 0.0f ? 0.0f : 1.0f / l_tot;
+    if (q_ok) {
+        float * dp = (float *) (a.d.data + (int64_t) hq*a.d.nb[1] + (int64_t) qi*a.d.nb[2]);
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int d0 = 32*i + 8*g + 4*hf;
+                *(float4 *) (dp + d0) = make_float4(o[i][4*g]*inv, o[i][4*g+1]*inv, o[i][4*g+2]*inv, o[i][4*g+3]*inv);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// vector kernel (T <= 8): 32 keys per wave, partial softmax records
+// ---------------------------------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(256) k_fattn_vec(const FattnArgs a) {
+    __shared__ __attribute__((aligned(16))) float qs[T][FA_D];
+    __shared__ float pl[4][T][32];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2;
+    const int pidx = blockIdx.x*4 + wave;                      // partial index == 32-key chunk index
+    const int kbeg = pidx*32;
+
+    for (int i = tid; i < T*FA_D; i += 256) {
+        const int t = i / FA_D, d = i % FA_D;
+        qs[t][d] = round_f16(*(const float *) (a.q.data + (int64_t) t*a.q.nb[1] + (int64_t) hq*a.q.nb[2] + d*4));
+    }
+    __syncthreads();
+    if (kbeg >= a.n_kv) {                                      // wave-uniform: padded chunk -> neutral record
+        for (int t = 0; t < T; t++) {
+            float * rec = a.part + (((int64_t) hq*T + t)*a.nparts + pidx)*66;
+            rec[2 + lane] = 0.0f;
+            if (lane == 0) { rec[0] = -1e30f; rec[1] = 0.0f; }
+        }
+        return;
+    }
+
+    const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2];
+    const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2];
+    const int dch = lane & 3;
+
+    float sc[2][T];
+    #pragma unroll
+    for (int ps = 0; ps < 2; ps++) {
+        const int key = kbeg + ps*16 + (lane >> 2);
+        const bool ok = key < a.n_kv;
+        float kf[16];
+        {
+            uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
+            if (ok) { const char * kp = kbase + (int64_t) key*a.k.nb[1] + dch*32; k0 = *(const uint4 *) kp; k1 = *(const uint4 *) (kp + 16); }
+            const uint32_t w[8] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
+            #pragma unroll
+            for (int i = 0; i < 8; i++) { kf[2*i] = h2f((uint16_t) (w[i] & 0xFFFF)); kf[2*i+1] = h2f((uint16_t) (w[i] >> 16)); }
+        }
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            float acc = 0.0f;
+            #pragma unroll
+            for (int i = 0; i < 16; i++) acc = fmaf(kf[i], qs[t][dch*16 + i], acc);
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            float x = acc * a.scale;
+            if (a.has_mask && ok) x += h2f(*(const uint16_t *) (a.m.data + (int64_t) t*a.m.nb[1] + key*2));
+            sc[ps][t] = ok ? x : -INFINITY;
+        }
+    }
+    float mt[T], lt[T];
+    #pragma unroll
+    for (int t = 0; t < T; t++) {
+        float m = fmaxf(sc[0][t], sc[1][t]);
+        #pragma unroll
+        for (int o = 4; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        m = fmaxf(m, -1e30f);
+        const float p0 = __expf(sc[0][t] - m), p1 = __expf(sc[1][t] - m);
+        float l = dch == 0 ? p0 + p1 : 0.0f;
+        l = wave_sum(l);
+        mt[t] = m; lt[t] = l;
+        if (dch == 0) { pl[wave][t][lane >> 2] = p0; pl[wave][t][16 + (lane >> 2)] = p1; }
+    }
+    // pl is written and read by the same wave only; LDS ops of one wave complete in order
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+
+    float o[T];
+    #pragma unroll
+    for (int t = 0; t < T; t++) o[t] = 0.0f;
+    const int nk = a.n_kv - kbeg < 32 ? a.n_kv - kbeg : 32;
+    #pragma unroll 8
+    for (int kk = 0; kk < nk; kk++) {
+        const float v = h2f(*(const uint16_t *) (vbase + (int64_t) (kbeg + kk)*a.v.nb[1] + lane*2));
+        #pragma unroll
+        for (int t = 0; t < T; t++) o[t] = fmaf(pl[wave][t][kk], v, o[t]);
+    }
+    #pragma unroll
+    for (int t = 0; t < T; t++) {
+        float * rec = a.part + (((int64_t) hq*T + t)*a.nparts + pidx)*66;
+        rec[2 + lane] = o[t];
+        if (lane == 0) { rec[0] = mt[t]; rec[1] = lt[t]; }
+    }
+}
+
+struct CombineArgs { const float * part; int nparts, T, H; dtensor d; };
+__global__ void __launch_bounds__(64) k_fattn_combine(const CombineArgs a) {
+    const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const float * rec = a.part + (((int64_t) h*a.T + t)*a.nparts)*66;
+    float M = -1e30f;
+    for (int i = 0; i < a.nparts; i++) M = fmaxf(M, rec[i*66]);
+    float L = 0.0f, O = 0.0f;
+    for (int i = 0; i < a.nparts; i++) {
+        const float w = __expf(rec[i*66] - M);
+        L = fmaf(w, rec[i*66 + 1], L);
+        O = fmaf(w, rec[i*66 + 2 + lane], O);
+    }
+    float * dp = (float *) (a.d.data + (int64_t) h*a.d.nb[1] + (int64_t) t*a.d.nb[2]);
+    dp[lane] = L == 0.0f ? 0.0f : O / L;
+}
+
+extern "C" int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
+                                     const mi355x_tensor * mask, const mi355x_tensor * dst, float scale) {
+    if (q->type != MI355X_TYPE_F32 || k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16 || dst->type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
+    if (q->ne[0] != FA_D || k->ne[0] != FA_D || v->ne[0] != FA_D || dst->ne[0] != FA_D) return MI355X_E_UNSUPPORTED;
+    if (q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return MI355X_E_UNSUPPORTED;
+    if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || dst->nb[0] != 4) return MI355X_E_UNSUPPORTED;
+    const int T = (int) q->ne[1], H = (int) q->ne[2], n_kv = (int) k->ne[1];
+    if (v->ne[1] != n_kv || dst->ne[1] != H || dst->ne[2] != T) return MI355X_E_UNSUPPORTED;
+    if (k->ne[2] <= 0 || H % k->ne[2] || v->ne[2] <= 0 || H % v->ne[2]) return MI355X_E_UNSUPPORTED;
+    // 16-byte vector accesses
+    if (((uintptr_t) q->data | q->nb[1] | q->nb[2]) % 16 || ((uintptr_t) k->data | k->nb[1] | k->nb[2]) % 16 ||
+        ((uintptr_t) v->data | v->nb[1] | v->nb[2]) % 16 || ((uintptr_t) dst->data | dst->nb[1] | dst->nb[2]) % 16) return MI355X_E_UNSUPPORTED;
+    if (mask && (mask->type != MI355X_TYPE_F16 || mask->ne[0] < n_kv || mask->ne[1] < T || mask->nb[0] != 2 || mask->ne[2] != 1 || mask->ne[3] != 1)) return MI355X_E_UNSUPPORTED;
+    if (T == 0 || H == 0) return 0;
+
+    FattnArgs a; memset(&a, 0, sizeof(a));
+    a.q = to_d(q); a.k = to_d(k); a.v = to_d(v); a.d = to_d(dst);
+    if (mask) a.m = to_d(mask);
+    a.has_mask = mask != nullptr; a.scale = scale; a.T = T; a.n_kv = n_kv; a.H = H;
+    a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
+    const double kv_bytes = 2.0 * n_kv * FA_D * 2 * H;
+    const double flops = 4.0 * T * (double) n_kv * FA_D * H;
+    if (n_kv == 0) return mi355x_memset(ctx, dst->data, 0, (size_t) dst->nb[3]*dst->ne[3]);
+
+    if (T <= 8) {
+        const int nparts = (n_kv + 31) / 32, nblk = (nparts + 3) / 4;
+        mi355x_scratch_reset(ctx);
+        a.nparts = nblk*4;
+        a.part = (float *) mi355x_scratch_alloc(ctx, (size_t) H*T*a.nparts*66*4);
+        if (!a.part) return (int) hipErrorOutOfMemory;
+        const dim3 grid(nblk, H), block(256);
+        int rc;
+        const double bytes = kv_bytes + (double) T*H*FA_D*8;
+        switch (T) {
+            case 1: rc = emit(ctx, "fattn_vec", k_fattn_vec<1>, grid, block, 0, a, bytes, flops); break;
+            case 2: rc = emit(ctx, "fattn_vec", k_fattn_vec<2>, grid, block, 0, a, bytes, flops); break;
+            case 3: rc = emit(ctx, "fattn_vec", k_fattn_vec<3>, grid, block, 0, a, bytes, flops); break;
+            case 4: rc = emit(ctx, "fattn_vec", k_fattn_vec<4>, grid, block, 0, a, bytes, flops); break;
+            case 5: rc = emit(ctx, "fattn_vec", k_fattn_vec<5>, grid, block, 0, a, bytes, flops); break;
+            case 6: rc = emit(ctx, "fattn_vec", k_fattn_vec<6>, grid, block, 0, a, bytes, flops); break;
+            case 7: rc = emit(ctx, "fattn_vec", k_fattn_vec<7>, grid, block, 0, a, bytes, flops); break;
+            default: rc = emit(ctx, "fattn_vec", k_fattn_vec<8>, grid, block, 0, a, bytes, flops); break;
+        }
+        if (rc) return rc;
+        return emit(ctx, "fattn_combine", k_fattn_combine, dim3(T, H), dim3(64), 0, CombineArgs{ a.part, a.nparts, T, H, a.d }, 0, 0);
+    }
+    const double bytes = kv_bytes * ((T + 127) / 128) + (double) T*H*FA_D*8;
+    return emit(ctx, "fattn_mfma", k_fattn_mfma, dim3((T + 127) / 128, H), dim3(256), 0, a, bytes, flops);
+}

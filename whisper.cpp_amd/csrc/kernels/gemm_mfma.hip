@@ -1,0 +1,381 @@
+// Dense half of the hot path (encoder, prompt, conv-as-GEMM): tiled GEMM on the CDNA4 matrix cores.
+//
+//   dst[m, t] = sum_k A[m, k] * B[t, k]       A = ggml src0 (weights, M rows), B = prepared activations
+//
+//  * A is block-quantized (planar Q4_0/Q5_0/Q8_0/Q4_K) or F16/F32.  Each K-step a workgroup dequantizes its
+//    128 x 64 A tile in registers and stores it as f16 into an XOR-swizzled LDS tile ("per-warp dequant into LDS
+//    tiles feeding MFMA"); the HBM side stays in the quantized layout (0.56-1.06 B/weight).
+//  * B is an f16 [T][K] matrix produced by k_prep_act below.  For quantized A it holds the reference's OWN
+//    activation rounding: x is quantized to Q8_0 / Q8_K blocks exactly as ggml-cpu does before its integer dot
+//    (ggml-cpu/ggml-cpu.c:1322-1357; arch/x86/quants.c:302-398; ggml-quants.c:2768-2805) and stored as
+//    f16(d * q).  So the MFMA path sees the same quantization decisions as the CPU path; what differs is f16
+//    rounding of d*q products (2^-12 relative) and f32 summation order.
+//  * v_mfma_f32_32x32x16_f16, f32 accumulate.  4 waves per workgroup in a 2x2 arrangement, each wave owns a
+//    64 x (BN/2) output tile; A = weights so consecutive accumulator registers are consecutive output features
+//    (contiguous in dst) => 16-byte stores.
+//  * Global loads for K-step k+1 are issued before the MFMAs of step k (register-staged prefetch), LDS tiles
+//    are conflict-free for ds_read_b128 via slot ^= (row>>1)&7.
+#include "common.h"
+
+// -------------------------------------------------------------------------------------------------
+// activation preparation: f32 [K, T] (ggml src1) -> f16 [T][K]
+//   mode 0: plain f16 rounding (F16/F32 weights: vec_dot_type F16, ggml-cpu/ggml-cpu.c:214-412)
+//   mode 1: Q8_0 round trip     mode 2: Q8_K round trip
+// -------------------------------------------------------------------------------------------------
+struct PrepArgs { const char * x; int64_t x_nb1; uint16_t * y; int K; int64_t T; int mode; int x_f16; };
+
+__global__ void __launch_bounds__(256) k_prep_act(const PrepArgs a) {
+    const int64_t t = blockIdx.y;
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= a.K) return;
+    float v[4];
+    if (a.x_f16) {
+        const uint2 h = *(const uint2 *) (a.x + t*a.x_nb1 + (int64_t) e*2);
+        v[0] = h2f((uint16_t) (h.x & 0xFFFF)); v[1] = h2f((uint16_t) (h.x >> 16)); v[2] = h2f((uint16_t) (h.y & 0xFFFF)); v[3] = h2f((uint16_t) (h.y >> 16));
+    } else {
+        const float4 x4 = *(const float4 *) (a.x + t*a.x_nb1 + (int64_t) e*4);
+        v[0] = x4.x; v[1] = x4.y; v[2] = x4.z; v[3] = x4.w;
+    }
+    float r[4];
+    if (a.mode == 0) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = v[i];
+    } else if (a.mode == 1) {
+        float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        const float d  = round_f16(amax / 127.0f);
+        const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = d * rintf(v[i]*id);
+    } else {
+        float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        float mn = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+        const float amax = fmaxf(mx, -mn);
+        const float maxv = (mx >= -mn) ? mx : mn;
+        if (amax == 0.0f) { r[0] = r[1] = r[2] = r[3] = 0.0f; }
+        else {
+            const float iscale = -127.0f / maxv;
+            const float d = 1.0f / iscale;
+            #pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = d * fminf(127.0f, rintf(iscale * v[i]));
+        }
+    }
+    *(uint2 *) (a.y + t*a.K + e) = make_uint2(f2h(r[0]) | ((uint32_t) f2h(r[1]) << 16), f2h(r[2]) | ((uint32_t) f2h(r[3]) << 16));
+}
+
+extern "C" int mi355x_prep_act(mi355x_ctx * ctx, const void * x, int64_t x_nb1, int x_f16, void * yv, int K, int64_t T, int mode) {
+    uint16_t * y = (uint16_t *) yv;
+    if (K % 4 || (mode == 1 && K % 32) || (mode == 2 && K % 256) || T > 65535*64LL) return MI355X_E_UNSUPPORTED;
+    PrepArgs k = { (const char *) x, x_nb1, y, K, T, mode, x_f16 };
+    // blockIdx.y limited to 65535: loop in chunks
+    int rc = 0;
+    for (int64_t t0 = 0; t0 < T && rc == 0; t0 += 65535) {
+        PrepArgs kk = k; kk.x += t0*x_nb1; kk.y += t0*K;
+        const int64_t nt = T - t0 < 65535 ? T - t0 : 65535;
+        rc = emit(ctx, "prep_act", k_prep_act, dim3((uint32_t) ((K/4 + 255) / 256), (uint32_t) nt), dim3(256), 0, kk, (double) nt*K*(x_f16 ? 4 : 6), 0);
+    }
+    return rc;
+}
+
+// -------------------------------------------------------------------------------------------------
+// GEMM
+// -------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const char * A; int64_t a_nb1; int64_t nbt;        // A rows: planar quant (nbt = total blocks) or f16/f32 with byte row stride
+    const uint16_t * B; int64_t ldb;                    // f16 [T][ldb]
+    int M, K; int64_t T;
+    char * dst; int64_t dst_nb1; int dst_f16;
+    const float * bias; float scale; int has_scale; int gelu;
+    const char * residual; int64_t res_nb1;
+    const uint16_t * gelu_tab;
+};
+
+#define BM 128
+#define BK 64
+
+// swizzled byte offset of 16-byte slot `slot` (0..7) of row `row` in a [rows][64] f16 tile
+__device__ __forceinline__ int lds_off(int row, int slot) { return row*128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) { return (uint32_t) f2h(a) | ((uint32_t) f2h(b) << 16); }
+
+// registers holding one thread's share of the next A tile
+template <int AT> struct a_regs;
+template <> struct a_regs<MI355X_TYPE_Q4_0> { uint4 q; uint16_t d; };
+template <> struct a_regs<MI355X_TYPE_Q5_0> { uint4 q; uint32_t qh; uint16_t d; };
+template <> struct a_regs<MI355X_TYPE_Q8_0> { uint4 q0, q1; uint16_t d; };
+template <> struct a_regs<MI355X_TYPE_Q4_K> { uint4 q0, q1; uint32_t dm; uint32_t sc[3]; };
+template <> struct a_regs<MI355X_TYPE_F16>  { uint4 v[4]; };
+template <> struct a_regs<MI355X_TYPE_F32>  { float4 v[8]; };
+
+// thread (row = tid>>1, half = tid&1) owns 32 consecutive k of its row: k0 + half*32 .. +31
+template <int AT>
+__device__ __forceinline__ void a_load(a_regs<AT> & r, const GemmArgs & a, int m, int k, bool valid) {
+    if constexpr (AT == MI355X_TYPE_F16) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool ok = valid && (k + 8*i < a.K);
+            r.v[i] = ok ? *(const uint4 *) (a.A + (int64_t) m*a.a_nb1 + (int64_t) (k + 8*i)*2) : make_uint4(0, 0, 0, 0);
+        }
+    } else if constexpr (AT == MI355X_TYPE_F32) {
+        #pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const bool ok = valid && (k + 4*i < a.K);
+            r.v[i] = ok ? *(const float4 *) (a.A + (int64_t) m*a.a_nb1 + (int64_t) (k + 4*i)*4) : make_float4(0, 0, 0, 0);
+        }
+    } else if constexpr (AT == MI355X_TYPE_Q4_K) {
+        const qplanes<MI355X_TYPE_Q4_K> p(a.A, a.nbt);
+        const bool ok = valid && (k < a.K);
+        if (ok) {
+            const int64_t sb = (int64_t) m * (a.K >> 8) + (k >> 8);
+            const int j = (k & 255) >> 5;
+            const uint8_t * qs = p.qs + sb*128 + (j >> 1)*32;
+            r.q0 = *(const uint4 *) qs; r.q1 = *(const uint4 *) (qs + 16);
+            r.dm = p.dm[sb];
+            const uint32_t * sc = (const uint32_t *) (p.sc + sb*12);
+            r.sc[0] = sc[0]; r.sc[1] = sc[1]; r.sc[2] = sc[2];
+        } else { r.q0 = r.q1 = make_uint4(0, 0, 0, 0); r.dm = 0; r.sc[0] = r.sc[1] = r.sc[2] = 0; }
+    } else {
+        const qplanes<AT> p(a.A, a.nbt);
+        const bool ok = valid && (k < a.K);
+        const int64_t ib = (int64_t) m * (a.K >> 5) + (k >> 5);
+        if constexpr (AT == MI355X_TYPE_Q8_0) {
+            r.q0 = ok ? *(const uint4 *) (p.qs + ib*32) : make_uint4(0, 0, 0, 0);
+            r.q1 = ok ? *(const uint4 *) (p.qs + ib*32 + 16) : make_uint4(0, 0, 0, 0);
+        } else {
+            r.q = ok ? *(const uint4 *) (p.qs + ib*16) : make_uint4(0, 0, 0, 0);
+            if constexpr (AT == MI355X_TYPE_Q5_0) r.qh = ok ? p.qh[ib] : 0;
+        }
+        r.d = ok ? p.d[ib] : (uint16_t) 0;
+    }
+}
+
+// dequantize to f16 and store the 4 slots (8 halves each) of this thread's 32 k-values
+template <int AT>
+__device__ __forceinline__ void a_store(const a_regs<AT> & r, char * lds, int row, int half, int k /* global k of first element */) {
+    uint4 out[4];
+    if constexpr (AT == MI355X_TYPE_F16) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = r.v[i];
+    } else if constexpr (AT == MI355X_TYPE_F32) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++)
+            out[i] = make_uint4(pack_h2(r.v[2*i].x, r.v[2*i].y), pack_h2(r.v[2*i].z, r.v[2*i].w), pack_h2(r.v[2*i+1].x, r.v[2*i+1].y), pack_h2(r.v[2*i+1].z, r.v[2*i+1].w));
+    } else if constexpr (AT == MI355X_TYPE_Q8_0) {
+        const float d = h2f(r.d);
+        const uint32_t w[8] = { r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w };
+        uint32_t o[16];
+        #pragma unroll
+        for (int i = 0; i < 8; i++) {
+            o[2*i]   = pack_h2((float) (int8_t) (w[i] & 0xFF) * d,         (float) (int8_t) ((w[i] >> 8) & 0xFF) * d);
+            o[2*i+1] = pack_h2((float) (int8_t) ((w[i] >> 16) & 0xFF) * d, (float) (int8_t) (w[i] >> 24) * d);
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = make_uint4(o[4*i], o[4*i+1], o[4*i+2], o[4*i+3]);
+    } else if constexpr (AT == MI355X_TYPE_Q4_K) {
+        const float d = h2f((uint16_t) (r.dm & 0xFFFF)), dmin = h2f((uint16_t) (r.dm >> 16));
+        const int j = (k & 255) >> 5;
+        int sc, m; q4k_scale_min(j, (const uint8_t *) r.sc, sc, m);
+        const float d1 = d * sc, m1 = dmin * m;
+        const int sh = (j & 1) * 4;
+        const uint32_t w[8] = { r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w };
+        uint32_t o[16];
+        #pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float v0 = d1 * (float) ((w[i] >> (sh))      & 0xF) - m1, v1 = d1 * (float) ((w[i] >> (8 + sh))  & 0xF) - m1;
+            const float v2 = d1 * (float) ((w[i] >> (16 + sh)) & 0xF) - m1, v3 = d1 * (float) ((w[i] >> (24 + sh)) & 0xF) - m1;
+            o[2*i] = pack_h2(v0, v1); o[2*i+1] = pack_h2(v2, v3);
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = make_uint4(o[4*i], o[4*i+1], o[4*i+2], o[4*i+3]);
+    } else {
+        // Q4_0 / Q5_0: byte j of qs -> element j (low nibble) and j+16 (high nibble)
+        const float d = h2f(r.d);
+        const uint32_t w[4] = { r.q.x, r.q.y, r.q.z, r.q.w };
+        uint32_t lo[4], hi[4];
+        int off;
+        if constexpr (AT == MI355X_TYPE_Q5_0) {
+            #pragma unroll
+            for (int i = 0; i < 4; i++) {
+                lo[i] = (w[i] & 0x0F0F0F0Fu)        | spread4_to_bit4(r.qh >> (4*i));
+                hi[i] = ((w[i] >> 4) & 0x0F0F0F0Fu) | spread4_to_bit4(r.qh >> (16 + 4*i));
+            }
+            off = 16;
+        } else {
+            #pragma unroll
+            for (int i = 0; i < 4; i++) { lo[i] = w[i] & 0x0F0F0F0Fu; hi[i] = (w[i] >> 4) & 0x0F0F0F0Fu; }
+            off = 8;
+        }
+        uint32_t o[16];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o[2*i]       = pack_h2((float) ((int) (lo[i] & 0xFF) - off) * d,         (float) ((int) ((lo[i] >> 8) & 0xFF) - off) * d);
+            o[2*i+1]     = pack_h2((float) ((int) ((lo[i] >> 16) & 0xFF) - off) * d, (float) ((int) (lo[i] >> 24) - off) * d);
+            o[8 + 2*i]   = pack_h2((float) ((int) (hi[i] & 0xFF) - off) * d,         (float) ((int) ((hi[i] >> 8) & 0xFF) - off) * d);
+            o[8 + 2*i+1] = pack_h2((float) ((int) ((hi[i] >> 16) & 0xFF) - off) * d, (float) ((int) (hi[i] >> 24) - off) * d);
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = make_uint4(o[4*i], o[4*i+1], o[4*i+2], o[4*i+3]);
+    }
+    #pragma unroll
+    for (int i = 0; i < 4; i++) *(uint4 *) (lds + lds_off(row, half*4 + i)) = out[i];
+}
+
+template <int AT, int BN>
+__global__ void __launch_bounds__(256) k_gemm_mfma(const GemmArgs a) {
+    constexpr int WN = BN / 2;            // wave tile width (tokens)
+    constexpr int NT = WN / 32;           // 32x32 tiles per wave along n
+    constexpr int BSLOTS = BN * 8 / 256;  // 16-byte B slots per thread (4 or 2)
+    __shared__ __attribute__((aligned(16))) char lds[(BM + BN) * 128];
+    char * ldsA = lds; char * ldsB = lds + BM*128;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int64_t n0 = (int64_t) blockIdx.y * BN;
+
+    // staging assignments
+    const int arow = tid >> 1, ahalf = tid & 1;
+    const bool a_valid = (m0 + arow) < a.M;
+    const int brow = BN == 128 ? (tid >> 1) : (tid >> 2);
+    const int bslot0 = BN == 128 ? (tid & 1) * 4 : (tid & 3) * 2;
+    const bool b_valid = (n0 + brow) < a.T;
+    const uint16_t * bptr = a.B + (n0 + brow) * a.ldb;
+
+    a_regs<AT> ar;
+    uint4 br[BSLOTS];
+
+    auto load_tile = [&](int k0) {
+        a_load<AT>(ar, a, m0 + arow, k0 + ahalf*32, a_valid);
+        #pragma unroll
+        for (int i = 0; i < BSLOTS; i++) {
+            const int k = k0 + (bslot0 + i)*8;
+            br[i] = (b_valid && k < a.K) ? *(const uint4 *) (bptr + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int k0) {
+        a_store<AT>(ar, ldsA, arow, ahalf, k0 + ahalf*32);
+        #pragma unroll
+        for (int i = 0; i < BSLOTS; i++) *(uint4 *) (ldsB + lds_off(brow, bslot0 + i)) = br[i];
+    };
+
+    floatx16 acc[2][NT];
+    #pragma unroll
+    for (int i = 0; i < 2; i++)
+        #pragma unroll
+        for (int j = 0; j < NT; j++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int nk = (a.K + BK - 1) / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+
+        #pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            half8_t af[2], bf[NT];
+            const int slot = kk*2 + (lane >> 5);
+            #pragma unroll
+            for (int i = 0; i < 2; i++) af[i] = *(const half8_t *) (ldsA + lds_off(wm*64 + i*32 + (lane & 31), slot));
+            #pragma unroll
+            for (int j = 0; j < NT; j++) bf[j] = *(const half8_t *) (ldsB + lds_off(wn*WN + j*32 + (lane & 31), slot));
+            #pragma unroll
+            for (int i = 0; i < 2; i++)
+                #pragma unroll
+                for (int j = 0; j < NT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) { store_tile((kt + 1) * BK); __syncthreads(); }
+    }
+
+    // epilogue: C[i = A row][j = B row]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) && !a.dst_f16 &&
+                        (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || ((uintptr_t) a.bias % 16 == 0));
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        #pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int64_t t = n0 + wn*WN + j*32 + (lane & 31);
+            if (t >= a.T) continue;
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int m = m0 + wm*64 + i*32 + 8*g + 4*(lane >> 5);
+                if (m >= a.M) continue;
+                float v[4] = { acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3] };
+                if (vec_ok) {                                   // m % 4 == 0 and M % 4 == 0  =>  m+3 < M
+                    if (a.bias) { const float4 b = *(const float4 *) (a.bias + m); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (a.has_scale) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
+                    if (a.gelu) { v[0] = gelu_lut(v[0], a.gelu_tab); v[1] = gelu_lut(v[1], a.gelu_tab); v[2] = gelu_lut(v[2], a.gelu_tab); v[3] = gelu_lut(v[3], a.gelu_tab); }
+                    if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                    *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (m + e >= a.M) break;
+                        float x = v[e];
+                        if (a.bias) x += a.bias[m + e];
+                        if (a.has_scale) x *= a.scale;
+                        if (a.gelu) x = gelu_lut(x, a.gelu_tab);
+                        if (a.residual) x += *(const float *) (a.residual + t*a.res_nb1 + (int64_t) (m + e)*4);
+                        if (a.dst_f16) *(uint16_t *) (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*2) = f2h(x);
+                        else           *(float *)    (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*4) = x;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int AT>
+static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, double flops) {
+    // pick BN so the grid covers the chip: 128-wide token tiles unless that leaves CUs idle
+    const int64_t mt = (k.M + BM - 1) / BM;
+    const int64_t nt128 = (k.T + 127) / 128, nt64 = (k.T + 63) / 64;
+    if (mt * nt128 >= ctx->n_cu || k.T > 64*65535LL) {
+        if (nt128 > 65535) return MI355X_E_UNSUPPORTED;
+        return emit(ctx, "gemm_mfma", k_gemm_mfma<AT, 128>, dim3((uint32_t) mt, (uint32_t) nt128), dim3(256), 0, k, bytes, flops);
+    }
+    return emit(ctx, "gemm_mfma", k_gemm_mfma<AT, 64>, dim3((uint32_t) mt, (uint32_t) nt64), dim3(256), 0, k, bytes, flops);
+}
+
+// A: [K, M] ggml src0; Bf16: prepared [T][K]; dst column stride dst_nb1
+extern "C" int mi355x_gemm_f16act(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act, int64_t ldb, int64_t T,
+                                  void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep) {
+    if (dst_type != MI355X_TYPE_F32 && dst_type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
+    const uint16_t * Bf16 = (const uint16_t *) act; const int dst_f16 = dst_type == MI355X_TYPE_F16;
+    GemmArgs k; memset(&k, 0, sizeof(k));
+    const int K = (int) A->ne[0], M = (int) A->ne[1];
+    k.A = (const char *) A->data; k.a_nb1 = A->nb[1]; k.B = Bf16; k.ldb = ldb; k.M = M; k.K = K; k.T = T;
+    k.dst = (char *) dst; k.dst_nb1 = dst_nb1; k.dst_f16 = dst_f16; k.gelu_tab = ctx->gelu_tab;
+    if (ep) { k.bias = ep->bias; k.scale = ep->scale; k.has_scale = ep->has_scale; k.gelu = ep->gelu; k.residual = (const char *) ep->residual; k.res_nb1 = ep->residual_nb1; }
+    if (M <= 0 || T <= 0 || K <= 0 || K % 8 || ldb % 8 || ((uintptr_t) Bf16 % 16)) return MI355X_E_UNSUPPORTED;
+    const double flops = 2.0 * M * (double) K * (double) T;
+    double abytes;
+    if (mi355x_type_is_quantized(A->type)) {
+        if (!t_is_contiguous(A) || K % type_block(A->type) || ((uintptr_t) A->data % 16)) return MI355X_E_UNSUPPORTED;
+        k.nbt = (int64_t) M * (K / type_block(A->type));
+        abytes = (double) mi355x_type_row_bytes(A->type, K) * M;
+    } else {
+        const int es = A->type == MI355X_TYPE_F16 ? 2 : 4;
+        if ((A->type != MI355X_TYPE_F16 && A->type != MI355X_TYPE_F32) || A->nb[0] != es || (A->nb[1] % 16) || ((uintptr_t) A->data % 16)) return MI355X_E_UNSUPPORTED;
+        abytes = (double) M * K * es;
+    }
+    const double bytes = abytes + (double) T*K*2 + (double) T*M*(dst_f16 ? 2 : 4);
+    switch (A->type) {
+        case MI355X_TYPE_Q4_0: return launch_gemm<MI355X_TYPE_Q4_0>(ctx, k, bytes, flops);
+        case MI355X_TYPE_Q5_0: return launch_gemm<MI355X_TYPE_Q5_0>(ctx, k, bytes, flops);
+        case MI355X_TYPE_Q8_0: return launch_gemm<MI355X_TYPE_Q8_0>(ctx, k, bytes, flops);
+        case MI355X_TYPE_Q4_K: return launch_gemm<MI355X_TYPE_Q4_K>(ctx, k, bytes, flops);
+        case MI355X_TYPE_F16:  return launch_gemm<MI355X_TYPE_F16>(ctx, k, bytes, flops);
+        case MI355X_TYPE_F32:  return launch_gemm<MI355X_TYPE_F32>(ctx, k, bytes, flops);
+        default: return MI355X_E_UNSUPPORTED;
+    }
+}

@@ -1,0 +1,194 @@
+"""Synthetic whisper.cpp model files (legacy `ggml` bin format) with seeded random weights.
+
+There are no real Whisper checkpoints in the build container or on the GPU box (no network), so every
+parity / benchmark run uses models of the real ARCHITECTURE with random-init weights, written in the
+reference's own file format and then quantized by the reference's own `whisper-quantize`
+(examples/quantize/quantize.cpp) so that the bytes the backend receives through set_tensor are produced by
+the reference's quantizer.
+
+File format (src/whisper.cpp:1485-1700 loader; models/convert-pt-to-ggml.py:264-340 writer):
+  u32 magic 0x67676d6c | 11 x i32 hparams | i32 n_mel, i32 n_fft, f32[n_mel*n_fft] filters |
+  i32 n_vocab, n_vocab x (u32 len, bytes) | tensors: i32 n_dims, i32 name_len, i32 ftype(0=f32,1=f16),
+  i32 ne[n_dims] (ggml order, fastest first), name, data
+Tensor names / shapes: src/whisper-arch.h:42-109, src/whisper.cpp:1757-1843.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+
+ARCHS = {
+    # name: n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer, n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels
+    "tiny.en":        (51864, 1500, 384, 6, 4, 448, 384, 6, 4, 80),
+    "base.en":        (51864, 1500, 512, 8, 6, 448, 512, 8, 6, 80),
+    "small.en":       (51864, 1500, 768, 12, 12, 448, 768, 12, 12, 80),
+    "large-v3":       (51866, 1500, 1280, 20, 32, 448, 1280, 20, 32, 128),
+    "large-v3-turbo": (51866, 1500, 1280, 20, 32, 448, 1280, 20, 4, 128),
+    # reduced-depth variants for fast tests (same widths => same kernels / tiles)
+    "large-v3-2l":    (51866, 1500, 1280, 20, 2, 448, 1280, 20, 2, 128),
+    "micro":          (51864, 1500, 256, 4, 2, 448, 256, 4, 2, 80),
+}
+
+QTYPES = ("f16", "q4_0", "q5_0", "q8_0", "q4_k")
+
+
+def _w_tensor(f, name: str, arr: np.ndarray):
+    """arr in numpy (row-major) order; ggml ne[] is the reverse."""
+    ftype = 1 if arr.dtype == np.float16 else 0
+    nb = name.encode()
+    f.write(struct.pack("iii", arr.ndim, len(nb), ftype))
+    for d in reversed(arr.shape):
+        f.write(struct.pack("i", d))
+    f.write(nb)
+    f.write(arr.tobytes())
+
+
+class _Rng:
+    """Fast seeded normal generator: one 4M-sample pool, consumed with a rolling offset (the statistics matter,
+    not independence across tensors; generating 1.5e9 fresh normals for large-v3 would take minutes)."""
+
+    def __init__(self, seed: int):
+        self.pool = np.random.default_rng(seed).standard_normal(1 << 22).astype(np.float32)
+        self.off = 0
+
+    def normal(self, shape, scale: float) -> np.ndarray:
+        n = int(np.prod(shape))
+        out = np.empty(n, dtype=np.float32)
+        pos = 0
+        while pos < n:
+            take = min(n - pos, self.pool.size - self.off)
+            out[pos:pos + take] = self.pool[self.off:self.off + take]
+            pos += take
+            self.off = (self.off + take + 7919) % self.pool.size   # de-correlate successive tensors a little
+        out *= scale
+        return out.reshape(shape)
+
+
+def write_f16_model(path: Path, arch: str, seed: int = 1234):
+    (n_vocab, n_audio_ctx, n_as, n_ah, n_al, n_text_ctx, n_ts, n_th, n_tl, n_mels) = ARCHS[arch]
+    rng = _Rng(seed)
+    with open(path, "wb") as f:
+        f.write(struct.pack("I", 0x67676D6C))
+        f.write(struct.pack("11i", n_vocab, n_audio_ctx, n_as, n_ah, n_al, n_text_ctx, n_ts, n_th, n_tl, n_mels, 1))
+        # mel filterbank: any non-negative [n_mels x 201] matrix works for the CPU front end; triangular bands
+        n_fft = 201
+        filt = np.zeros((n_mels, n_fft), dtype=np.float32)
+        edges = np.linspace(0, n_fft - 1, n_mels + 2)
+        for m in range(n_mels):
+            lo, c, hi = edges[m], edges[m + 1], edges[m + 2]
+            k = np.arange(n_fft, dtype=np.float32)
+            filt[m] = np.clip(np.minimum((k - lo) / max(c - lo, 1e-3), (hi - k) / max(hi - c, 1e-3)), 0, None) * (2.0 / (hi - lo))
+        f.write(struct.pack("ii", n_mels, n_fft))
+        f.write(filt.tobytes())
+        # vocab: synthetic token strings; the loader appends the special tokens itself (whisper.cpp:1640-1672)
+        n_file = 50257 if n_vocab >= 51865 else 50256
+        f.write(struct.pack("i", n_file))
+        for i in range(n_file):
+            w = (" t%d" % i).encode()
+            f.write(struct.pack("I", len(w)))
+            f.write(w)
+
+        def mat(name, out_f, in_f):          # 2-D weights: f16, N(0, 1/in)
+            _w_tensor(f, name, rng.normal((out_f, in_f), 1.0 / np.sqrt(in_f)).astype(np.float16))
+
+        def vec(name, n, scale=0.02, base=0.0):  # biases / LN: f32
+            _w_tensor(f, name, (rng.normal((n,), scale) + base).astype(np.float32))
+
+        # encoder
+        _w_tensor(f, "encoder.positional_embedding", rng.normal((n_audio_ctx, n_as), 0.02).astype(np.float32))
+        _w_tensor(f, "encoder.conv1.weight", rng.normal((n_as, n_mels, 3), 1.0 / np.sqrt(3 * n_mels)).astype(np.float16))
+        _w_tensor(f, "encoder.conv1.bias", rng.normal((n_as, 1), 0.02).astype(np.float32))
+        _w_tensor(f, "encoder.conv2.weight", rng.normal((n_as, n_as, 3), 1.0 / np.sqrt(3 * n_as)).astype(np.float16))
+        _w_tensor(f, "encoder.conv2.bias", rng.normal((n_as, 1), 0.02).astype(np.float32))
+        vec("encoder.ln_post.weight", n_as, 0.02, 1.0)
+        vec("encoder.ln_post.bias", n_as)
+        for i in range(n_al):
+            p = f"encoder.blocks.{i}."
+            vec(p + "mlp_ln.weight", n_as, 0.02, 1.0); vec(p + "mlp_ln.bias", n_as)
+            mat(p + "mlp.0.weight", 4 * n_as, n_as); vec(p + "mlp.0.bias", 4 * n_as)
+            mat(p + "mlp.2.weight", n_as, 4 * n_as); vec(p + "mlp.2.bias", n_as)
+            vec(p + "attn_ln.weight", n_as, 0.02, 1.0); vec(p + "attn_ln.bias", n_as)
+            mat(p + "attn.query.weight", n_as, n_as); vec(p + "attn.query.bias", n_as)
+            mat(p + "attn.key.weight", n_as, n_as)
+            mat(p + "attn.value.weight", n_as, n_as); vec(p + "attn.value.bias", n_as)
+            mat(p + "attn.out.weight", n_as, n_as); vec(p + "attn.out.bias", n_as)
+        # decoder
+        _w_tensor(f, "decoder.positional_embedding", rng.normal((n_text_ctx, n_ts), 0.02).astype(np.float32))
+        # token embedding doubles as the logits matrix: larger scale so that logits are well separated
+        _w_tensor(f, "decoder.token_embedding.weight", rng.normal((n_vocab, n_ts), 0.05).astype(np.float16))
+        vec("decoder.ln.weight", n_ts, 0.02, 1.0)
+        vec("decoder.ln.bias", n_ts)
+        for i in range(n_tl):
+            p = f"decoder.blocks.{i}."
+            vec(p + "mlp_ln.weight", n_ts, 0.02, 1.0); vec(p + "mlp_ln.bias", n_ts)
+            mat(p + "mlp.0.weight", 4 * n_ts, n_ts); vec(p + "mlp.0.bias", 4 * n_ts)
+            mat(p + "mlp.2.weight", n_ts, 4 * n_ts); vec(p + "mlp.2.bias", n_ts)
+            vec(p + "attn_ln.weight", n_ts, 0.02, 1.0); vec(p + "attn_ln.bias", n_ts)
+            mat(p + "attn.query.weight", n_ts, n_ts); vec(p + "attn.query.bias", n_ts)
+            mat(p + "attn.key.weight", n_ts, n_ts)
+            mat(p + "attn.value.weight", n_ts, n_ts); vec(p + "attn.value.bias", n_ts)
+            mat(p + "attn.out.weight", n_ts, n_ts); vec(p + "attn.out.bias", n_ts)
+            vec(p + "cross_attn_ln.weight", n_ts, 0.02, 1.0); vec(p + "cross_attn_ln.bias", n_ts)
+            mat(p + "cross_attn.query.weight", n_ts, n_ts); vec(p + "cross_attn.query.bias", n_ts)
+            mat(p + "cross_attn.key.weight", n_ts, n_ts)
+            mat(p + "cross_attn.value.weight", n_ts, n_ts); vec(p + "cross_attn.value.bias", n_ts)
+            mat(p + "cross_attn.out.weight", n_ts, n_ts); vec(p + "cross_attn.out.bias", n_ts)
+
+
+def make_model(arch: str, qtype: str, out_dir: Path | None = None, seed: int = 1234, quantize_bin: Path | None = None) -> Path:
+    """Create (or reuse) <out_dir>/synth-<arch>-<qtype>.bin and return its path."""
+    assert arch in ARCHS and qtype in QTYPES
+    out_dir = Path(out_dir or os.environ.get("WHISPER_SYNTH_DIR", "/tmp/whisper_synth"))
+    out_dir.mkdir(parents=True, exist_ok=True)
+    f16 = out_dir / f"synth-{arch}-f16.bin"
+    if not f16.exists():
+        tmp = f16.with_suffix(".tmp")
+        write_f16_model(tmp, arch, seed)
+        tmp.rename(f16)
+    if qtype == "f16":
+        return f16
+    q = out_dir / f"synth-{arch}-{qtype}.bin"
+    if not q.exists():
+        qb = Path(quantize_bin or ROOT / "oracle" / "_ref" / "whisper-quantize")
+        tmp = q.with_suffix(".tmp")
+        r = subprocess.run([str(qb), str(f16), str(tmp), qtype], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0 or not tmp.exists():
+            raise RuntimeError(f"whisper-quantize failed:\n{r.stdout[-2000:]}")
+        tmp.rename(q)
+    return q
+
+
+def synth_audio(n_samples: int = 16000 * 11, seed: int = 7) -> np.ndarray:
+    """Deterministic speech-like test signal (chirps + amplitude modulation + noise), f32 in [-1, 1], 16 kHz."""
+    t = np.arange(n_samples, dtype=np.float64) / 16000.0
+    rng = np.random.default_rng(seed)
+    x = 0.35 * np.sin(2 * np.pi * (180 + 60 * np.sin(2 * np.pi * 0.7 * t)) * t)
+    x += 0.20 * np.sin(2 * np.pi * (700 + 300 * np.sin(2 * np.pi * 1.3 * t)) * t)
+    x += 0.10 * np.sin(2 * np.pi * (2300 + 500 * np.sin(2 * np.pi * 0.4 * t)) * t)
+    x *= 0.5 * (1 + np.sin(2 * np.pi * 3.1 * t)) * (t % 2.0 < 1.6)
+    x += 0.02 * rng.standard_normal(n_samples)
+    return np.clip(x, -1, 1).astype(np.float32)
+
+
+def write_wav(path: Path, pcm: np.ndarray):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.clip(pcm, -1, 1) * 32767).astype("<i2").tobytes())
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="base.en", choices=sorted(ARCHS))
+    ap.add_argument("--qtype", default="q5_0", choices=QTYPES)
+    ap.add_argument("--out-dir", default=None)
+    ap.add_argument("--seed", type=int, default=1234)
+    a = ap.parse_args()
+    print(make_model(a.arch, a.qtype, a.out_dir, a.seed))
