@@ -1,0 +1,128 @@
+// Model-level parity: the same whisper.cpp model file evaluated through the UNMODIFIED reference libwhisper
+// once on the reference CPU backend (use_gpu = false) and once with the MI355X plugin (use_gpu = true), same
+// seeded mel input, greedy decoding with teacher forcing on the CPU's tokens so that both stay on one path.
+// Prints one JSON object: logits error per step, argmax agreement, and a free-running greedy transcript
+// comparison.  TEST code (links the reference libraries).
+#include "whisper.h"
+#include "ggml-backend.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+static void log_quiet(enum ggml_log_level level, const char * text, void *) {
+    if (level == GGML_LOG_LEVEL_ERROR || getenv("MODEL_PARITY_VERBOSE")) fputs(text, stderr);
+}
+
+struct cmp_t { double nmse = 0, max_diff = 0, max_ref = 0; int argmax_ref = -1, argmax_got = -1; double margin_ref = 0; };
+
+static cmp_t cmp_logits(const float * a, const float * b, int n) {
+    cmp_t c; double num = 0, den = 0; float ba = -INFINITY, bb = -INFINITY, second = -INFINITY;
+    for (int i = 0; i < n; i++) {
+        const double d = (double) a[i] - b[i];
+        num += d * d; den += (double) a[i] * a[i];
+        c.max_diff = std::max(c.max_diff, fabs(d)); c.max_ref = std::max(c.max_ref, (double) fabs(a[i]));
+        if (a[i] > ba) { second = ba; ba = a[i]; c.argmax_ref = i; } else if (a[i] > second) second = a[i];
+        if (b[i] > bb) { bb = b[i]; c.argmax_got = i; }
+    }
+    c.nmse = den > 0 ? num / den : num; c.margin_ref = ba - second;
+    return c;
+}
+
+int main(int argc, char ** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s model.bin [n_steps=24] [flash_attn=1]\n  env GGML_MI355X_PLUGIN=path\n", argv[0]); return 2; }
+    const char * model = argv[1];
+    const int n_steps = argc > 2 ? atoi(argv[2]) : 24;
+    const bool fa = argc > 3 ? atoi(argv[3]) != 0 : true;
+    const int n_threads = 8;
+    whisper_log_set(log_quiet, nullptr);
+    const char * plugin = getenv("GGML_MI355X_PLUGIN");
+    const bool selftest = plugin && !strcmp(plugin, "cpu");     // harness self-test: CPU against CPU
+    if (!selftest && (!plugin || !ggml_backend_load(plugin))) { fprintf(stderr, "cannot load plugin (GGML_MI355X_PLUGIN)\n"); return 3; }
+
+    whisper_context_params cp = whisper_context_default_params();
+    cp.flash_attn = fa;
+    cp.use_gpu = false;
+    whisper_context * cpu = whisper_init_from_file_with_params(model, cp);
+    cp.use_gpu = !selftest; cp.gpu_device = 0;
+    whisper_context * gpu = whisper_init_from_file_with_params(model, cp);
+    if (!cpu || !gpu) { fprintf(stderr, "model load failed\n"); return 3; }
+
+    const int n_mels = whisper_model_n_mels(cpu), n_vocab = whisper_n_vocab(cpu), n_len = 3000;
+    std::vector<float> mel((size_t) n_mels * n_len);
+    std::mt19937 rng(42);
+    for (int j = 0; j < n_mels; j++) for (int i = 0; i < n_len; i++)
+        mel[(size_t) j * n_len + i] = 0.6f * sinf(0.013f * i + 0.21f * j) + 0.4f * ((rng() >> 8) * (1.0f / 8388608.0f) - 1.0f);
+    whisper_set_mel(cpu, mel.data(), n_len, n_mels);
+    whisper_set_mel(gpu, mel.data(), n_len, n_mels);
+
+    auto t0 = std::chrono::steady_clock::now();
+    if (whisper_encode(cpu, 0, n_threads) != 0) { fprintf(stderr, "cpu encode failed\n"); return 4; }
+    auto t1 = std::chrono::steady_clock::now();
+    if (whisper_encode(gpu, 0, n_threads) != 0) { fprintf(stderr, "gpu encode failed\n"); return 4; }
+    auto t2 = std::chrono::steady_clock::now();
+    if (whisper_encode(gpu, 0, n_threads) != 0) { fprintf(stderr, "gpu encode failed\n"); return 4; }
+    auto t3 = std::chrono::steady_clock::now();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+
+    printf("{\"model\": \"%s\", \"flash_attn\": %d, \"encode_ms_cpu\": %.2f, \"encode_ms_gpu_first\": %.2f, \"encode_ms_gpu\": %.2f,\n", model, fa ? 1 : 0, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+
+    // ---- teacher-forced single-token steps ----
+    double worst_nmse = 0, worst_diff = 0, max_ref = 0, min_margin_on_mismatch = 1e30; int agree = 0;
+    whisper_token tok = whisper_token_sot(cpu);
+    double gpu_ms = 0, cpu_ms = 0;
+    printf(" \"steps\": [");
+    for (int i = 0; i < n_steps; i++) {
+        auto a0 = std::chrono::steady_clock::now();
+        if (whisper_decode(cpu, &tok, 1, i, n_threads) != 0) { fprintf(stderr, "cpu decode failed\n"); return 4; }
+        auto a1 = std::chrono::steady_clock::now();
+        if (whisper_decode(gpu, &tok, 1, i, n_threads) != 0) { fprintf(stderr, "gpu decode failed\n"); return 4; }
+        auto a2 = std::chrono::steady_clock::now();
+        cpu_ms += ms(a0, a1); gpu_ms += ms(a1, a2);
+        const cmp_t c = cmp_logits(whisper_get_logits(cpu), whisper_get_logits(gpu), n_vocab);
+        worst_nmse = std::max(worst_nmse, c.nmse); worst_diff = std::max(worst_diff, c.max_diff); max_ref = std::max(max_ref, c.max_ref);
+        if (c.argmax_ref == c.argmax_got) agree++; else min_margin_on_mismatch = std::min(min_margin_on_mismatch, c.margin_ref);
+        printf("%s{\"nmse\": %.3e, \"max_diff\": %.3e, \"tok_cpu\": %d, \"tok_gpu\": %d, \"margin\": %.3e}", i ? ", " : "", c.nmse, c.max_diff, c.argmax_ref, c.argmax_got, c.margin_ref);
+        tok = c.argmax_ref;
+        if (tok >= whisper_token_eot(cpu)) tok = (whisper_token) (i * 7919 % 50000);    // keep decoding text tokens
+    }
+    printf("],\n \"single\": {\"steps\": %d, \"argmax_agree\": %d, \"worst_nmse\": %.3e, \"worst_abs_diff\": %.3e, \"max_abs_logit\": %.3e, \"min_margin_on_mismatch\": %.3e, \"ms_per_tok_cpu\": %.3f, \"ms_per_tok_gpu\": %.3f},\n",
+           n_steps, agree, worst_nmse, worst_diff, max_ref, min_margin_on_mismatch > 1e29 ? -1.0 : min_margin_on_mismatch, cpu_ms / n_steps, gpu_ms / n_steps);
+
+    // ---- batches: 5 tokens (beam-sized) and a 48-token prompt, n_past = 0 ----
+    for (int nb : { 5, 48 }) {
+        std::vector<whisper_token> toks(nb);
+        for (int i = 0; i < nb; i++) toks[i] = (whisper_token) ((i * 2654435761u + 17) % 50000);
+        if (whisper_decode(cpu, toks.data(), nb, 0, n_threads) != 0 || whisper_decode(gpu, toks.data(), nb, 0, n_threads) != 0) { fprintf(stderr, "batch decode failed\n"); return 4; }
+        double wn = 0, wd = 0; int ag = 0;
+        // whisper_get_logits: rows for the tokens that requested logits (only the last one by default, whisper.cpp:3961-3969)
+        const cmp_t c = cmp_logits(whisper_get_logits(cpu), whisper_get_logits(gpu), n_vocab);
+        wn = c.nmse; wd = c.max_diff; ag = c.argmax_ref == c.argmax_got;
+        printf(" \"batch%d\": {\"nmse\": %.3e, \"max_diff\": %.3e, \"argmax_agree\": %d},\n", nb, wn, wd, ag);
+    }
+
+    // ---- free-running greedy: each side follows its own argmax ----
+    std::vector<int> seq_c, seq_g;
+    for (int side = 0; side < 2; side++) {
+        whisper_context * ctx = side ? gpu : cpu;
+        std::vector<int> & seq = side ? seq_g : seq_c;
+        whisper_token t = whisper_token_sot(ctx);
+        for (int i = 0; i < n_steps; i++) {
+            if (whisper_decode(ctx, &t, 1, i, n_threads) != 0) return 4;
+            const float * l = whisper_get_logits(ctx);
+            int best = 0; for (int k = 1; k < whisper_token_eot(ctx); k++) if (l[k] > l[best]) best = k;   // text tokens only
+            seq.push_back(best); t = best;
+        }
+    }
+    int same = 0; while (same < n_steps && seq_c[same] == seq_g[same]) same++;
+    printf(" \"greedy\": {\"steps\": %d, \"identical_prefix\": %d}}\n", n_steps, same);
+
+    whisper_free(cpu); whisper_free(gpu);
+    return 0;
+}
