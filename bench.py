@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""whisper-bench encoder+decoder ms per 30 s chunk on MI355X (BASELINE.json metric), N independent streams on N GPUs.
+
+A "step" is one pass of the hot path over one 30 s chunk, with the whisper-bench protocol
+(/root/reference/examples/bench/bench.cpp:124-136): 1 x whisper_encode (conv + encoder + cross-KV graphs) followed by
+256 x whisper_decode(n_tokens = 1, n_past = i).  The host is the UNMODIFIED reference application
+(whisper.cpp_amd/host/_whisper/libwhisper.so, built from the reference sources by oracle/Makefile); all compute runs in
+the MI355X ggml backend plugin loaded through ggml's own plugin loader.  GGML_MI355X_STRICT=1 turns any CPU fallback
+into an abort, so a number printed here was computed by the HIP kernels.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--arch large-v3] [--qtype q5_0]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One JSON line on stdout (rank 0).  `value` = wall ms per chunk aggregated over all streams (T_max / (K*N)); per-stream
+latency is `ms_per_step`.  Weights are synthetic (seeded random, real architecture, reference quantizer); mel is seeded
+random.  `roofline` comes from a hipEvent-bracketed replay of one extra chunk inside this process; `cpu_baseline` is the
+reference CPU path (oracle/_ref, AVX2 build) on a bounded sample, rank 0 at N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
+
+
+class ContextParams(C.Structure):       # struct whisper_context_params, include/whisper.h:116-129
+    _fields_ = [("use_gpu", C.c_bool), ("flash_attn", C.c_bool), ("gpu_device", C.c_int), ("dtw_token_timestamps", C.c_bool),
+                ("dtw_aheads_preset", C.c_int), ("dtw_n_top", C.c_int), ("dtw_n_heads", C.c_size_t), ("dtw_heads", C.c_void_p),
+                ("dtw_mem_size", C.c_size_t)]
+
+
+class Timings(C.Structure):             # struct whisper_timings, include/whisper.h:438-444
+    _fields_ = [("sample_ms", C.c_float), ("encode_ms", C.c_float), ("decode_ms", C.c_float), ("batchd_ms", C.c_float), ("prompt_ms", C.c_float)]
+
+
+class ProfRow(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("calls", C.c_uint64), ("total_ms", C.c_double), ("algo_bytes", C.c_double), ("algo_flops", C.c_double)]
+
+
+def load_host(plugin: Path):
+    host = ROOT / "whisper.cpp_amd" / "host" / "_whisper"
+    if not (host / "libwhisper.so").exists():
+        raise RuntimeError(f"{host}/libwhisper.so missing: run `python -c 'import __graft_entry__ as g; g.build()'` where the reference tree exists")
+    if not plugin.exists():
+        raise RuntimeError(f"{plugin} missing (no CPU fallback exists): build first")
+    for n in ("libggml-base.so", "libggml-cpu.so", "libggml.so"):
+        C.CDLL(str(host / n), mode=C.RTLD_GLOBAL)
+    w = C.CDLL(str(host / "libwhisper.so"), mode=C.RTLD_GLOBAL)
+    C.CDLL(str(ROOT / "whisper.cpp_amd" / "lib" / "libmi355x_kernels.so"), mode=C.RTLD_GLOBAL)
+    g = C.CDLL(str(host / "libggml.so"))
+    g.ggml_backend_load.restype = C.c_void_p
+    g.ggml_backend_load.argtypes = [C.c_char_p]
+    reg = g.ggml_backend_load(str(plugin).encode())
+    if not reg:
+        raise RuntimeError("ggml_backend_load rejected the MI355X plugin (no gfx950 device?)")
+    p = C.CDLL(str(plugin))
+    w.whisper_context_default_params.restype = ContextParams
+    w.whisper_init_from_file_with_params.restype = C.c_void_p
+    w.whisper_init_from_file_with_params.argtypes = [C.c_char_p, ContextParams]
+    w.whisper_set_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    w.whisper_encode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    w.whisper_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    w.whisper_model_n_mels.argtypes = [C.c_void_p]
+    w.whisper_get_timings.restype = C.POINTER(Timings)
+    w.whisper_get_timings.argtypes = [C.c_void_p]
+    w.whisper_reset_timings.argtypes = [C.c_void_p]
+    w.whisper_free.argtypes = [C.c_void_p]
+    p.ggml_backend_mi355x_prof_report_all.argtypes = [C.POINTER(ProfRow), C.c_int]
+    p.ggml_backend_mi355x_stats.argtypes = [C.POINTER(C.c_uint64)]
+    return w, p
+
+
+def algorithmic_figures(arch: str, qtype: str):
+    """algorithmic HBM bytes per decoded token and FLOPs per encode, from the hyper-parameters."""
+    from whisper_cpp_amd.synth_model import ARCHS
+    (n_vocab, n_actx, n_as, n_ah, n_al, n_tctx, n_ts, n_th, n_tl, n_mels) = ARCHS[arch]
+    bpw = {"q4_0": 18 / 32, "q4_k": 144 / 256, "q5_0": 22 / 32, "q8_0": 34 / 32, "f16": 2.0}[qtype]
+    n_ctx_pad = (n_actx + 255) // 256 * 256
+    dec_w = n_tl * (4 + 4 + 8) * n_ts * n_ts + n_vocab * n_ts            # self-attn 4n^2, cross-attn q/k(v precomputed)/o ... + mlp 8n^2 + logits
+    dec_w = n_tl * (4 * n_ts * n_ts + 2 * n_ts * n_ts + 8 * n_ts * n_ts) + n_vocab * n_ts
+    kv_cross = n_tl * 2 * n_ctx_pad * n_ts * 2
+    enc_flop = 2.0 * n_actx * n_al * 12 * n_as * n_as + 4.0 * n_actx * n_ctx_pad * n_as * n_al \
+        + 2.0 * (2 * n_actx) * n_as * 3 * n_mels + 2.0 * n_actx * n_as * 3 * n_as + 2.0 * n_actx * n_tl * 2 * n_ts * n_ts
+    return {"decode_bytes_per_token": dec_w * bpw + kv_cross, "encode_flop": enc_flop}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--arch", default="large-v3")
+    ap.add_argument("--qtype", default="q5_0")
+    ap.add_argument("--n-decode", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-only", action="store_true", help="print the per-kernel hipEvent profile of one chunk and exit")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("GGML_MI355X_STRICT", "1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    import __graft_entry__ as graft
+    graft.load_package()
+    from whisper_cpp_amd.synth_model import make_model
+
+    # rank 0 writes the synthetic model file once; every rank loads the same file (one replica per GPU).
+    # Replicas are independent streams: no data-path collective.
+    if rank == 0:
+        model = make_model(a.arch, a.qtype)
+    barrier()
+    model = make_model(a.arch, a.qtype)
+
+    plugin = ROOT / "whisper.cpp_amd" / "lib" / "libggml-mi355x.so"
+    w, p = load_host(plugin)
+    cp = w.whisper_context_default_params()
+    cp.use_gpu, cp.flash_attn, cp.gpu_device = True, True, local_rank
+    ctx = w.whisper_init_from_file_with_params(str(model).encode(), cp)
+    if not ctx:
+        raise SystemExit("whisper_init_from_file_with_params failed")
+    n_mels = w.whisper_model_n_mels(ctx)
+    mel = (np.random.default_rng(42 + rank).random((n_mels, 3000), dtype=np.float32) * 2 - 1)
+    w.whisper_set_mel(ctx, mel.ctypes.data_as(C.c_void_p), 3000, n_mels)
+    tokens = (C.c_int32 * 512)()
+    n_threads = 4
+
+    def chunk():
+        if w.whisper_encode(ctx, 0, n_threads) != 0:
+            raise RuntimeError("whisper_encode failed")
+        for i in range(a.n_decode):
+            if w.whisper_decode(ctx, tokens, 1, i, n_threads) != 0:
+                raise RuntimeError("whisper_decode failed")
+
+    def profile_chunk():
+        p.ggml_backend_mi355x_prof_enable_all(1)
+        p.ggml_backend_mi355x_prof_reset_all()
+        chunk()
+        rows = (ProfRow * 64)()
+        n = p.ggml_backend_mi355x_prof_report_all(rows, 64)
+        p.ggml_backend_mi355x_prof_enable_all(0)
+        return [dict(name=rows[i].name.decode(), calls=int(rows[i].calls), total_ms=rows[i].total_ms, algo_bytes=rows[i].algo_bytes,
+                     algo_flops=rows[i].algo_flops) for i in range(n)]
+
+    if a.profile_only:
+        chunk()
+        prof = sorted(profile_chunk(), key=lambda r: -r["total_ms"])
+        print(json.dumps({"arch": a.arch, "qtype": a.qtype, "kernels": prof}, indent=1))
+        return
+
+    from whisper_cpp_amd.dist_timing import aggregate, timed_region
+    for _ in range(a.warmup):
+        chunk()
+    w.whisper_reset_timings(ctx)
+    # barrier + synchronize on both sides, exactly K steps, MAX over ranks.  Every whisper_encode / whisper_decode
+    # returns only after the backend's stream is drained (ggml_backend_sched_synchronize), torch.cuda.synchronize()
+    # additionally drains the device.
+    elapsed_s = timed_region(chunk, a.steps, dist, torch.cuda.synchronize, "cuda")
+    tm = w.whisper_get_timings(ctx).contents
+    encode_ms, decode_ms = float(tm.encode_ms), float(tm.decode_ms)
+
+    # reported beside the headline (bench.cpp:138-152): 5-token batches and 256-token prompts
+    w.whisper_reset_timings(ctx)
+    for _ in range(16):
+        w.whisper_decode(ctx, tokens, 5, 0, n_threads)
+    for _ in range(4):
+        w.whisper_decode(ctx, tokens, 256, 0, n_threads)
+    tm = w.whisper_get_timings(ctx).contents
+    batchd_ms, prompt_ms = float(tm.batchd_ms), float(tm.prompt_ms)
+
+    prof = profile_chunk() if rank == 0 else []
+    stats = (C.c_uint64 * 4)()
+    p.ggml_backend_mi355x_stats(stats)
+
+    if rank == 0:
+        figs = algorithmic_figures(a.arch, a.qtype)
+        ms_per_step, agg_ms, chunks_per_s = aggregate(elapsed_s, a.steps, world)
+        out = {
+            "metric": "whisper-bench encoder+decoder ms per 30s chunk", "value": round(agg_ms, 4), "unit": "ms/chunk",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": False,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int8 dot (decode) / f16 MFMA (encode), f32 accumulate", "data": "synthetic",
+            "config": {"workload": f"{a.arch} {a.qtype.upper()}: 1 x whisper_encode + {a.n_decode} x whisper_decode(1 token), one stream per GPU",
+                       "streams": world, "flash_attn": True, "weights": "seeded random, reference quantizer", "mel": "seeded uniform(-1,1)"},
+            "chunks_per_s": round(chunks_per_s, 4),
+            "encode_ms": round(encode_ms, 3), "decode_ms_per_token": round(decode_ms, 4),
+            "batchd_ms_per_token": round(batchd_ms, 4), "prompt_ms_per_token": round(prompt_ms, 4),
+            "hip_graph": {"graph_computes": int(stats[0]), "replays": int(stats[1]), "patched_nodes": int(stats[2]), "builds": int(stats[3])},
+        }
+        if prof:
+            dom = max(prof, key=lambda r: r["total_ms"])
+            total = sum(r["total_ms"] for r in prof)
+            avg_ms = dom["total_ms"] / max(dom["calls"], 1)
+            if dom["name"] in ("gemm_mfma", "fattn_mfma"):
+                ach = dom["algo_flops"] / (dom["total_ms"] * 1e-3) / 1e12
+                out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None}
+            else:
+                ach = dom["algo_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
+                out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            out["roofline"].update({"launches": dom["calls"], "avg_launch_us": round(avg_ms * 1e3, 3), "share_of_gpu_time": round(dom["total_ms"] / total, 4),
+                                    "algorithmic_per_launch": (dom["algo_bytes"] if out["roofline"]["bound"] == "hbm" else dom["algo_flops"]) / max(dom["calls"], 1)})
+            out["kernel_time_ms_per_chunk"] = {r["name"]: round(r["total_ms"], 3) for r in sorted(prof, key=lambda r: -r["total_ms"])}
+            dec_bytes = figs["decode_bytes_per_token"]
+            out["step_roofline"] = {"decode_algorithmic_MB_per_token": round(dec_bytes / 1e6, 2),
+                                    "decode_GBps_at_measured_ms": round(dec_bytes / (decode_ms * 1e-3) / 1e9, 1) if decode_ms > 0 else None,
+                                    "encode_TFLOP": round(figs["encode_flop"] / 1e12, 3),
+                                    "encode_TFLOPs_at_measured_ms": round(figs["encode_flop"] / (encode_ms * 1e-3) / 1e12, 2) if encode_ms > 0 else None}
+        if world == 1 and not a.no_cpu_baseline:
+            exe = ROOT / "oracle" / "_ref" / "cpu_baseline"
+            cores = os.cpu_count() or 1
+            n_dec = 16 if "large" in a.arch else 64
+            try:
+                env = dict(os.environ, LD_LIBRARY_PATH=str(ROOT / "oracle" / "_ref"))
+                r = subprocess.run([str(exe), str(model), str(cores), str(n_dec), "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
+                cb = json.loads(r.stdout.strip().splitlines()[-1])
+                out["cpu_baseline"] = {"value": round(cb["encode_ms"] + a.n_decode * cb["decode_ms_per_token"], 2), "unit": "ms/chunk", "cores": cores,
+                                       "kind": "reference", "encode_ms": cb["encode_ms"], "decode_ms_per_token": cb["decode_ms_per_token"],
+                                       "sample": f"reference AVX2 CPU path (oracle/_ref, use_gpu=false): 1 cold whisper_encode + {n_dec} single-token decodes, "
+                                                 f"extrapolated to encode + {a.n_decode} x decode", "system_info": cb["system_info"].strip()}
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "ms/chunk", "cores": cores, "kind": "reference", "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    w.whisper_free(ctx)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,13 @@ GGML_MI355X_API void ggml_backend_mi355x_prof_enable(void * backend, int on);
 GGML_MI355X_API void ggml_backend_mi355x_prof_reset(void * backend);
 GGML_MI355X_API int  ggml_backend_mi355x_prof_report(void * backend, struct ggml_mi355x_prof_row * rows, int cap);
 
+/* process-wide variants over every live MI355X backend (whisper.h does not expose its ggml_backend_t handles);
+ * ggml_backend_mi355x_stats fills out[4] = {graph_compute calls, hipGraph replays, patched kernel nodes, graph builds} */
+GGML_MI355X_API void ggml_backend_mi355x_prof_enable_all(int on);
+GGML_MI355X_API void ggml_backend_mi355x_prof_reset_all(void);
+GGML_MI355X_API int  ggml_backend_mi355x_prof_report_all(struct ggml_mi355x_prof_row * rows, int cap);
+GGML_MI355X_API void ggml_backend_mi355x_stats(uint64_t * out);
+
 /* Multi-GPU weight distribution: device-to-device copy of every WEIGHTS buffer allocated on
  * `src_device` into the identically laid out buffers on `dst_device` of the same process (xGMI peer copy).
  * Across processes the same buffers are broadcast with RCCL by the host harness through

@@ -217,6 +217,10 @@ MI355X_API int mi355x_rope(mi355x_ctx * ctx, const mi355x_tensor * x, const mi35
 /* ggml_concat along `dim` for F32 (CPU ggml-cpu/ops.cpp concat; dtw timestamps only, src/whisper.cpp:2741) */
 MI355X_API int mi355x_concat(mi355x_ctx * ctx, const mi355x_tensor * a, const mi355x_tensor * b, const mi355x_tensor * dst, int dim);
 
+/* the 65536-entry f16 GELU lookup table the kernels use (== ggml_table_gelu_f16, ggml-cpu/ggml-cpu.c:3847),
+ * computed on the host; exposed so that tests can compare it with the reference's table without a GPU */
+MI355X_API void mi355x_gelu_table_host(uint16_t * out65536);
+
 /* memset / memcpy helpers on the context stream */
 MI355X_API int mi355x_memset(mi355x_ctx * ctx, void * dptr, int value, size_t n);
 

@@ -1,0 +1,85 @@
+"""Generate the golden vectors that pin oracle/oracle.c, FROM THE REFERENCE ITSELF (oracle/_ref, built by
+oracle/Makefile from /root/reference).  Run in the build container:  python tests/golden/make_golden.py
+
+  tests/golden/ops.npz     op-level cases computed by the reference CPU backend through ggml graphs
+                           (tests/native/bin/op_parity with OP_PARITY_DUMP; inputs are raw ggml block bytes)
+  tests/golden/blocks.npz  block-level cases from the reference's exported functions (ctypes on libggml-base /
+                           libggml-cpu): dequantize_row_*, quantize_row_*_ref, the AVX2 quantize_row_q8_0,
+                           quantize_row_q8_K, ggml_vec_dot_*, ggml_fp32_to_fp16_row, ggml_table_gelu_f16
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import tempfile
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+REF = ROOT / "oracle" / "_ref"
+
+
+def ops_npz():
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, OP_PARITY_DUMP=d, GGML_MI355X_PLUGIN="cpu")
+        subprocess.run([str(ROOT / "tests/native/bin/op_parity")], env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        out = {}
+        manifest = []
+        for line in open(Path(d) / "manifest.jsonl"):
+            m = json.loads(line)
+            manifest.append(m)
+            for i, leaf in enumerate(m["leaves"]):
+                out[f"{m['case']}.leaf{i}"] = np.fromfile(Path(d) / leaf["file"], dtype=np.uint8)
+            for i, o in enumerate(m["outs"]):
+                out[f"{m['case']}.out{i}"] = np.fromfile(Path(d) / o["file"], dtype=np.float32)
+        out["manifest"] = np.frombuffer(json.dumps(manifest).encode(), dtype=np.uint8)
+        np.savez_compressed(HERE / "ops.npz", **out)
+        print("ops.npz:", len(manifest), "cases")
+
+
+def blocks_npz():
+    base = C.CDLL(str(REF / "libggml-base.so"), mode=C.RTLD_GLOBAL)
+    cpu = C.CDLL(str(REF / "libggml-cpu.so"), mode=C.RTLD_GLOBAL)
+    cpu.ggml_cpu_init()
+    rng = np.random.default_rng(20260921)
+    n = 1024
+    x = (rng.standard_normal(n) * np.repeat(rng.uniform(0.01, 30, n // 32), 32)).astype(np.float32)
+    x[64:96] = 0.0                                     # an all-zero block
+    x[96] = 127.5; x[97] = -0.5; x[98] = 2.5           # exact .5 ties after scaling (amax = 127.5 -> id = 127/127.5)
+    w = (rng.standard_normal(n) * 0.05).astype(np.float32)
+    out = {"x": x, "w": w}
+    sizes = {"q4_0": 18 * n // 32, "q5_0": 22 * n // 32, "q8_0": 34 * n // 32, "q4_K": 144 * n // 256}
+    for t, nb in sizes.items():
+        blk = np.zeros(nb, dtype=np.uint8)
+        getattr(base, f"quantize_row_{t}_ref")(w.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), C.c_int64(n))
+        deq = np.zeros(n, dtype=np.float32)
+        getattr(base, f"dequantize_row_{t}")(blk.ctypes.data_as(C.c_void_p), deq.ctypes.data_as(C.c_void_p), C.c_int64(n))
+        out[f"wblk_{t}"] = blk
+        out[f"wdeq_{t}"] = deq
+    a8 = np.zeros(34 * n // 32, dtype=np.uint8)
+    cpu.quantize_row_q8_0(x.ctypes.data_as(C.c_void_p), a8.ctypes.data_as(C.c_void_p), C.c_int64(n))      # AVX2 path
+    out["act_q8_0"] = a8
+    aK = np.zeros(292 * n // 256, dtype=np.uint8)
+    cpu.quantize_row_q8_K(x.ctypes.data_as(C.c_void_p), aK.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    out["act_q8_K"] = aK
+    for t in sizes:
+        s = C.c_float(0)
+        act = aK if t == "q4_K" else a8
+        fn = getattr(cpu, f"ggml_vec_dot_{t}_q8_{'K' if t == 'q4_K' else '0'}")
+        fn(C.c_int(n), C.byref(s), C.c_size_t(0), out[f"wblk_{t}"].ctypes.data_as(C.c_void_p), C.c_size_t(0),
+           act.ctypes.data_as(C.c_void_p), C.c_size_t(0), C.c_int(1))
+        out[f"dot_{t}"] = np.float32(s.value)
+    h = np.zeros(n, dtype=np.uint16)
+    base.ggml_fp32_to_fp16_row(x.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), C.c_int64(n))
+    out["x_f16"] = h
+    tab = (C.c_uint16 * 65536).in_dll(cpu, "ggml_table_gelu_f16")
+    out["gelu_table"] = np.frombuffer(tab, dtype=np.uint16).copy()
+    np.savez_compressed(HERE / "blocks.npz", **out)
+    print("blocks.npz:", sorted(out))
+
+
+if __name__ == "__main__":
+    ops_npz()
+    blocks_npz()

@@ -124,6 +124,30 @@ static void run_case(const std::string & name, const build_fn & fn, bool node_mo
             ggml_backend_graph_compute(g_cpu, gf);
         }
         for (auto * o : outs) ref.push_back(read_f32(o));
+        if (const char * dump = getenv("OP_PARITY_DUMP")) {
+            // golden-vector export: raw leaf bytes (ggml block layout) + f32 outputs + one manifest line per case
+            std::string man = "{\"case\": \"" + name + "\", \"leaves\": [";
+            for (size_t i = 0; i < b.leaves.size(); i++) {
+                const ggml_tensor * t = b.leaves[i].first;
+                std::vector<uint8_t> raw(ggml_nbytes(t));
+                ggml_backend_tensor_get(t, raw.data(), 0, raw.size());
+                const std::string fn = name + ".leaf" + std::to_string(i) + ".bin";
+                FILE * f = fopen((std::string(dump) + "/" + fn).c_str(), "wb"); fwrite(raw.data(), 1, raw.size(), f); fclose(f);
+                char buf2[256]; snprintf(buf2, sizeof(buf2), "%s{\"file\": \"%s\", \"type\": %d, \"ne\": [%lld, %lld, %lld, %lld]}", i ? ", " : "", fn.c_str(), (int) t->type,
+                                         (long long) t->ne[0], (long long) t->ne[1], (long long) t->ne[2], (long long) t->ne[3]);
+                man += buf2;
+            }
+            man += "], \"outs\": [";
+            for (size_t i = 0; i < outs.size(); i++) {
+                const std::string fn = name + ".out" + std::to_string(i) + ".bin";
+                FILE * f = fopen((std::string(dump) + "/" + fn).c_str(), "wb"); fwrite(ref[i].data(), 4, ref[i].size(), f); fclose(f);
+                char buf2[256]; snprintf(buf2, sizeof(buf2), "%s{\"file\": \"%s\", \"ne\": [%lld, %lld, %lld, %lld]}", i ? ", " : "", fn.c_str(),
+                                         (long long) outs[i]->ne[0], (long long) outs[i]->ne[1], (long long) outs[i]->ne[2], (long long) outs[i]->ne[3]);
+                man += buf2;
+            }
+            man += "]}\n";
+            FILE * f = fopen((std::string(dump) + "/manifest.jsonl").c_str(), "ab"); fputs(man.c_str(), f); fclose(f);
+        }
         ggml_backend_buffer_free(buf);
         ggml_free(b.ctx);
     }
@@ -182,6 +206,41 @@ int main(int argc, char ** argv) {
     fprintf(stderr, "op_parity: gpu backend = %s\n", ggml_backend_name(g_gpu));
 
     const ggml_type wtypes[] = { GGML_TYPE_Q5_0, GGML_TYPE_Q8_0, GGML_TYPE_Q4_0, GGML_TYPE_Q4_K, GGML_TYPE_F16 };
+
+    // ---------------- small cases exported as golden vectors for the CPU oracle (tests/golden/make_golden.py) -----
+    if (getenv("OP_PARITY_DUMP") || g_filter.rfind("golden", 0) == 0) {
+        for (ggml_type wt : wtypes) {
+            run_case(std::string("golden_mul_mat_") + tname(wt), [=](builder & b) {
+                return std::vector<ggml_tensor *>{ ggml_mul_mat(b.ctx, b.randn(wt, {256, 24}, 0.07f), b.randn(GGML_TYPE_F32, {256, 3})) }; }, false, false);
+        }
+        run_case("golden_norm", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_norm(b.ctx, b.randn(GGML_TYPE_F32, {384, 5}, 2.0f), 1e-5f) }; }, false, false);
+        run_case("golden_gelu", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_gelu(b.ctx, b.randn(GGML_TYPE_F32, {1024, 3}, 4.0f)) }; }, false, false);
+        run_case("golden_soft_max", [](builder & b) {
+            ggml_tensor * x = b.randn(GGML_TYPE_F32, {100, 6}, 2.0f);
+            ggml_tensor * m = b.leaf(GGML_TYPE_F32, {100, 6}, [](int64_t i) { return (i % 100) > 70 + (i / 100) ? -INFINITY : 0.0f; });
+            return std::vector<ggml_tensor *>{ ggml_soft_max_ext(b.ctx, x, m, 0.3f, 0.0f) }; }, false, false);
+        for (int mode : { 0, 2 }) {
+            run_case(std::string("golden_rope_mode") + std::to_string(mode), [=](builder & b) {
+                ggml_tensor * x = b.randn(GGML_TYPE_F32, {64, 3, 7});
+                ggml_tensor * pos = b.leaf(GGML_TYPE_I32, {7}, [](int64_t i) { return (float) (i * 5 + 2); });
+                return std::vector<ggml_tensor *>{ ggml_rope_ext(b.ctx, x, pos, nullptr, 48, mode, 4096, 10000.0f, 0.5f, 1.0f, 1.0f, 32.0f, 1.0f) }; }, false, false);
+        }
+        run_case("golden_im2col", [](builder & b) {
+            ggml_tensor * k = b.randn(GGML_TYPE_F16, {3, 10, 4});
+            ggml_tensor * x = b.randn(GGML_TYPE_F32, {50, 10});
+            return std::vector<ggml_tensor *>{ ggml_cast(b.ctx, ggml_im2col(b.ctx, k, x, 2, 0, 1, 0, 1, 0, false, GGML_TYPE_F16), GGML_TYPE_F32) }; }, false, false);
+        // flash attention through the reference ("use_ref") vec path: contiguous q [D,T,H] / k,v [D,n_kv,H] views as in whisper
+        run_case("golden_flash_attn", [](builder & b) {
+            const int D = 64, T = 3, H = 2, n_kv = 40;
+            ggml_tensor * q = b.randn(GGML_TYPE_F32, {D, H, T}, 0.7f);
+            ggml_tensor * k = b.randn(GGML_TYPE_F16, {D, H, n_kv}, 0.7f);
+            ggml_tensor * v = b.randn(GGML_TYPE_F16, {D, H, n_kv}, 1.0f);
+            ggml_tensor * mf = b.leaf(GGML_TYPE_F32, {n_kv, T}, [=](int64_t i) { return (i % n_kv) > 30 + (i / n_kv) * 3 ? -INFINITY : 0.0f; });
+            ggml_tensor * o = ggml_flash_attn_ext(b.ctx, ggml_permute(b.ctx, q, 0, 2, 1, 3), ggml_permute(b.ctx, k, 0, 2, 1, 3), ggml_permute(b.ctx, v, 0, 2, 1, 3),
+                                                  ggml_cast(b.ctx, mf, GGML_TYPE_F16), 0.125f, 0.0f, 0.0f);
+            return std::vector<ggml_tensor *>{ o }; }, false, false);
+        if (getenv("OP_PARITY_DUMP")) { ggml_backend_free(g_gpu); ggml_backend_free(g_cpu); return 0; }
+    }
 
     // ---------------- mul_mat: decoder shapes (T <= 8) and encoder/prompt shapes (T > 8) ----------------
     struct mm_shape { int K, N, T; };

@@ -1,0 +1,172 @@
+"""Pin the CPU oracle (oracle/oracle.c) against vectors generated from the reference itself.
+
+tests/golden/blocks.npz and ops.npz were produced by tests/golden/make_golden.py from oracle/_ref, i.e. by the
+reference's own compiled kernels (AVX2 build).  The reference has no known-answer vectors for this path
+(SURVEY.md §8c), so "the reference run here" is the pin.
+"""
+import ctypes as C
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import nmse, ptr
+
+G = Path(__file__).resolve().parent / "golden"
+TYPES = {"q4_0": 2, "q5_0": 6, "q8_0": 8, "q4_K": 12}
+
+
+@pytest.fixture(scope="module")
+def blocks():
+    return np.load(G / "blocks.npz")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    z = np.load(G / "ops.npz")
+    man = json.loads(bytes(z["manifest"]).decode())
+    return z, {m["case"]: m for m in man}
+
+
+def test_f16_conversion_matches_reference(oracle, blocks):
+    x = blocks["x"]
+    got = np.array([oracle.oracle_f32_to_f16(float(v)) for v in x], dtype=np.uint16)
+    assert np.array_equal(got, blocks["x_f16"])
+    # exhaustive round trip: every finite half survives f16 -> f32 -> f16, and matches numpy's conversion
+    allh = np.arange(65536, dtype=np.uint16)
+    f = np.array([oracle.oracle_f16_to_f32(int(h)) for h in allh], dtype=np.float32)
+    ref = allh.view(np.float16).astype(np.float32)
+    fin = np.isfinite(ref)
+    assert np.array_equal(f[fin], ref[fin])
+    # f32 -> f16 on a dense sample incl. ties, subnormals and overflow
+    rng = np.random.default_rng(1)
+    s = np.concatenate([rng.standard_normal(20000).astype(np.float32) * 10 ** rng.uniform(-9, 6, 20000).astype(np.float32),
+                        np.array([65504, 65519.99, 65520, 1e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 0.0, -0.0, 6.1e-5], dtype=np.float32)])
+    got = np.array([oracle.oracle_f32_to_f16(float(v)) for v in s], dtype=np.uint16)
+    with np.errstate(over="ignore"):
+        assert np.array_equal(got, s.astype(np.float16).view(np.uint16))
+
+
+@pytest.mark.parametrize("t", list(TYPES))
+def test_dequantize_bit_exact(oracle, blocks, t):
+    blk = blocks[f"wblk_{t}"]
+    n = blocks["w"].size
+    y = np.zeros(n, dtype=np.float32)
+    oracle.oracle_dequantize_row(TYPES[t], ptr(blk), ptr(y), n)
+    ref = blocks[f"wdeq_{t}"]
+    if t == "q4_K":
+        # the reference is compiled with -ffp-contract=fast: d1*q - m1 may be a single fma there (1 ulp)
+        assert np.allclose(y, ref, rtol=0, atol=np.abs(ref).max() * 2.0 ** -22)
+    else:
+        assert np.array_equal(y, ref)
+
+
+@pytest.mark.parametrize("t", ["q4_0", "q5_0", "q8_0"])
+def test_weight_quantizer_bit_exact(oracle, blocks, t):
+    w = blocks["w"]
+    blk = np.zeros_like(blocks[f"wblk_{t}"])
+    oracle.oracle_quantize_row_ref(TYPES[t], ptr(w), ptr(blk), w.size)
+    assert np.array_equal(blk, blocks[f"wblk_{t}"])
+
+
+def test_activation_quantizers_bit_exact(oracle, blocks):
+    x = blocks["x"]
+    a8 = np.zeros_like(blocks["act_q8_0"])
+    oracle.oracle_quantize_row_q8_0(ptr(x), ptr(a8), x.size)
+    assert np.array_equal(a8, blocks["act_q8_0"]), "Q8_0 activation blocks differ from the AVX2 reference"
+    aK = np.zeros_like(blocks["act_q8_K"])
+    oracle.oracle_quantize_row_q8_K(ptr(x), ptr(aK), x.size)
+    assert np.array_equal(aK, blocks["act_q8_K"])
+
+
+@pytest.mark.parametrize("t", list(TYPES))
+def test_vec_dot(oracle, blocks, t):
+    act = blocks["act_q8_K"] if t == "q4_K" else blocks["act_q8_0"]
+    got = oracle.oracle_vec_dot(TYPES[t], blocks["w"].size, ptr(blocks[f"wblk_{t}"]), ptr(act))
+    ref = float(blocks[f"dot_{t}"])
+    # identical integer sums; only the f32 accumulation order differs (8 SIMD lanes vs sequential)
+    assert abs(got - ref) <= 2e-6 * max(1.0, abs(ref)), (got, ref)
+
+
+def test_gelu_table_bit_exact(oracle, blocks):
+    allh = np.arange(65536, dtype=np.uint16)
+    x = allh.view(np.float16).astype(np.float32)
+    ok = np.isfinite(x) & (np.abs(x) < 10)
+    xs = np.ascontiguousarray(x[ok])
+    y = np.zeros_like(xs)
+    oracle.oracle_gelu(ptr(xs), ptr(y), xs.size)
+    ref = blocks["gelu_table"][ok].view(np.float16).astype(np.float32)
+    assert np.array_equal(y, ref)
+
+
+def _leaf(z, man, case, i, dtype=np.uint8):
+    return np.ascontiguousarray(z[f"{case}.leaf{i}"]).view(dtype)
+
+
+@pytest.mark.parametrize("t,tid", [("q5_0", 6), ("q8_0", 8), ("q4_0", 2), ("q4_K", 12), ("f16", 1)])
+def test_mul_mat_matches_reference_graph(oracle, ops, t, tid):
+    z, man = ops
+    case = f"golden_mul_mat_{t}"
+    m = man[case]
+    # the two leaves are created inside one C++ expression (unspecified order): identify them by type
+    iw = [i for i, l in enumerate(m["leaves"]) if l["type"] == tid][0]
+    ix = 1 - iw
+    K, N = m["leaves"][iw]["ne"][:2]
+    T = m["leaves"][ix]["ne"][1]
+    w = _leaf(z, man, case, iw)
+    x = _leaf(z, man, case, ix, np.float32)
+    ref = z[f"{case}.out0"]
+    got = np.zeros(N * T, dtype=np.float32)
+    oracle.oracle_mul_mat(tid, ptr(w), ptr(x), ptr(got), K, N, T)
+    assert nmse(ref, got) < 1e-12, nmse(ref, got)
+    assert np.abs(ref - got).max() <= 3e-6 * np.abs(ref).max()
+
+
+def test_norm_gelu_softmax_im2col(oracle, ops):
+    z, man = ops
+    x = _leaf(z, man, "golden_norm", 0, np.float32)
+    y = np.zeros_like(x)
+    oracle.oracle_norm(ptr(x), ptr(y), 384, 5, 1e-5)
+    assert nmse(z["golden_norm.out0"], y) < 1e-12
+    x = _leaf(z, man, "golden_gelu", 0, np.float32)
+    y = np.zeros_like(x)
+    oracle.oracle_gelu(ptr(x), ptr(y), x.size)
+    assert np.array_equal(y, z["golden_gelu.out0"])
+    x = _leaf(z, man, "golden_soft_max", 0, np.float32)
+    mk = _leaf(z, man, "golden_soft_max", 1, np.float32)
+    y = np.zeros_like(x)
+    oracle.oracle_soft_max(ptr(x), ptr(mk), ptr(y), 100, 6, 0.3)
+    assert nmse(z["golden_soft_max.out0"], y) < 1e-12
+    x = _leaf(z, man, "golden_im2col", 1, np.float32)
+    dst = np.zeros(30 * 24, dtype=np.uint16)          # OW = (50 + 2*1 - 3)/2 + 1 = 25 ... computed below
+    OW = man["golden_im2col"]["outs"][0]["ne"][1]
+    dst = np.zeros(OW * 30, dtype=np.uint16)
+    oracle.oracle_im2col_1d_f16(ptr(x), ptr(dst), 50, 10, OW, 3, 2, 1, 1)
+    assert np.array_equal(dst.view(np.float16).astype(np.float32), z["golden_im2col.out0"])
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_rope(oracle, ops, mode):
+    z, man = ops
+    case = f"golden_rope_mode{mode}"
+    x = _leaf(z, man, case, 0, np.float32)
+    pos = _leaf(z, man, case, 1, np.int32)
+    y = np.zeros_like(x)
+    oracle.oracle_rope(ptr(x), ptr(pos), ptr(y), 64, 3, 7, 48, mode, 4096, 10000.0, 0.5, 1.0, 1.0, 32.0, 1.0)
+    assert nmse(z[f"{case}.out0"], y) < 1e-10
+
+
+def test_flash_attn(oracle, ops):
+    z, man = ops
+    case = "golden_flash_attn"
+    D, T, H, n_kv = 64, 3, 2, 40
+    q = _leaf(z, man, case, 0, np.float32)       # [T][H][D]
+    k = _leaf(z, man, case, 1, np.uint16)        # [n_kv][H][D]
+    v = _leaf(z, man, case, 2, np.uint16)
+    mf = _leaf(z, man, case, 3, np.float32)      # [T][n_kv]
+    mh = mf.astype(np.float16).view(np.uint16)
+    out = np.zeros(T * H * D, dtype=np.float32)
+    oracle.oracle_flash_attn(ptr(q), ptr(k), ptr(v), ptr(mh), ptr(out), D, T, H, n_kv, 0.125)
+    # same algorithm incl. f16 V accumulation; the reference's f16 dot / mad run in 8-lane SIMD order
+    assert nmse(z[f"{case}.out0"], out) < 1e-5

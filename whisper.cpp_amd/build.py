@@ -80,7 +80,7 @@ def build_backend():
         if so.exists():
             return so  # GPU box: use the prebuilt plugin
         raise RuntimeError(f"{REF} not found and no prebuilt {so}")
-    refdir = ROOT / "oracle" / "_ref"
+    refdir = PKG / "host" / "_whisper"        # the unmodified reference host application (installed by oracle/Makefile)
     deps = srcs + [ROOT / "include" / "ggml_mi355x.h", ROOT / "include" / "mi355x_kernels.h", LIB / "libmi355x_kernels.so"]
     deps += list((CSRC / "backend").glob("*.h"))
     if _stale(so, deps):
@@ -89,7 +89,7 @@ def build_backend():
               f"-I{ROOT / 'include'}", f"-I{REF / 'ggml' / 'include'}", f"-I{REF / 'ggml' / 'src'}",
               *map(str, srcs), "-o", str(so),
               f"-L{LIB}", "-lmi355x_kernels", f"-L{refdir}", "-lggml-base", "-L/opt/rocm/lib", "-lamdhip64",
-              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../../oracle/_ref"])
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/../host/_whisper"])
     return so
 
 

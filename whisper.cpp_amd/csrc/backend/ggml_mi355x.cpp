@@ -222,6 +222,9 @@ struct mi_backend_ctx {
     bool     recording = false, record_abort = false;
 };
 
+static std::vector<mi_backend_ctx *> g_backends;           // live backends (guarded by g_weights_mtx)
+static uint64_t g_total_stats[4] = { 0, 0, 0, 0 };         // counters of already freed backends
+
 static mi355x_tensor to_mt(const ggml_tensor * t) {
     mi355x_tensor m;
     m.data = t->data; m.type = (int32_t) t->type; m.reserved = 0;
@@ -679,6 +682,11 @@ static void mi_backend_free(ggml_backend_t backend) {
                            b->name.c_str(), b->n_graph_compute, b->n_replay, b->n_update, b->n_rebuild);
     for (auto & c : b->gcache) { if (c.exec) (void) hipGraphExecDestroy(c.exec); if (c.graph) (void) hipGraphDestroy(c.graph); }
     if (b->act) (void) hipFree(b->act);
+    {
+        std::lock_guard<std::mutex> lk(g_weights_mtx);
+        for (size_t i = 0; i < g_backends.size(); i++) if (g_backends[i] == b) { g_backends.erase(g_backends.begin() + i); break; }
+        g_total_stats[0] += b->n_graph_compute; g_total_stats[1] += b->n_replay; g_total_stats[2] += b->n_update; g_total_stats[3] += b->n_rebuild;
+    }
     mi355x_ctx_destroy(b->k);
     delete b;
     delete backend;
@@ -765,12 +773,19 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
     b->device = d->index; b->k = k; b->name = d->name;
     b->fuse = env_flag("GGML_MI355X_FUSE", true); b->graphs = env_flag("GGML_MI355X_GRAPHS", true); b->prof = env_flag("GGML_MI355X_PROF", false);
     if (b->prof) mi355x_prof_enable(k, 1);
+    { std::lock_guard<std::mutex> lk(g_weights_mtx); g_backends.push_back(b); }
     return new ggml_backend{ mi_guid(), mi_backend_iface, dev, b };
 }
 static ggml_backend_buffer_type_t mi_dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi_device_ctx *) dev->context)->buft; }
 static bool mi_dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
     const bool ok = mi_supports_op_impl(op);
-    if (!ok) MI_LOG("unsupported op %s (%s) type=%s", ggml_op_name(op->op), op->name, ggml_type_name(op->type));
+    if (!ok) {
+        MI_LOG("unsupported op %s (%s) type=%s", ggml_op_name(op->op), op->name, ggml_type_name(op->type));
+        // GGML_MI355X_STRICT=1 (set by bench.py and the GPU tests): a node that would silently fall back to the CPU
+        // backend is a hard error, so a measured or parity-checked run is guaranteed to have executed on the HIP path
+        static const bool strict = env_flag("GGML_MI355X_STRICT", false);
+        if (strict) GGML_ABORT("ggml-mi355x: STRICT mode: op %s (%s, type %s) is not supported by the MI355X backend", ggml_op_name(op->op), op->name, ggml_type_name(op->type));
+    }
     return ok;
 }
 static bool mi_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
@@ -848,6 +863,38 @@ int ggml_backend_mi355x_prof_report(void * backend, ggml_mi355x_prof_row * rows,
     return mi355x_prof_report(b->k, (mi355x_prof_row *) rows, cap);
 }
 
+// process-wide variants (whisper.h does not expose its ggml_backend_t handles)
+void ggml_backend_mi355x_prof_enable_all(int on) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    for (auto * b : g_backends) { (void) hipSetDevice(b->device); b->prof = on != 0; mi355x_prof_enable(b->k, on); }
+}
+void ggml_backend_mi355x_prof_reset_all(void) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    for (auto * b : g_backends) { (void) hipSetDevice(b->device); mi355x_prof_reset(b->k); }
+}
+int ggml_backend_mi355x_prof_report_all(ggml_mi355x_prof_row * rows, int cap) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    int n = 0;
+    for (auto * b : g_backends) {
+        (void) hipSetDevice(b->device);
+        mi355x_prof_row tmp[64];
+        const int m = mi355x_prof_report(b->k, tmp, 64);
+        for (int i = 0; i < m; i++) {
+            int j = 0;
+            for (; j < n; j++) if (!strcmp(rows[j].name, tmp[i].name)) break;
+            if (j == n) { if (n >= cap) continue; rows[n].name = tmp[i].name; rows[n].calls = 0; rows[n].total_ms = rows[n].algo_bytes = rows[n].algo_flops = 0; n++; }
+            rows[j].calls += tmp[i].calls; rows[j].total_ms += tmp[i].total_ms; rows[j].algo_bytes += tmp[i].algo_bytes; rows[j].algo_flops += tmp[i].algo_flops;
+        }
+    }
+    return n;
+}
+// out[0..3] = graph_compute calls, hipGraph replays, patched kernel nodes, graph (re)builds — over all backends so far
+void ggml_backend_mi355x_stats(uint64_t * out) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    for (int i = 0; i < 4; i++) out[i] = g_total_stats[i];
+    for (auto * b : g_backends) { out[0] += b->n_graph_compute; out[1] += b->n_replay; out[2] += b->n_update; out[3] += b->n_rebuild; }
+}
+
 int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     int n = 0;
@@ -865,6 +912,10 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_prof_reset"))      return (void *) ggml_backend_mi355x_prof_reset;
     if (!strcmp(name, "ggml_backend_mi355x_prof_report"))     return (void *) ggml_backend_mi355x_prof_report;
     if (!strcmp(name, "ggml_backend_mi355x_weight_buffers"))  return (void *) ggml_backend_mi355x_weight_buffers;
+    if (!strcmp(name, "ggml_backend_mi355x_prof_enable_all")) return (void *) ggml_backend_mi355x_prof_enable_all;
+    if (!strcmp(name, "ggml_backend_mi355x_prof_reset_all"))  return (void *) ggml_backend_mi355x_prof_reset_all;
+    if (!strcmp(name, "ggml_backend_mi355x_prof_report_all")) return (void *) ggml_backend_mi355x_prof_report_all;
+    if (!strcmp(name, "ggml_backend_mi355x_stats"))           return (void *) ggml_backend_mi355x_stats;
     return nullptr;
 }
 

@@ -33,7 +33,18 @@ extern "C" int mi355x_device_count(void) {
 // produced by the same libm tanhf as the reference's ggml_table_gelu_f16 (ggml-cpu/ggml-cpu.c table init)
 static inline float gelu_f32_host(float x) {
     const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
-    return 0.5f*x*(1.0f + tanhf(SQRT_2_OVER_PI*x*(1.0f + GELU_COEF_A*x*x)));
+    // the reference binary is built with gcc's default -ffp-contract=fast, which turns (A*x)*x + 1 into one fma;
+    // with the explicit fmaf all 65536 table entries equal the reference's (tests/test_oracle.py, tests/test_host.py)
+    const float inner = fmaf(GELU_COEF_A*x, x, 1.0f);
+    return 0.5f*x*(1.0f + tanhf(SQRT_2_OVER_PI*x*inner));
+}
+
+extern "C" void mi355x_gelu_table_host(uint16_t * out) {
+    for (int i = 0; i < 65536; i++) {
+        uint16_t h = (uint16_t) i; _Float16 x; memcpy(&x, &h, 2);
+        _Float16 y = (_Float16) gelu_f32_host((float) x);
+        memcpy(&out[i], &y, 2);
+    }
 }
 
 extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
@@ -46,11 +57,7 @@ extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
     if (hipGetDeviceProperties(&p, device) == hipSuccess) ctx->n_cu = p.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
     std::vector<uint16_t> tab(65536);
-    for (int i = 0; i < 65536; i++) {
-        uint16_t h = (uint16_t) i; _Float16 x; memcpy(&x, &h, 2);
-        _Float16 y = (_Float16) gelu_f32_host((float) x);
-        memcpy(&tab[i], &y, 2);
-    }
+    mi355x_gelu_table_host(tab.data());
     if (hipMalloc((void **) &ctx->gelu_tab, 65536*2) != hipSuccess ||
         hipMemcpy(ctx->gelu_tab, tab.data(), 65536*2, hipMemcpyHostToDevice) != hipSuccess) {
         mi355x_set_error("gelu table upload failed"); (void) hipStreamDestroy(ctx->stream); delete ctx; return nullptr;
