@@ -1,0 +1,61 @@
+#!/bin/bash
+# One gpurun call: GPU pytest, bench, rocprofv3 kernel trace (+ optional PMC passes).  Logs land in gpurun_out/.
+# usage: scripts/gpu_round.sh [stage ...]    stages: pytest bench prof pmc wbench   (default: pytest bench prof)
+set -u
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+STAGES=${*:-pytest bench prof}
+ARCH=${BENCH_ARCH:-large-v3}
+QT=${BENCH_QTYPE:-q5_0}
+stage() { echo; echo "=== $1 === $(date +%T)"; }
+
+{ rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -6; lscpu | grep -E "Model name|^CPU\(s\)|Thread|Socket"; } > "$OUT/info.txt" 2>&1
+
+for s in $STAGES; do case $s in
+pytest)
+    stage "pytest -m gpu"
+    timeout 1700 python3 -m pytest tests -m gpu -q -p no:cacheprovider ${PYTEST_ARGS:-} > "$OUT/pytest_gpu.txt" 2>&1
+    echo "exit=$?"; tail -40 "$OUT/pytest_gpu.txt"
+    ;;
+bench)
+    stage "bench.py $ARCH $QT"
+    timeout 1500 python3 bench.py --arch "$ARCH" --qtype "$QT" > "$OUT/bench_${ARCH}_${QT}.json" 2> "$OUT/bench_${ARCH}_${QT}.err"
+    echo "exit=$?"; tail -3 "$OUT/bench_${ARCH}_${QT}.err"; cat "$OUT/bench_${ARCH}_${QT}.json"
+    ;;
+prof)
+    stage "rocprofv3 --kernel-trace --stats (bench.py $ARCH $QT, 1 step)"
+    rm -rf "$OUT/prof"
+    ( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline \
+        > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err" )
+    echo "exit=$?"
+    f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1)
+    if [ -n "$f" ]; then cp "$f" "$OUT/kernel_stats_${ARCH}_${QT}.csv"; head -25 "$f"; fi
+    # the raw trace is large: keep only the stats
+    find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
+    ;;
+pmc)
+    stage "rocprofv3 --pmc passes (bench.py $ARCH $QT, decode only)"
+    for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+        tag=$(echo "$ctr" | tr ' ' '+')
+        rm -rf "$OUT/pmc_$tag"
+        ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace -d "$OUT/pmc_$tag" -o pmc -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 0 --n-decode 8 --no-cpu-baseline --no-profile \
+            > "$OUT/pmc_$tag.json" 2> "$OUT/pmc_$tag.err" )
+        echo "$tag exit=$?"
+        python3 scripts/summarize_pmc.py "$OUT/pmc_$tag" > "$OUT/pmc_$tag.summary.txt" 2>&1; head -30 "$OUT/pmc_$tag.summary.txt"
+        find "$OUT/pmc_$tag" -name "*.csv" -size +20M -delete
+    done
+    ;;
+wbench)
+    stage "reference whisper-bench binary + plugin"
+    export GGML_BACKEND_PATH=$ROOT/whisper.cpp_amd/lib/libggml-mi355x.so
+    export LD_LIBRARY_PATH=$ROOT/whisper.cpp_amd/host/_whisper:$ROOT/whisper.cpp_amd/lib:${LD_LIBRARY_PATH:-}
+    m=$(python3 whisper.cpp_amd/synth_model.py --arch "$ARCH" --qtype "$QT")
+    timeout 900 whisper.cpp_amd/host/_whisper/whisper-bench -m "$m" -t 8 > "$OUT/wbench_gpu_${ARCH}_${QT}.log" 2>&1
+    grep -E "encode time|decode time|batchd time|prompt time|backends|MI355X" "$OUT/wbench_gpu_${ARCH}_${QT}.log" | head -12
+    ;;
+esac; done
+echo; echo "=== done $(date +%T)"

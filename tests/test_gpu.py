@@ -1,0 +1,432 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X).  Everything here goes through the C ABIs the product ships:
+include/mi355x_kernels.h (ctypes, device memory owned by torch) and include/ggml_mi355x.h (the ggml plugin, driven by
+the UNMODIFIED reference host through tests/native/bin/*).  The CPU oracle (oracle/liboracle.so, oracle/_ref) is only
+the checker.  The kernel library has no CPU fallback: a missing .so or a missing GPU fails these tests loudly.
+
+Tolerances (NMSE = sum (ref-got)^2 / sum ref^2 against the reference's CPU arithmetic):
+  * bit-exact            : dequantization (get_rows), GELU (f16 table), im2col, cpy/cast
+  * 1e-10                : norm, soft_max, rope, mat-vec with int8 dot products (T <= 8: same integer sums as the CPU,
+                           only the f32 summation order differs)
+  * 2e-6                 : MFMA mat-mul (T > 8): the reference's Q8_0/Q8_K activation rounding is reproduced, d*q products
+                           are rounded to f16 (2^-11 relative) before the f32-accumulating MFMA
+  * 3e-5                 : flash attention (the CPU accumulates V in f16, ops.cpp:8629-8643; we accumulate in f32)
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu, nmse, ptr
+
+pytestmark = pytest.mark.gpu
+
+G = Path(__file__).resolve().parent / "golden"
+QT = {"q4_0": 2, "q5_0": 6, "q8_0": 8, "q4_K": 12}
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from whisper_cpp_amd import kernels_api as ka
+    ctx = ka.Ctx(0)          # raises when libmi355x_kernels.so or the device is missing: no fallback
+    yield ctx, ka, torch
+    ctx.close()
+
+
+def dev(torch, a: np.ndarray):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    torch.cuda.synchronize()
+    return t
+
+
+def quantize(oracle, ka, tid, wf):
+    """reference weight quantizer (restated in the oracle, pinned bit-exact by tests/test_oracle.py) -> ggml blocks + planar"""
+    N, K = wf.shape
+    blocks = np.empty(N * ka.row_bytes(tid, K), dtype=np.uint8)
+    oracle.oracle_quantize_row_ref(tid, ptr(wf), ptr(blocks), N * K)
+    return blocks, ka.repack_to_planar(tid, blocks, N * K)
+
+
+def run_mul_mat(gpu, tid, planar_or_f16, x, K, N, T, ep=None):
+    ctx, ka, torch = gpu
+    w_d = dev(torch, planar_or_f16)
+    x_d = dev(torch, x)
+    y_d = torch.zeros((T, N), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    tw = ka.tensor(w_d.data_ptr(), tid, [K, N])
+    tx = ka.tensor(x_d.data_ptr(), ka.F32, [K, T])
+    ty = ka.tensor(y_d.data_ptr(), ka.F32, [N, T])
+    ctx.check(ka.lib().mi355x_mul_mat(ctx.h, C.byref(tw), C.byref(tx), C.byref(ty), ep), "mul_mat")
+    ctx.sync()
+    return y_d.cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# quantized mat-mul against the oracle (seeded inputs) — decoder (T <= 8, int8 dot) and encoder (T > 8, MFMA) kernels
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("t", list(QT))
+@pytest.mark.parametrize("K,N,T", [(1280, 640, 1), (1280, 333, 5), (512, 1027, 8), (5120, 256, 2),
+                                   (1280, 640, 9), (512, 515, 100), (1280, 384, 257), (5120, 130, 64)])
+def test_mul_mat_vs_oracle(gpu, oracle, t, K, N, T):
+    _, ka, _ = gpu
+    tid = QT[t]
+    rng = np.random.default_rng(K * 7 + N * 3 + T)
+    wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    x[0, :32] = 0.0                                     # an all-zero activation block (amax == 0 branch)
+    blocks, planar = quantize(oracle, ka, tid, wf)
+    ref = np.empty((T, N), dtype=np.float32)
+    oracle.oracle_mul_mat(tid, ptr(blocks), ptr(x), ptr(ref), K, N, T)
+    got = run_mul_mat(gpu, tid, planar, x, K, N, T)
+    tol = 1e-10 if T <= 8 else 2e-6
+    e = nmse(ref, got)
+    assert e < tol, f"{t} K={K} N={N} T={T}: NMSE {e:.3e} >= {tol}"
+
+
+def test_mul_mat_f16_weights(gpu, oracle):
+    _, ka, _ = gpu
+    rng = np.random.default_rng(5)
+    for (K, N, T) in [(384, 200, 3), (240, 300, 77), (1280, 128, 40)]:
+        wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)
+        x = rng.standard_normal((T, K)).astype(np.float32)
+        ref = np.empty((T, N), dtype=np.float32)
+        oracle.oracle_mul_mat(1, ptr(wf), ptr(x), ptr(ref), K, N, T)
+        got = run_mul_mat(gpu, ka.F16, wf.view(np.uint8).ravel(), x, K, N, T)
+        assert nmse(ref, got) < 1e-9, (K, N, T, nmse(ref, got))
+
+
+def test_mul_mat_golden_vectors_from_reference(gpu):
+    """tests/golden/ops.npz: inputs AND outputs produced by the reference's own compiled CPU kernels."""
+    _, ka, _ = gpu
+    z = np.load(G / "ops.npz")
+    man = {m["case"]: m for m in json.loads(bytes(z["manifest"]).decode())}
+    for t, tid in [("q5_0", 6), ("q8_0", 8), ("q4_0", 2), ("q4_K", 12), ("f16", 1)]:
+        case = f"golden_mul_mat_{t}"
+        m = man[case]
+        iw = [i for i, l in enumerate(m["leaves"]) if l["type"] == tid][0]
+        K, N = m["leaves"][iw]["ne"][:2]
+        T = m["leaves"][1 - iw]["ne"][1]
+        w = np.ascontiguousarray(z[f"{case}.leaf{iw}"]).view(np.uint8)
+        x = np.ascontiguousarray(z[f"{case}.leaf{1 - iw}"]).view(np.float32).reshape(T, K)
+        planar = ka.repack_to_planar(tid, w, K * N) if tid != 1 else w
+        got = run_mul_mat(gpu, tid, planar, x, K, N, T)
+        ref = z[f"{case}.out0"].reshape(T, N)
+        assert nmse(ref, got) < 1e-10, (t, nmse(ref, got))
+
+
+def test_mul_mat_columns_are_independent_and_deterministic(gpu, oracle):
+    """size-independent properties: a column's result does not depend on its batch-mates, and replays are bit-identical"""
+    _, ka, _ = gpu
+    rng = np.random.default_rng(11)
+    K, N = 1280, 1280
+    wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    _, planar = quantize(oracle, ka, 6, wf)
+    x = rng.standard_normal((5, K)).astype(np.float32)
+    y5 = run_mul_mat(gpu, 6, planar, x, K, N, 5)
+    for t in range(5):
+        y1 = run_mul_mat(gpu, 6, planar, x[t:t + 1], K, N, 1)
+        assert np.array_equal(y1[0], y5[t])
+    xl = rng.standard_normal((300, K)).astype(np.float32)
+    a = run_mul_mat(gpu, 6, planar, xl, K, N, 300)
+    b = run_mul_mat(gpu, 6, planar, xl, K, N, 300)
+    assert np.array_equal(a, b)
+    # MFMA path agrees with the int8-dot path on the same columns
+    assert nmse(run_mul_mat(gpu, 6, planar, xl[:8], K, N, 8), a[:8]) < 2e-6
+
+
+@pytest.mark.parametrize("t", ["q5_0", "q4_K"])
+def test_mul_mat_full_size_vs_f64(gpu, oracle, t):
+    """BASELINE.json full size (large-v3 MLP up-projection over a 1500-frame encoder window): the result must be
+    as close to the exact (f64, dequantized weights) product as the reference's own int8-activation arithmetic allows."""
+    _, ka, _ = gpu
+    tid = QT[t]
+    K, N, T = 1280, 5120, 1500
+    rng = np.random.default_rng(3)
+    wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    blocks, planar = quantize(oracle, ka, tid, wf)
+    wd = np.empty((N, K), dtype=np.float32)
+    oracle.oracle_dequantize_row(tid, ptr(blocks), ptr(wd), N * K)
+    exact = x.astype(np.float64) @ wd.astype(np.float64).T
+    got = run_mul_mat(gpu, tid, planar, x, K, N, T)
+    # Q8_0 activation rounding: relative step 1/254 per element, uniform => NMSE ~ (1/127)^2/12 * (E[amax^2]/E[x^2]) ~ 3e-5
+    e = nmse(exact, got)
+    assert e < 1e-4, e
+    # and it matches the oracle on a slice the oracle finishes quickly
+    ref = np.empty((16, N), dtype=np.float32)
+    oracle.oracle_mul_mat(tid, ptr(blocks), ptr(np.ascontiguousarray(x[:16])), ptr(ref), K, N, 16)
+    assert nmse(ref, got[:16]) < 2e-6
+
+
+def test_mul_mat_epilogue_matches_separate_ops(gpu, oracle):
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(21)
+    for T in (3, 40):
+        K, N = 1280, 512
+        wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        blocks, planar = quantize(oracle, ka, 6, wf)
+        x = rng.standard_normal((T, K)).astype(np.float32)
+        bias = rng.standard_normal(N).astype(np.float32) * 0.1
+        res = rng.standard_normal((T, N)).astype(np.float32)
+        ref = np.empty((T, N), dtype=np.float32)
+        oracle.oracle_mul_mat(6, ptr(blocks), ptr(x), ptr(ref), K, N, T)
+        pre = (ref + bias[None, :]).astype(np.float32)
+        g = np.empty_like(pre)
+        oracle.oracle_gelu(ptr(np.ascontiguousarray(pre)), ptr(g), pre.size)
+        want = g + res
+        b_d, r_d = dev(torch, bias), dev(torch, res)
+        ep = ka.Epilogue(b_d.data_ptr(), 0.0, 0, 1, r_d.data_ptr(), N * 4)
+        got = run_mul_mat(gpu, 6, planar, x, K, N, T, C.byref(ep))
+        assert nmse(want, got) < (1e-8 if T <= 8 else 5e-6), (T, nmse(want, got))
+
+
+def test_fused_norm_gemv(gpu, oracle):
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(31)
+    K, T = 1280, 5
+    x = (rng.standard_normal((T, K)) * 2).astype(np.float32)
+    lw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    lb = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    nx = np.empty_like(x)
+    oracle.oracle_norm(ptr(x), ptr(nx), K, T, 1e-5)
+    nx = (nx * lw[None, :]).astype(np.float32) + lb[None, :]
+    segs = []
+    d = ka.GemvDesc()
+    x_d, lw_d, lb_d = dev(torch, x), dev(torch, lw), dev(torch, lb)
+    d.x, d.x_nb1, d.K, d.T, d.has_norm, d.eps = x_d.data_ptr(), K * 4, K, T, 1, 1e-5
+    d.ln_w, d.ln_b, d.nseg = lw_d.data_ptr(), lb_d.data_ptr(), 3
+    keep = []
+    for s, N in enumerate((1280, 640, 384)):
+        wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        blocks, planar = quantize(oracle, ka, 6, wf)
+        ref = np.empty((T, N), dtype=np.float32)
+        oracle.oracle_mul_mat(6, ptr(blocks), ptr(np.ascontiguousarray(nx)), ptr(ref), K, N, T)
+        w_d = dev(torch, planar)
+        y_d = torch.zeros((T, N), dtype=torch.float32, device="cuda:0")
+        keep += [w_d, y_d]
+        d.seg[s].w, d.seg[s].wtype, d.seg[s].N = w_d.data_ptr(), 6, N
+        d.seg[s].dst, d.seg[s].dst_type, d.seg[s].dst_nb1 = y_d.data_ptr(), ka.F32, N * 4
+        segs.append((ref, y_d))
+    torch.cuda.synchronize()
+    ctx.check(ka.lib().mi355x_gemv_fused(ctx.h, C.byref(d)), "gemv_fused")
+    ctx.sync()
+    for ref, y_d in segs:
+        assert nmse(ref, y_d.cpu().numpy()) < 1e-9
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the other ops of the path
+# ---------------------------------------------------------------------------------------------------------------
+def test_norm_gelu_softmax(gpu, oracle):
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(41)
+    L = ka.lib()
+    x = (rng.standard_normal((150, 1280)) * 3).astype(np.float32)
+    ref = np.empty_like(x)
+    oracle.oracle_norm(ptr(x), ptr(ref), 1280, 150, 1e-5)
+    x_d, y_d = dev(torch, x), torch.zeros_like(dev(torch, x))
+    tx, ty = ka.tensor(x_d.data_ptr(), ka.F32, [1280, 150]), ka.tensor(y_d.data_ptr(), ka.F32, [1280, 150])
+    ctx.check(L.mi355x_norm(ctx.h, C.byref(tx), C.byref(ty), 1e-5, None, None), "norm")
+    ctx.sync()
+    assert nmse(ref, y_d.cpu().numpy()) < 1e-10
+    # gelu: bit-exact (f16 lookup table == reference table)
+    ref = np.empty_like(x)
+    oracle.oracle_gelu(ptr(x), ptr(ref), x.size)
+    ctx.check(L.mi355x_gelu(ctx.h, C.byref(tx), C.byref(ty)), "gelu")
+    ctx.sync()
+    assert np.array_equal(ref, y_d.cpu().numpy())
+    # soft_max with an f32 mask incl. -inf
+    n, rows = 1500, 40
+    s = (rng.standard_normal((rows, n)) * 2).astype(np.float32)
+    mk = np.where(rng.random((rows, n)) < 0.2, -np.inf, 0.0).astype(np.float32)
+    mk[:, 0] = 0
+    ref = np.empty_like(s)
+    oracle.oracle_soft_max(ptr(s), ptr(mk), ptr(ref), n, rows, 0.125)
+    s_d, m_d = dev(torch, s), dev(torch, mk)
+    o_d = torch.zeros_like(s_d)
+    ts, tm, to = (ka.tensor(a.data_ptr(), ka.F32, [n, rows]) for a in (s_d, m_d, o_d))
+    ctx.check(L.mi355x_soft_max(ctx.h, C.byref(ts), C.byref(tm), C.byref(to), 0.125, 0.0), "soft_max")
+    ctx.sync()
+    assert nmse(ref, o_d.cpu().numpy()) < 1e-10
+
+
+def test_im2col_and_rope(gpu, oracle):
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(43)
+    L = ka.lib()
+    IW, IC, KW = 3000, 128, 3
+    x = rng.standard_normal((IC, IW)).astype(np.float32)
+    for s0 in (1, 2):
+        OW = (IW + 2 - KW) // s0 + 1
+        ref = np.zeros(OW * IC * KW, dtype=np.uint16)
+        oracle.oracle_im2col_1d_f16(ptr(x), ptr(ref), IW, IC, OW, KW, s0, 1, 1)
+        x_d = dev(torch, x)
+        d_d = torch.zeros(OW * IC * KW, dtype=torch.float16, device="cuda:0")
+        tx = ka.tensor(x_d.data_ptr(), ka.F32, [IW, IC])
+        td = ka.tensor(d_d.data_ptr(), ka.F16, [IC * KW, OW])
+        ctx.check(L.mi355x_im2col_1d(ctx.h, C.byref(tx), C.byref(td), KW, s0, 1, 1), "im2col")
+        ctx.sync()
+        assert np.array_equal(ref, d_d.cpu().numpy().view(np.uint16))
+    for mode in (0, 2):
+        ne0, nh, npos = 64, 12, 40
+        xr = rng.standard_normal((npos, nh, ne0)).astype(np.float32)
+        pos = (np.arange(npos) * 3 + 1).astype(np.int32)
+        ref = np.empty_like(xr)
+        oracle.oracle_rope(ptr(xr), ptr(pos), ptr(ref), ne0, nh, npos, 48, mode, 4096, 10000.0, 0.5, 1.0, 1.0, 32.0, 1.0)
+        x_d, p_d = dev(torch, xr), dev(torch, pos)
+        y_d = torch.zeros_like(x_d)
+        tx, ty = ka.tensor(x_d.data_ptr(), ka.F32, [ne0, nh, npos]), ka.tensor(y_d.data_ptr(), ka.F32, [ne0, nh, npos])
+        tp = ka.tensor(p_d.data_ptr(), ka.I32, [npos])
+        p = ka.RopeParams(48, mode, 4096, 10000.0, 0.5, 1.0, 1.0, 32.0, 1.0)
+        ctx.check(L.mi355x_rope(ctx.h, C.byref(tx), C.byref(tp), None, C.byref(ty), C.byref(p)), "rope")
+        ctx.sync()
+        assert nmse(ref, y_d.cpu().numpy()) < 1e-9, mode
+
+
+@pytest.mark.parametrize("t", list(QT))
+def test_get_rows_dequant_bit_exact(gpu, oracle, t):
+    ctx, ka, torch = gpu
+    tid = QT[t]
+    rng = np.random.default_rng(47)
+    K, N = 1280, 700
+    wf = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    blocks, planar = quantize(oracle, ka, tid, wf)
+    wd = np.empty((N, K), dtype=np.float32)
+    oracle.oracle_dequantize_row(tid, ptr(blocks), ptr(wd), N * K)
+    idx = np.array([5, 699, 0, 131, 262, 5], dtype=np.int32)
+    w_d, i_d = dev(torch, planar), dev(torch, idx)
+    y_d = torch.zeros((len(idx), K), dtype=torch.float32, device="cuda:0")
+    tw, ti, ty = ka.tensor(w_d.data_ptr(), tid, [K, N]), ka.tensor(i_d.data_ptr(), ka.I32, [len(idx)]), ka.tensor(y_d.data_ptr(), ka.F32, [K, len(idx)])
+    ctx.check(ka.lib().mi355x_get_rows(ctx.h, C.byref(tw), C.byref(ti), C.byref(ty)), "get_rows")
+    ctx.sync()
+    got = y_d.cpu().numpy()
+    assert np.array_equal(got, wd[idx])     # (-ffp-contract=off on both sides: no fma in d*q - m)
+
+
+@pytest.mark.parametrize("T,n_kv,H,mask", [(1, 1536, 20, False), (5, 77, 8, True), (8, 448, 6, True), (1, 1, 4, True),
+                                            (33, 100, 6, True), (200, 320, 4, False), (256, 256, 8, True)])
+def test_flash_attn_vs_oracle(gpu, oracle, T, n_kv, H, mask):
+    ctx, ka, torch = gpu
+    D = 64
+    rng = np.random.default_rng(T * 13 + n_kv)
+    q = (rng.standard_normal((T, H, D)) * 0.6).astype(np.float32)
+    k = (rng.standard_normal((n_kv, H, D)) * 0.6).astype(np.float16)
+    v = rng.standard_normal((n_kv, H, D)).astype(np.float16)
+    mh = None
+    if mask:
+        mf = np.zeros((T, n_kv), dtype=np.float32)
+        for t in range(T):
+            mf[t, max(1, n_kv - T + t + 1):] = -np.inf
+        mh = mf.astype(np.float16)
+    ref = np.empty((T, H, D), dtype=np.float32)
+    oracle.oracle_flash_attn(ptr(q), ptr(k.view(np.uint16)), ptr(v.view(np.uint16)), ptr(mh.view(np.uint16)) if mask else None, ptr(ref), D, T, H, n_kv, 0.125)
+    q_d, k_d, v_d = dev(torch, q), dev(torch, k), dev(torch, v)
+    o_d = torch.zeros((T, H, D), dtype=torch.float32, device="cuda:0")
+    # whisper's views: q [D, T, H] permuted from [D, H, T]; k/v [D, n_kv, H] with row stride H*D
+    tq = ka.tensor(q_d.data_ptr(), ka.F32, [D, T, H], [4, H * D * 4, D * 4, T * H * D * 4])
+    tk = ka.tensor(k_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    tv = ka.tensor(v_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    to = ka.tensor(o_d.data_ptr(), ka.F32, [D, H, T])
+    tm = None
+    if mask:
+        m_d = dev(torch, mh)
+        tm = C.byref(ka.tensor(m_d.data_ptr(), ka.F16, [n_kv, T]))
+    ctx.check(ka.lib().mi355x_flash_attn_ext(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), tm, C.byref(to), 0.125), "flash_attn")
+    ctx.sync()
+    e = nmse(ref, o_d.cpu().numpy())
+    assert e < 3e-5, e
+
+
+def test_flash_attn_full_size_property(gpu):
+    """encoder size (T = 1500, n_kv = 1536 incl. zero-padded keys, 20 heads): with V == 1 every output must be exactly 1
+    up to rounding (softmax rows sum to one), and the zero pad keys must take softmax mass like the reference's do."""
+    ctx, ka, torch = gpu
+    D, T, n_kv, H = 64, 1500, 1536, 20
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    q = torch.randn((T, H, D), device="cuda:0", generator=g) * 0.5
+    k = (torch.randn((n_kv, H, D), device="cuda:0", generator=g) * 0.5).half()
+    k[1500:] = 0
+    v = torch.ones((n_kv, H, D), device="cuda:0", dtype=torch.float16)
+    o = torch.zeros((T, H, D), device="cuda:0")
+    torch.cuda.synchronize()
+    tq = ka.tensor(q.data_ptr(), ka.F32, [D, T, H], [4, H * D * 4, D * 4, T * H * D * 4])
+    tk = ka.tensor(k.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    tv = ka.tensor(v.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    to = ka.tensor(o.data_ptr(), ka.F32, [D, H, T])
+    ctx.check(ka.lib().mi355x_flash_attn_ext(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), None, C.byref(to), 0.125), "flash_attn")
+    ctx.sync()
+    assert float((o - 1).abs().max()) < 2e-3
+    # against torch fp32 attention on the same f16-rounded q (floating-point kernel: torch fp32 reference, tolerance 1e-5 NMSE)
+    v2 = torch.randn((n_kv, H, D), device="cuda:0", generator=g).half()
+    tv2 = ka.tensor(v2.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    torch.cuda.synchronize()
+    ctx.check(ka.lib().mi355x_flash_attn_ext(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv2), None, C.byref(to), 0.125), "flash_attn")
+    ctx.sync()
+    s = torch.einsum("thd,khd->htk", q.half().float(), k.float()) * 0.125
+    ref = torch.einsum("htk,khd->thd", torch.softmax(s, dim=-1), v2.float())
+    err = float(((ref - o) ** 2).sum() / (ref ** 2).sum())
+    assert err < 1e-5, err
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the plugin, driven by the unmodified reference host
+# ---------------------------------------------------------------------------------------------------------------
+def _native(name):
+    exe = ROOT / "tests" / "native" / "bin" / name
+    assert exe.exists(), f"{exe} missing (built by __graft_entry__.build() where the reference tree exists)"
+    return exe
+
+
+def test_plugin_op_parity_against_reference_cpu_backend(plugin_env, tmp_path):
+    """every hot-path op, node mode (ggml_backend_compare_graph_backend) and scheduler mode (fusion + hipGraph replay)"""
+    env = dict(plugin_env, GGML_MI355X_STRICT="0")
+    out = tmp_path / "op_parity.jsonl"
+    with open(out, "w") as f:
+        r = subprocess.run([str(_native("op_parity"))], env=env, stdout=f, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    keep = ROOT / "gpurun_out"
+    if keep.exists():
+        (keep / "op_parity.jsonl").write_text(out.read_text())
+    s = subprocess.run([sys.executable, str(ROOT / "scripts" / "summarize_ops.py"), str(out)], stdout=subprocess.PIPE, text=True)
+    assert s.returncode == 0, s.stdout[-3000:]
+    n = sum(1 for l in out.read_text().splitlines() if l.startswith("{"))
+    assert n > 250, n
+
+
+@pytest.mark.parametrize("arch,qtype", [("micro", "q5_0"), ("base.en", "q5_0"), ("base.en", "q4_k"), ("large-v3-2l", "q8_0")])
+def test_plugin_model_parity(plugin_env, arch, qtype):
+    """same model file through the unmodified libwhisper on the reference CPU backend and on the plugin: logits within
+    tolerance at every teacher-forced step; greedy tokens identical wherever the CPU's own top-2 margin exceeds the
+    logit error (random-weight models have near-ties a real model does not)."""
+    from whisper_cpp_amd.synth_model import make_model
+    m = make_model(arch, qtype)
+    env = dict(plugin_env, GGML_MI355X_STRICT="1")
+    r = subprocess.run([str(_native("model_parity")), str(m), "16"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    keep = ROOT / "gpurun_out"
+    if keep.exists():
+        (keep / f"model_parity_{arch}_{qtype}.json").write_text(r.stdout)
+    s = d["single"]
+    assert s["worst_nmse"] < 1e-4, s
+    for st in d["steps"]:
+        if st["tok_cpu"] != st["tok_gpu"]:
+            assert st["margin"] <= 4 * st["max_diff"], st
+    assert d["batch5"]["nmse"] < 1e-4 and d["batch48"]["nmse"] < 1e-4, d
+
+
+def test_bench_smoke():
+    """bench.py end to end on a small model: one JSON line with the contract's keys, roofline measured live"""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--arch", "base.en", "--qtype", "q5_0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["value"] > 0 and d["roofline"]["achieved"] > 0
