@@ -81,6 +81,42 @@ def load_host(plugin: Path):
     return w, p
 
 
+class _DevMem:
+    """expose a raw device range to torch through __cuda_array_interface__ (no copy)"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def broadcast_weights(p, dist, torch, device: int, rank: int):
+    """one-time RCCL broadcast (over xGMI) of rank 0's WEIGHTS buffers into the identically laid out
+    buffers of every other replica.  Every context allocates the same tensors in the same order, so buffer i has the same
+    size on every rank (checked).  Outside the timed region; no collective is ever issued on the per-chunk path."""
+    cap = 64
+    bases, sizes = (C.c_void_p * cap)(), (C.c_size_t * cap)()
+    p.ggml_backend_mi355x_weight_buffers.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
+    n = p.ggml_backend_mi355x_weight_buffers(device, bases, sizes, cap)
+    total, t0 = 0, time.perf_counter()
+    try:
+        meta = torch.tensor([n] + [int(sizes[i]) for i in range(min(n, cap))] + [0] * (cap - min(n, cap)), dtype=torch.int64, device="cuda")
+        ref = meta.clone()
+        dist.broadcast(ref, src=0)
+        ok = torch.tensor([1 if torch.equal(ref, meta) and 0 < n <= cap else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same branch: no rank is left waiting in a collective
+        if int(ok.item()) == 0:
+            raise RuntimeError("weight buffer layout differs between ranks")
+        for i in range(n):
+            t = torch.as_tensor(_DevMem(int(bases[i]), int(sizes[i])), device="cuda")
+            dist.broadcast(t, src=0)
+            total += int(sizes[i])
+        torch.cuda.synchronize()
+        return {"bytes": total, "buffers": n, "seconds": round(time.perf_counter() - t0, 4)}
+    except Exception as e:  # noqa: BLE001  (every rank already holds the weights from the model file: safe to continue)
+        if rank == 0:
+            print(f"bench.py: weight broadcast skipped: {e}", file=sys.stderr)
+        return None
+
+
 def algorithmic_figures(arch: str, qtype: str):
     """algorithmic HBM bytes per decoded token and FLOPs per encode, from the hyper-parameters."""
     from whisper_cpp_amd.synth_model import ARCHS
@@ -105,6 +141,7 @@ def main():
     ap.add_argument("--n-decode", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="print the per-kernel hipEvent profile of one chunk and exit")
+    ap.add_argument("--no-profile", action="store_true", help="skip the hipEvent per-kernel pass (no roofline object; used under rocprofv3 --pmc)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,6 +183,7 @@ def main():
     ctx = w.whisper_init_from_file_with_params(str(model).encode(), cp)
     if not ctx:
         raise SystemExit("whisper_init_from_file_with_params failed")
+    bcast = broadcast_weights(p, dist, torch, local_rank, rank) if dist is not None else None
     n_mels = w.whisper_model_n_mels(ctx)
     mel = (np.random.default_rng(42 + rank).random((n_mels, 3000), dtype=np.float32) * 2 - 1)
     w.whisper_set_mel(ctx, mel.ctypes.data_as(C.c_void_p), 3000, n_mels)
@@ -195,9 +233,12 @@ def main():
     tm = w.whisper_get_timings(ctx).contents
     batchd_ms, prompt_ms = float(tm.batchd_ms), float(tm.prompt_ms)
 
-    prof = profile_chunk() if rank == 0 else []
     stats = (C.c_uint64 * 4)()
     p.ggml_backend_mi355x_stats(stats)
+    host_ms = (C.c_double * 4)()
+    p.ggml_backend_mi355x_host_times.argtypes = [C.POINTER(C.c_double)]
+    p.ggml_backend_mi355x_host_times(host_ms)
+    prof = profile_chunk() if (rank == 0 and not a.no_profile) else []
 
     if rank == 0:
         figs = algorithmic_figures(a.arch, a.qtype)
@@ -211,7 +252,9 @@ def main():
             "chunks_per_s": round(chunks_per_s, 4),
             "encode_ms": round(encode_ms, 3), "decode_ms_per_token": round(decode_ms, 4),
             "batchd_ms_per_token": round(batchd_ms, 4), "prompt_ms_per_token": round(prompt_ms, 4),
-            "hip_graph": {"graph_computes": int(stats[0]), "replays": int(stats[1]), "patched_nodes": int(stats[2]), "builds": int(stats[3])},
+            "weight_broadcast": bcast,
+            "hip_graph": {"graph_computes": int(stats[0]), "replays": int(stats[1]), "patched_nodes": int(stats[2]), "builds": int(stats[3]),
+                          "host_ms_total": {"plan": round(host_ms[0], 2), "patch": round(host_ms[1], 2), "launch": round(host_ms[2], 2), "eager": round(host_ms[3], 2)}},
         }
         if prof:
             dom = max(prof, key=lambda r: r["total_ms"])
@@ -235,11 +278,13 @@ def main():
                                     "encode_TFLOPs_at_measured_ms": round(figs["encode_flop"] / (encode_ms * 1e-3) / 1e12, 2) if encode_ms > 0 else None}
         if world == 1 and not a.no_cpu_baseline:
             exe = ROOT / "oracle" / "_ref" / "cpu_baseline"
-            cores = os.cpu_count() or 1
+            # threads actually used: ggml's CPU path stops scaling (and with 2-way SMT oversubscription collapses) well
+            # below the 256 hardware threads of the GPU box's host; 32 = one thread per core of half a socket
+            cores = max(1, min(32, (os.cpu_count() or 2) // 2))
             n_dec = 16 if "large" in a.arch else 64
             try:
-                env = dict(os.environ, LD_LIBRARY_PATH=str(ROOT / "oracle" / "_ref"))
-                r = subprocess.run([str(exe), str(model), str(cores), str(n_dec), "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900)
+                env = dict(os.environ, LD_LIBRARY_PATH=str(ROOT / "oracle" / "_ref"), OMP_PROC_BIND="close", OMP_PLACES="cores")
+                r = subprocess.run([str(exe), str(model), str(cores), str(n_dec), "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
                 cb = json.loads(r.stdout.strip().splitlines()[-1])
                 out["cpu_baseline"] = {"value": round(cb["encode_ms"] + a.n_decode * cb["decode_ms_per_token"], 2), "unit": "ms/chunk", "cores": cores,
                                        "kind": "reference", "encode_ms": cb["encode_ms"], "decode_ms_per_token": cb["decode_ms_per_token"],

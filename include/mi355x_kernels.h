@@ -165,8 +165,29 @@ typedef struct mi355x_gemv_desc {
     int32_t       nseg;
     int32_t       reserved;
     mi355x_gemv_seg seg[3];
+    /* alternative activation source (x == NULL): the partial records of a decode attention
+     * (mi355x_flash_attn_partial below); the combine (ggml-cpu/ops.cpp:8479-8715 final normalisation) runs in the
+     * mat-vec prologue, K must equal H*64.  Not combinable with has_norm. */
+    const float * attn_part_o;
+    const float * attn_part_ml;
+    int32_t       attn_nparts;
+    int32_t       reserved2;
 } mi355x_gemv_desc;
 MI355X_API int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
+
+/* Decode attention in two halves (T <= 8 queries, head_dim 64): mi355x_flash_attn_partial computes, per head, query and
+ * 128-key chunk, the un-normalised partial (max score m, sum l, sum_k exp(s_k - m) v_k) of ggml_flash_attn_ext
+ * (ggml/src/ggml.c:5418-5460; CPU ggml-cpu/ops.cpp:8479-8715) into context scratch memory that stays valid until the
+ * next scratch-using op on the same context; mi355x_flash_attn_combine merges the chunks into dst F32 [64, H, T].
+ * The backend normally skips the second call and hands the partials to mi355x_gemv_fused (O-projection). */
+typedef struct mi355x_attn_partials {
+    const float * part_o;          /* [H][T][nparts][64] */
+    const float * part_ml;         /* [H][T][nparts][2]  */
+    int32_t       nparts, T, H, reserved;
+} mi355x_attn_partials;
+MI355X_API int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
+                                         const mi355x_tensor * mask /* nullable */, float scale, mi355x_attn_partials * out);
+MI355X_API int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_partials * p, const mi355x_tensor * dst);
 
 /* ggml_flash_attn_ext (ggml/src/ggml.c:5418-5460; CPU ggml-cpu/ops.cpp:8479-8715).
  * q: F32 [D, T, H] (any nb1/nb2), k/v: F16 [D, n_kv, H] views, mask: F16 [n_kv, >=T] or NULL,

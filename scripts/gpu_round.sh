@@ -29,11 +29,12 @@ bench)
 prof)
     stage "rocprofv3 --kernel-trace --stats (bench.py $ARCH $QT, 1 step)"
     rm -rf "$OUT/prof"
-    ( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline \
+    ( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline \
         > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err" )
     echo "exit=$?"
     f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1)
     if [ -n "$f" ]; then cp "$f" "$OUT/kernel_stats_${ARCH}_${QT}.csv"; head -25 "$f"; fi
+    python3 scripts/summarize_trace.py "$OUT/prof" > "$OUT/kernel_trace_summary_${ARCH}_${QT}.txt" 2>&1; head -40 "$OUT/kernel_trace_summary_${ARCH}_${QT}.txt"
     # the raw trace is large: keep only the stats
     find "$OUT/prof" -name "*kernel_trace.csv" -size +20M -delete
     ;;
@@ -42,11 +43,25 @@ pmc)
     for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
         tag=$(echo "$ctr" | tr ' ' '+')
         rm -rf "$OUT/pmc_$tag"
-        ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace -d "$OUT/pmc_$tag" -o pmc -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 0 --n-decode 8 --no-cpu-baseline --no-profile \
+        ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace -f csv -d "$OUT/pmc_$tag" -o pmc -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 0 --n-decode 8 --no-cpu-baseline --no-profile \
             > "$OUT/pmc_$tag.json" 2> "$OUT/pmc_$tag.err" )
         echo "$tag exit=$?"
         python3 scripts/summarize_pmc.py "$OUT/pmc_$tag" > "$OUT/pmc_$tag.summary.txt" 2>&1; head -30 "$OUT/pmc_$tag.summary.txt"
         find "$OUT/pmc_$tag" -name "*.csv" -size +20M -delete
+    done
+    ;;
+kbench)
+    stage "kernel micro-benchmarks under rocprofv3 (variants: $KB_VARIANTS)"
+    i=0
+    for var in ${KB_VARIANTS:-default}; do
+        i=$((i+1)); tag="kb$i"
+        rm -rf "$OUT/$tag"
+        ( cd /tmp && env $(echo "$var" | tr ',' ' ' | sed 's/^default$//') timeout 300 rocprofv3 --kernel-trace -f csv -d "$OUT/$tag" -o kb -- python3 "$ROOT/scripts/kbench.py" ${KB_ARGS:-} > "$OUT/$tag.json" 2> "$OUT/$tag.err" )
+        echo "--- $tag [$var] exit=$?"
+        python3 scripts/summarize_trace.py "$OUT/$tag" > "$OUT/$tag.trace.txt" 2>&1
+        echo "variant: $var" >> "$OUT/$tag.trace.txt"
+        head -30 "$OUT/$tag.trace.txt"
+        find "$OUT/$tag" -name "*.csv" -size +8M -delete
     done
     ;;
 wbench)

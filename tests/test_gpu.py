@@ -9,7 +9,12 @@ Tolerances (NMSE = sum (ref-got)^2 / sum ref^2 against the reference's CPU arith
                            only the f32 summation order differs)
   * 2e-6                 : MFMA mat-mul (T > 8): the reference's Q8_0/Q8_K activation rounding is reproduced, d*q products
                            are rounded to f16 (2^-11 relative) before the f32-accumulating MFMA
-  * 3e-5                 : flash attention (the CPU accumulates V in f16, ops.cpp:8629-8643; we accumulate in f32)
+  * flash attention      : the CPU accumulates V in f16 (ops.cpp:8629-8643), we accumulate in f32: checked against an exact
+                           f64 attention (ours < 1e-6 NMSE and never further from the truth than the reference's own
+                           result) and within 1e-4 of the reference
+  * whole model          : logits NMSE < 5e-4 vs the reference CPU path at every step, greedy tokens identical; for scale,
+                           the reference's OWN two attention paths (flash_attn on/off) differ by 1e-3 .. 4e-3 on the same
+                           models (tests/native/model_parity.cpp, MODEL_PARITY_SPREAD=1)
 """
 import ctypes as C
 import json
@@ -46,10 +51,24 @@ def dev(torch, a: np.ndarray):
 
 
 def quantize(oracle, ka, tid, wf):
-    """reference weight quantizer (restated in the oracle, pinned bit-exact by tests/test_oracle.py) -> ggml blocks + planar"""
+    """reference weight quantizer (restated in the oracle, pinned bit-exact by tests/test_oracle.py) -> ggml blocks + planar.
+    Q4_K: the oracle restates the dequantizer and the dot product but not make_qkx2_quants (the weight quantizer is not
+    on the hot path: whisper-quantize produces the file), so valid super-blocks are drawn directly: any bit pattern with
+    finite d / dmin is a legal block_q4_K (ggml-common.h:327-338)."""
     N, K = wf.shape
-    blocks = np.empty(N * ka.row_bytes(tid, K), dtype=np.uint8)
-    oracle.oracle_quantize_row_ref(tid, ptr(wf), ptr(blocks), N * K)
+    if tid == 12:
+        rng = np.random.default_rng(N * 31 + K)
+        nblk = N * K // 256
+        blk = np.zeros((nblk, 144), dtype=np.uint8)
+        d = (rng.uniform(0.5, 1.5, nblk) / (40.0 * np.sqrt(K) * 8)).astype(np.float16)
+        dmin = (rng.uniform(0.5, 1.5, nblk) / (40.0 * np.sqrt(K))).astype(np.float16)
+        blk[:, 0:2] = d.view(np.uint8).reshape(nblk, 2)
+        blk[:, 2:4] = dmin.view(np.uint8).reshape(nblk, 2)
+        blk[:, 4:144] = rng.integers(0, 256, (nblk, 140), dtype=np.uint8)
+        blocks = blk.ravel()
+    else:
+        blocks = np.empty(N * ka.row_bytes(tid, K), dtype=np.uint8)
+        oracle.oracle_quantize_row_ref(tid, ptr(wf), ptr(blocks), N * K)
     return blocks, ka.repack_to_planar(tid, blocks, N * K)
 
 
@@ -339,8 +358,69 @@ def test_flash_attn_vs_oracle(gpu, oracle, T, n_kv, H, mask):
         tm = C.byref(ka.tensor(m_d.data_ptr(), ka.F16, [n_kv, T]))
     ctx.check(ka.lib().mi355x_flash_attn_ext(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), tm, C.byref(to), 0.125), "flash_attn")
     ctx.sync()
-    e = nmse(ref, o_d.cpu().numpy())
-    assert e < 3e-5, e
+    got = o_d.cpu().numpy()
+    # exact (f64) attention on the same f16-rounded q: the reference's error is its f16 V accumulation
+    # (ops.cpp:8629-8643); ours must be no further from the truth than the reference is, and within 1e-4 of the reference
+    qh = q.astype(np.float16).astype(np.float64)
+    sc = np.einsum("thd,khd->htk", qh, k.astype(np.float64)) * 0.125
+    if mask:
+        sc = sc + mf.astype(np.float64)[None, :, :]
+    sc = sc - sc.max(axis=-1, keepdims=True)
+    pr = np.exp(sc)
+    pr /= pr.sum(axis=-1, keepdims=True)
+    exact = np.einsum("htk,khd->thd", pr, v.astype(np.float64))
+    e_ref, e_got = nmse(exact, ref), nmse(exact, got)
+    assert e_got < 1e-9 + e_ref, (e_got, e_ref)
+    assert e_got < 1e-6, e_got
+    assert nmse(ref, got) < 1e-4, nmse(ref, got)
+
+
+@pytest.mark.parametrize("T,n_kv,H", [(1, 1536, 20), (1, 130, 8), (5, 300, 6), (8, 129, 4)])
+def test_attention_partials_feed_the_projection(gpu, oracle, T, n_kv, H):
+    """decode attention leaves per-128-key partial records; the O-projection mat-vec combines them in its prologue.
+    Checked against oracle attention -> oracle mul_mat (the unfused reference sequence W:2623-2660)."""
+    ctx, ka, torch = gpu
+    D, K, N = 64, H * 64, 384
+    rng = np.random.default_rng(T * 101 + n_kv)
+    q = (rng.standard_normal((T, H, D)) * 0.6).astype(np.float32)
+    k = (rng.standard_normal((n_kv, H, D)) * 0.6).astype(np.float16)
+    v = rng.standard_normal((n_kv, H, D)).astype(np.float16)
+    att = np.empty((T, H, D), dtype=np.float32)
+    oracle.oracle_flash_attn(ptr(q), ptr(k.view(np.uint16)), ptr(v.view(np.uint16)), None, ptr(att), D, T, H, n_kv, 0.125)
+    wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    blocks, planar = quantize(oracle, ka, 6, wf)
+    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    res = rng.standard_normal((T, N)).astype(np.float32)
+    q_d, k_d, v_d, w_d, b_d, r_d = (dev(torch, a) for a in (q, k, v, planar, bias, res))
+    tq = ka.tensor(q_d.data_ptr(), ka.F32, [D, T, H], [4, H * D * 4, D * 4, T * H * D * 4])
+    tk = ka.tensor(k_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    tv = ka.tensor(v_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    parts = ka.AttnPartials()
+    ctx.check(ka.lib().mi355x_flash_attn_partial(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), None, 0.125, C.byref(parts)), "fattn_partial")
+    assert parts.nparts == (n_kv + 127) // 128 and parts.T == T and parts.H == H
+    # (a) stand-alone combine
+    o_d = torch.zeros((T, H, D), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    to = ka.tensor(o_d.data_ptr(), ka.F32, [D, H, T])
+    ctx.check(ka.lib().mi355x_flash_attn_combine(ctx.h, C.byref(parts), C.byref(to)), "fattn_combine")
+    # (b) combine inside the projection's prologue, with bias + residual epilogue
+    y_d = torch.zeros((T, N), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    d = ka.GemvDesc()
+    d.K, d.T, d.nseg = K, T, 1
+    d.attn_part_o, d.attn_part_ml, d.attn_nparts = parts.part_o, parts.part_ml, parts.nparts
+    d.seg[0].w, d.seg[0].wtype, d.seg[0].N = w_d.data_ptr(), 6, N
+    d.seg[0].ep = ka.Epilogue(b_d.data_ptr(), 0.0, 0, 0, r_d.data_ptr(), N * 4)
+    d.seg[0].dst, d.seg[0].dst_type, d.seg[0].dst_nb1 = y_d.data_ptr(), ka.F32, N * 4
+    ctx.check(ka.lib().mi355x_gemv_fused(ctx.h, C.byref(d)), "gemv_fused(attn partials)")
+    ctx.sync()
+    got_att = o_d.cpu().numpy()
+    assert nmse(att, got_att) < 1e-4
+    # projection of OUR attention output through the oracle == fused result (isolates the mat-vec from the f16-V difference)
+    ref = np.empty((T, N), dtype=np.float32)
+    oracle.oracle_mul_mat(6, ptr(blocks), ptr(np.ascontiguousarray(got_att.reshape(T, K))), ptr(ref), K, N, T)
+    want = ref + bias[None, :] + res
+    assert nmse(want, y_d.cpu().numpy()) < 1e-9
 
 
 def test_flash_attn_full_size_property(gpu):
@@ -414,11 +494,12 @@ def test_plugin_model_parity(plugin_env, arch, qtype):
     if keep.exists():
         (keep / f"model_parity_{arch}_{qtype}.json").write_text(r.stdout)
     s = d["single"]
-    assert s["worst_nmse"] < 1e-4, s
+    assert s["worst_nmse"] < 5e-4, s
+    assert d["greedy"]["identical_prefix"] == d["greedy"]["steps"], d["greedy"]
     for st in d["steps"]:
         if st["tok_cpu"] != st["tok_gpu"]:
             assert st["margin"] <= 4 * st["max_diff"], st
-    assert d["batch5"]["nmse"] < 1e-4 and d["batch48"]["nmse"] < 1e-4, d
+    assert d["batch5"]["nmse"] < 5e-4 and d["batch48"]["nmse"] < 5e-4, d
 
 
 def test_bench_smoke():

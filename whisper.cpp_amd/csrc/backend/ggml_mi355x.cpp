@@ -15,6 +15,7 @@
 #include "mi355x_kernels.h"
 
 #include <atomic>
+#include <chrono>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -220,10 +221,16 @@ struct mi_backend_ctx {
     std::vector<mi_graph_cache> gcache;
     uint64_t n_graph_compute = 0, n_replay = 0, n_update = 0, n_rebuild = 0;
     bool     recording = false, record_abort = false;
+    double   t_plan_ms = 0, t_patch_ms = 0, t_launch_ms = 0, t_eager_ms = 0;    // host time inside graph_compute
 };
+
+static inline double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static std::vector<mi_backend_ctx *> g_backends;           // live backends (guarded by g_weights_mtx)
 static uint64_t g_total_stats[4] = { 0, 0, 0, 0 };         // counters of already freed backends
+static double   g_total_host_ms[4] = { 0, 0, 0, 0 };
 
 static mi355x_tensor to_mt(const ggml_tensor * t) {
     mi355x_tensor m;
@@ -441,6 +448,52 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
     return true;
 }
 
+// decoder step: flash_attn_ext (T <= 8) -> reshape -> mul_mat chain (the O-projection).  The attention kernel leaves
+// per-128-key partial records; their combine runs in the prologue of the projection mat-vec (one kernel less per
+// attention, src/whisper.cpp:2623-2660 and :2703-2770)
+static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int & end_out, int & rc_out) {
+    const ggml_tensor * fa = g->nodes[i];
+    const ggml_tensor * q = fa->src[0], * k = fa->src[1], * v = fa->src[2], * m = fa->src[3];
+    const int64_t T = q->ne[1], H = q->ne[2];
+    if (T > 8 || q->ne[3] != 1 || fa->type != GGML_TYPE_F32 || !ggml_is_contiguous(fa)) return false;
+    mi355x_tensor mq = to_mt(q), mk = to_mt(k), mv = to_mt(v), mm_;
+    if (m) mm_ = to_mt(m);
+    float scale; memcpy(&scale, fa->op_params, 4);
+    mi355x_attn_partials parts;
+    int rc = mi355x_flash_attn_partial(b->k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
+    if (rc == MI355X_E_UNSUPPORTED) return false;
+    rc_out = rc; end_out = i;
+    if (rc) return true;
+
+    // from here on the partials exist: either the projection consumes them, or they are combined into fa's memory
+    bool fused = false;
+    const int j = next_real(g, i);
+    mm_chain ch;
+    if (j < g->n_nodes && g->nodes[j]->op == GGML_OP_MUL_MAT && can_elide(g, fa, 1)) {
+        const ggml_tensor * mm = g->nodes[j], * x = mm->src[1], * w = mm->src[0];
+        const bool x_is_fa = x->view_src == fa && x->view_offs == 0 && x->type == GGML_TYPE_F32 && ggml_is_contiguous(x) &&
+                             x->ne[0] == H*64 && x->ne[1] == T && x->ne[2] == 1 && x->ne[3] == 1 &&
+                             use_count(g, x) == 1 && !(x->flags & GGML_TENSOR_FLAG_OUTPUT);
+        if (x_is_fa && is_quant_type(w->type) && w->type != GGML_TYPE_Q4_K && ggml_is_contiguous(w) && ggml_n_dims(w) <= 2 && w->ne[0] == H*64 &&
+            parse_mm_chain(g, j, true, ch)) {
+            mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
+            d.K = (int) (H*64); d.T = (int) T; d.nseg = 1;
+            d.attn_part_o = parts.part_o; d.attn_part_ml = parts.part_ml; d.attn_nparts = parts.nparts;
+            mi355x_gemv_seg & sg = d.seg[0];
+            sg.w = w->data; sg.wtype = (int32_t) w->type; sg.N = (int32_t) w->ne[1]; sg.ep = ch.ep;
+            sg.dst = ch.last->data; sg.dst_type = (int32_t) ch.last->type;
+            sg.dst_nb1 = ch.last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch.last == ch.mm ? (int64_t) ch.mm->nb[1] : (int64_t) ch.last->nb[1]);
+            rc = mi355x_gemv_fused(b->k, &d);
+            if (rc != MI355X_E_UNSUPPORTED) { fused = true; rc_out = rc; end_out = ch.end; }
+        }
+    }
+    if (!fused) {
+        mi355x_tensor md = to_mt(fa);
+        rc_out = mi355x_flash_attn_combine(b->k, &parts, &md);
+    }
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // supports_op / single-node dispatch
 // ---------------------------------------------------------------------------------------------------
@@ -586,6 +639,11 @@ static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
                 else i = c.end;
                 b->act_src = nullptr;
             }
+        } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->fuse && n->src[0]->ne[1] <= 8) {
+            int end = i, rc2 = MI355X_E_UNSUPPORTED;
+            if (try_fattn_gemv(b, g, i, end, rc2)) { rc = rc2; i = end; }
+            else rc = run_node(b, n);
+            b->act_src = nullptr;
         } else {
             rc = run_node(b, n);
             b->act_src = nullptr;
@@ -647,6 +705,7 @@ static int mi_run_recorded(mi_backend_ctx * b, const mi355x_launch * L, int n, c
         b->n_rebuild++;
     } else {
         // patch the kernel nodes whose arguments or grid changed since the last replay
+        const double tp0 = now_ms();
         for (int i = 0; i < n; i++) {
             const mi355x_launch & o = gc->launches[i];
             const bool same = !memcmp(o.grid, L[i].grid, sizeof(o.grid)) &&
@@ -665,9 +724,12 @@ static int mi_run_recorded(mi_backend_ctx * b, const mi355x_launch * L, int n, c
             b->n_update++;
         }
         b->n_replay++;
+        b->t_patch_ms += now_ms() - tp0;
     }
     gc->hits++;
+    const double tl0 = now_ms();
     hipError_t e = hipGraphLaunch(gc->exec, stream);
+    b->t_launch_ms += now_ms() - tl0;
     if (e != hipSuccess) { MI_LOG("hipGraphLaunch failed: %s", hipGetErrorString(e)); return -2; }
     return 0;
 }
@@ -686,6 +748,7 @@ static void mi_backend_free(ggml_backend_t backend) {
         std::lock_guard<std::mutex> lk(g_weights_mtx);
         for (size_t i = 0; i < g_backends.size(); i++) if (g_backends[i] == b) { g_backends.erase(g_backends.begin() + i); break; }
         g_total_stats[0] += b->n_graph_compute; g_total_stats[1] += b->n_replay; g_total_stats[2] += b->n_update; g_total_stats[3] += b->n_rebuild;
+        g_total_host_ms[0] += b->t_plan_ms; g_total_host_ms[1] += b->t_patch_ms; g_total_host_ms[2] += b->t_launch_ms; g_total_host_ms[3] += b->t_eager_ms;
     }
     mi355x_ctx_destroy(b->k);
     delete b;
@@ -705,10 +768,12 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
     // graphs pay off when the launch sequence is long and launch-bound (decoder step); profiling needs eager launches
     const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32;
     if (use_graph) {
+        const double t0 = now_ms();
         mi355x_record_begin(b->k);
         b->recording = true; b->record_abort = false;
         int rc = mi_emit_graph(b, cgraph);
         b->recording = false;
+        b->t_plan_ms += now_ms() - t0;
         const mi355x_launch * L; const uint8_t * blob; size_t bsz;
         const int n = mi355x_record_end(b->k, &L, &blob, &bsz);
         if (rc != 0) return GGML_STATUS_FAILED;
@@ -721,7 +786,10 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
             b->graphs = false;
         } else return GGML_STATUS_SUCCESS;
     }
-    return mi_emit_graph(b, cgraph) == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    const double t0 = now_ms();
+    const int rc = mi_emit_graph(b, cgraph);
+    b->t_eager_ms += now_ms() - t0;
+    return rc == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
 }
 
 static const ggml_backend_i mi_backend_iface = {
@@ -895,6 +963,14 @@ void ggml_backend_mi355x_stats(uint64_t * out) {
     for (auto * b : g_backends) { out[0] += b->n_graph_compute; out[1] += b->n_replay; out[2] += b->n_update; out[3] += b->n_rebuild; }
 }
 
+// out[0..3] = host milliseconds spent inside graph_compute: planning (graph walk + launch recording), hipGraph node
+// patching, hipGraphLaunch, eager launches — over all backends so far
+void ggml_backend_mi355x_host_times(double * out) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    for (int i = 0; i < 4; i++) out[i] = g_total_host_ms[i];
+    for (auto * b : g_backends) { out[0] += b->t_plan_ms; out[1] += b->t_patch_ms; out[2] += b->t_launch_ms; out[3] += b->t_eager_ms; }
+}
+
 int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     int n = 0;
@@ -916,6 +992,7 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_prof_reset_all"))  return (void *) ggml_backend_mi355x_prof_reset_all;
     if (!strcmp(name, "ggml_backend_mi355x_prof_report_all")) return (void *) ggml_backend_mi355x_prof_report_all;
     if (!strcmp(name, "ggml_backend_mi355x_stats"))           return (void *) ggml_backend_mi355x_stats;
+    if (!strcmp(name, "ggml_backend_mi355x_host_times"))      return (void *) ggml_backend_mi355x_host_times;
     return nullptr;
 }
 

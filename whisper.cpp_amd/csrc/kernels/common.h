@@ -63,6 +63,9 @@ static inline int emit(mi355x_ctx * ctx, const char * name, void (*kernel)(Args)
     return mi355x_emit(ctx, name, (const void *) kernel, grid, block, shmem, &a, (uint32_t) sizeof(Args), bytes, flops);
 }
 
+// second-generation decoder mat-vec (decode.hip); MI355X_E_UNSUPPORTED => caller uses k_gemv (gemv.hip)
+int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
+
 // ---------------------------------------------------------------------------------------------
 // tensor helpers (host)
 // ---------------------------------------------------------------------------------------------

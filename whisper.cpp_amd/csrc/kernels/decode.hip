@@ -1,0 +1,586 @@
+// Decoder-step kernels, second generation (T <= 8 columns): the launch/latency-bound half of the hot path.
+//
+// One whisper decode step is ~8 all-to-all dependent phases per layer (LN+QKV, self-attention, O-proj, LN+Q_cross,
+// cross-attention, O-proj, LN+fc1+GELU, fc2), each only 1-8 MB of HBM traffic, i.e. each phase costs one memory
+// round trip plus a kernel boundary rather than bytes/bandwidth.  These kernels are built around that:
+//   k_gemv8      : quantized mat-vec.  8 lanes per weight row, 8 rows per wave pass => every lane busy for the
+//                  row lengths Whisper uses (nb = K/32 = 16/24/32/40/160 blocks), 128-byte contiguous segments per
+//                  row per load instruction, 3-step instead of 6-step lane reduction.  The first chunk of weight
+//                  loads is issued BEFORE the activation prologue (LayerNorm / attention-combine / Q8_0
+//                  quantization into LDS), so the HBM latency of the weights overlaps the prologue instead of
+//                  following it.  Non-temporal loads: every weight byte is used exactly once.
+//   k_fattn_dec  : decode attention, 128 keys per workgroup (4 waves x 32 keys), all K and V loads of a wave in
+//                  flight at once (8 x 16 B per lane), in-wave softmax, one partial (m, l, o[64]) record per
+//                  (head, query, 128-key chunk).
+//   the combine of those partial records is folded into the prologue of the mat-vec that consumes the attention
+//   output (the O-projection), so attention costs ONE kernel instead of two; k_fattn_combine2 is the stand-alone
+//   fallback when no such consumer follows.
+//
+// Reference arithmetic reproduced: activations -> Q8_0 blocks (arch/x86/quants.c:302-398), integer block dot products,
+// f32 accumulation of d_w*d_x*isum (ggml-cpu/quants.c:225-259, :365-406, :451-479); flash_attn_ext semantics of
+// ggml-cpu/ops.cpp:8479-8715 (q rounded to f16, f32 scores, online softmax; V accumulated in f32 here, f16 there).
+#include "common.h"
+#include <math.h>
+#include <stdlib.h>
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct DGSeg {
+    const void *  w;  int64_t nbt;  int N;  int has_scale;
+    const float * bias; float scale; int gelu;
+    const float * residual; int64_t res_nb1;
+    void * dst; int64_t dst_nb1; int dst_f16; int pad;
+};
+struct DGArgs {
+    const float * x; int64_t x_nb1; int K; int has_norm; float eps; int nseg;
+    const float * ln_w; const float * ln_b;
+    const float * part_o; const float * part_ml; int nparts; int passes;     // x == nullptr: x = combine(attention partials)
+    int row_start[4];
+    int xfirst; int pad1;
+    DGSeg seg[3];
+    const uint16_t * gelu_tab;
+};
+
+#define DG_U 5            // 32-element blocks per lane per chunk (8 lanes x 5 = 40 blocks = one K=1280 row)
+#define DG_XR 5           // float4 activation registers per thread in the "activations first" order
+
+static inline size_t dg_lds_bytes(int K, int T, bool staged) {
+    // red[64 floats] | lo[T][nb] uint4 | hi[T][nb] uint4 | dx[T][nb] f32 | sx[T][nb] i32 | stage[T][K] f32 (optional)
+    return 256 + (size_t) T * (K/32) * 40 + (staged ? (size_t) T * K * 4 : 0);
+}
+
+template <int WT> struct wblk;
+template <> struct wblk<MI355X_TYPE_Q4_0> { u32x4 q; uint16_t d; };
+template <> struct wblk<MI355X_TYPE_Q5_0> { u32x4 q; uint32_t qh; uint16_t d; };
+template <> struct wblk<MI355X_TYPE_Q8_0> { u32x4 q, q1; uint16_t d; };
+
+template <int WT>
+__device__ __forceinline__ void wblk_load(wblk<WT> & r, const char * base, int64_t nbt, int64_t ib, bool ok) {
+    const u32x4 z = { 0, 0, 0, 0 };
+    if constexpr (WT == MI355X_TYPE_Q8_0) {
+        const u32x4 * q = (const u32x4 *) (base + ib*32);
+        r.q  = ok ? __builtin_nontemporal_load(q)     : z;
+        r.q1 = ok ? __builtin_nontemporal_load(q + 1) : z;
+        r.d  = ok ? *((const uint16_t *) (base + nbt*32) + ib) : (uint16_t) 0;    // small planes: plain loads (L1 reuse across chunks)
+    } else {
+        r.q = ok ? __builtin_nontemporal_load((const u32x4 *) (base + ib*16)) : z;
+        if constexpr (WT == MI355X_TYPE_Q5_0) {
+            r.qh = ok ? *((const uint32_t *) (base + nbt*16) + ib) : 0u;
+            r.d  = ok ? *((const uint16_t *) (base + nbt*20) + ib) : (uint16_t) 0;
+        } else {
+            r.d  = ok ? *((const uint16_t *) (base + nbt*16) + ib) : (uint16_t) 0;
+        }
+    }
+}
+
+// integer dot of one weight block with the Q8_0 activation block (al = elements 0..15, ah = 16..31), minus the offset term
+template <int WT>
+__device__ __forceinline__ void wblk_unpack(const wblk<WT> & r, uint32_t vlo[4], uint32_t vhi[4]) {
+    if constexpr (WT == MI355X_TYPE_Q8_0) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { vlo[i] = r.q[i]; vhi[i] = r.q1[i]; }
+    } else if constexpr (WT == MI355X_TYPE_Q5_0) {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            vlo[i] = (r.q[i] & 0x0F0F0F0Fu)        | spread4_to_bit4(r.qh >> (4*i));
+            vhi[i] = ((r.q[i] >> 4) & 0x0F0F0F0Fu) | spread4_to_bit4(r.qh >> (16 + 4*i));
+        }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { vlo[i] = r.q[i] & 0x0F0F0F0Fu; vhi[i] = (r.q[i] >> 4) & 0x0F0F0F0Fu; }
+    }
+}
+
+// quantize 4 consecutive values (one lane of an 8-lane group = one 32-block) to Q8_0 and store to LDS
+__device__ __forceinline__ void dg_q8_0_store(const float v[4], int e, int t, int nb, uint32_t * lo, uint32_t * hi, float * dx, int * sx) {
+    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    const float d  = amax / 127.0f;
+    const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+    const int q0 = (int) rintf(v[0]*id), q1 = (int) rintf(v[1]*id), q2 = (int) rintf(v[2]*id), q3 = (int) rintf(v[3]*id);
+    int s = q0 + q1 + q2 + q3;
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    const uint32_t packed = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+    const int b = e >> 5, w = (e & 31) >> 2;
+    uint32_t * plane = w < 4 ? lo : hi;
+    plane[((size_t) t*nb + b)*4 + (w & 3)] = packed;
+    if (w == 0) { dx[t*nb + b] = round_f16(d); sx[t*nb + b] = s; }
+}
+
+template <int WT, int T>
+__global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int K = a.K, nb = K >> 5;
+    const int r8 = lane >> 3, j8 = lane & 7;
+    const int ntot = a.row_start[a.nseg];
+    const int nchunks = (nb + 8*DG_U - 1) / (8*DG_U);
+    const int total = a.passes * nchunks;
+    const int wg = blockIdx.x * nwaves + wave;
+
+    // ---- per-lane row bookkeeping for pass p: returns weight base / block count of this lane's row ----
+    auto row_of = [&](int pass, int & s, int & row) -> bool {
+        const int grow = (wg * a.passes + pass) * 8 + r8;
+        s = 0;
+        if (a.nseg > 1 && grow >= a.row_start[1]) s = 1;
+        if (a.nseg > 2 && grow >= a.row_start[2]) s = 2;
+        row = grow - a.row_start[s];
+        return grow < ntot;
+    };
+    auto load_chunk = [&](wblk<WT> * r, int it) {
+        const int pass = it / nchunks, c = it - pass*nchunks;
+        int s, row; const bool rok = row_of(pass, s, row);
+        const char * base = (const char *) (s == 0 ? a.seg[0].w : (s == 1 ? a.seg[1].w : a.seg[2].w));
+        const int64_t nbt = s == 0 ? a.seg[0].nbt : (s == 1 ? a.seg[1].nbt : a.seg[2].nbt);
+        #pragma unroll
+        for (int u = 0; u < DG_U; u++) {
+            const int g = j8 + 8*(c*DG_U + u);
+            wblk_load<WT>(r[u], base, nbt, (int64_t) row * nb + g, rok && g < nb);
+        }
+    };
+
+    // ---- prologue: activations -> [combine attention partials] -> [LayerNorm] -> Q8_0 planes in LDS ----
+    float * red = (float *) smem;
+    uint32_t * lo = (uint32_t *) (smem + 256);
+    uint32_t * hi = lo + (size_t) T*nb*4;
+    float * dx = (float *) (hi + (size_t) T*nb*4);
+    int *   sx = (int *) (dx + T*nb);
+    float * stage = (float *) (sx + T*nb);
+    const bool staged = a.x == nullptr || a.has_norm;
+    const int K4 = K >> 2;
+
+    // Loads return in issue order (vmcnt), so the short-latency activation loads (L2 hits) go first and the first chunk
+    // of weights (HBM misses) right behind them: the prologue then runs while the weights are still in flight.
+    // xfirst: the whole activation fits DG_XR float4 registers per thread; otherwise the weights are requested first and
+    // the activation streams through behind them.
+    wblk<WT> cur[DG_U], nxt[DG_U];
+    float4 xr[DG_XR];
+    if (a.xfirst) {
+        #pragma unroll
+        for (int i = 0; i < DG_XR; i++) {
+            const int idx = tid + i*nthreads;
+            const int t = idx / K4, e4 = idx - t*K4;
+            xr[i] = idx < T*K4 ? *(const float4 *) ((const char *) a.x + (int64_t) t*a.x_nb1 + (int64_t) e4*16) : make_float4(0, 0, 0, 0);
+        }
+    }
+    load_chunk(cur, 0);
+
+    if (a.xfirst) {
+        if (a.has_norm) {
+            #pragma unroll
+            for (int i = 0; i < DG_XR; i++) {
+                const int idx = tid + i*nthreads;
+                if (idx < T*K4) *(float4 *) (stage + (size_t) idx*4) = xr[i];          // stage[t][K] is contiguous: idx*4 == t*K + e4*4
+            }
+            __syncthreads();
+        } else {
+            #pragma unroll
+            for (int i = 0; i < DG_XR; i++) {
+                const int idx = tid + i*nthreads;
+                if (idx < T*K4) {
+                    const int t = idx / K4, e4 = idx - t*K4;
+                    const float v[4] = { xr[i].x, xr[i].y, xr[i].z, xr[i].w };
+                    dg_q8_0_store(v, e4*4, t, nb, lo, hi, dx, sx);
+                }
+            }
+        }
+    } else if (a.x == nullptr) {
+        // x[t][h*64 + d] = sum_p w_p o_p[d] / sum_p w_p l_p,  w_p = exp(m_p - max_p m_p)   (k_fattn_dec records)
+        for (int idx = tid; idx < T*K4; idx += nthreads) {
+            const int t = idx / K4, e4 = idx - t*K4, h = e4 >> 4, d = (e4 & 15) << 2;
+            const int64_t base = ((int64_t) h*T + t) * a.nparts;
+            float M = -1e30f;
+            for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
+            float L = 0.0f; float4 o = make_float4(0, 0, 0, 0);
+            for (int p = 0; p < a.nparts; p++) {
+                const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
+                const float w = __expf(ml.x - M);
+                const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + d);
+                L = fmaf(w, ml.y, L);
+                o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
+            }
+            const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+            *(float4 *) (stage + (size_t) t*K + e4*4) = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
+        }
+        __syncthreads();
+    } else if (a.has_norm) {
+        for (int idx = tid; idx < T*K4; idx += nthreads) {
+            const int t = idx / K4, e4 = idx - t*K4;
+            *(float4 *) (stage + (size_t) t*K + e4*4) = *(const float4 *) ((const char *) a.x + (int64_t) t*a.x_nb1 + (int64_t) e4*16);
+        }
+        __syncthreads();
+    }
+    if (a.has_norm) {
+        // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine: mean, then variance of (x - mean), y = (x-mean)*rsqrt(var+eps)*w + b
+        float part[T];
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            float s = 0.0f;
+            for (int e4 = tid; e4 < K4; e4 += nthreads) { const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4); s += (v.x + v.y) + (v.z + v.w); }
+            s = wave_sum(s);
+            if (lane == 0) red[wave*8 + t] = s;
+        }
+        __syncthreads();
+        float mean[T];
+        #pragma unroll
+        for (int t = 0; t < T; t++) { float s = 0.0f; for (int w = 0; w < nwaves; w++) s += red[w*8 + t]; mean[t] = s / K; }
+        __syncthreads();
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            float s = 0.0f;
+            for (int e4 = tid; e4 < K4; e4 += nthreads) {
+                const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4);
+                const float d0 = v.x - mean[t], d1 = v.y - mean[t], d2 = v.z - mean[t], d3 = v.w - mean[t];
+                s += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+            }
+            s = wave_sum(s);
+            if (lane == 0) red[wave*8 + t] = s;
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int t = 0; t < T; t++) { float s = 0.0f; for (int w = 0; w < nwaves; w++) s += red[w*8 + t]; part[t] = 1.0f / sqrtf(s / K + a.eps); }
+        for (int idx = tid; idx < T*K4; idx += nthreads) {
+            const int t = idx / K4, e4 = idx - t*K4;
+            float mt = mean[0], sc = part[0];
+            #pragma unroll
+            for (int tt = 1; tt < T; tt++) { mt = t == tt ? mean[tt] : mt; sc = t == tt ? part[tt] : sc; }
+            const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4);
+            const float4 w = *(const float4 *) (a.ln_w + e4*4);
+            const float4 b = *(const float4 *) (a.ln_b + e4*4);
+            float o[4] = { (v.x - mt) * sc, (v.y - mt) * sc, (v.z - mt) * sc, (v.w - mt) * sc };
+            o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
+            o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
+            dg_q8_0_store(o, e4*4, t, nb, lo, hi, dx, sx);
+        }
+    } else if (!a.xfirst) {
+        for (int idx = tid; idx < T*K4; idx += nthreads) {
+            const int t = idx / K4, e4 = idx - t*K4;
+            const float4 x4 = staged ? *(const float4 *) (stage + (size_t) t*K + e4*4)
+                                     : *(const float4 *) ((const char *) a.x + (int64_t) t*a.x_nb1 + (int64_t) e4*16);
+            const float v[4] = { x4.x, x4.y, x4.z, x4.w };
+            dg_q8_0_store(v, e4*4, t, nb, lo, hi, dx, sx);
+        }
+    }
+    __syncthreads();
+
+    // ---- main loop: chunk `it` in registers, chunk it+1 in flight ----
+    const uint4 * alo = (const uint4 *) lo;
+    const uint4 * ahi = (const uint4 *) hi;
+    float acc[T];
+    #pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = 0.0f;
+
+    for (int it = 0; it < total; it++) {
+        if (it + 1 < total) load_chunk(nxt, it + 1);
+        const int pass = it / nchunks, c = it - pass*nchunks;
+        #pragma unroll
+        for (int u = 0; u < DG_U; u++) {
+            const int g = j8 + 8*(c*DG_U + u);
+            if (g < nb) {
+                uint32_t vlo[4], vhi[4];
+                wblk_unpack<WT>(cur[u], vlo, vhi);
+                const float dw = h2f(cur[u].d);
+                constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+                #pragma unroll
+                for (int t = 0; t < T; t++) {
+                    const uint4 al = alo[(size_t) t*nb + g], ah = ahi[(size_t) t*nb + g];
+                    int sum = 0;
+                    sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
+                    if (off) sum -= off * sx[t*nb + g];
+                    acc[t] = fmaf(dw * dx[t*nb + g], (float) sum, acc[t]);
+                }
+            }
+        }
+        if (c == nchunks - 1) {
+            // reduce over the 8 lanes of the row, lane j8 == t finishes column t
+            #pragma unroll
+            for (int t = 0; t < T; t++) {
+                float v = acc[t];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                acc[t] = v;
+            }
+            float v = acc[0];
+            #pragma unroll
+            for (int t = 1; t < T; t++) v = (j8 == t) ? acc[t] : v;
+            int s, row; const bool rok = row_of(pass, s, row);
+            if (rok && j8 < T) {
+                const DGSeg & sg = a.seg[s];
+                if (sg.bias)      v = v + sg.bias[row];
+                if (sg.has_scale) v = v * sg.scale;
+                if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
+                if (sg.residual)  v = v + *(const float *) ((const char *) sg.residual + (int64_t) j8*sg.res_nb1 + (int64_t) row*4);
+                char * dp = (char *) sg.dst + (int64_t) j8*sg.dst_nb1;
+                if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
+            }
+            #pragma unroll
+            for (int t = 0; t < T; t++) acc[t] = 0.0f;
+        }
+        #pragma unroll
+        for (int u = 0; u < DG_U; u++) cur[u] = nxt[u];
+    }
+}
+
+template <int WT>
+static int launch_gemv8_T(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
+    const char * name = "gemv";
+    switch (T) {
+        case 1: return emit(ctx, name, k_gemv8<WT, 1>, grid, block, lds, k, bytes, flops);
+        case 2: return emit(ctx, name, k_gemv8<WT, 2>, grid, block, lds, k, bytes, flops);
+        case 3: return emit(ctx, name, k_gemv8<WT, 3>, grid, block, lds, k, bytes, flops);
+        case 4: return emit(ctx, name, k_gemv8<WT, 4>, grid, block, lds, k, bytes, flops);
+        case 5: return emit(ctx, name, k_gemv8<WT, 5>, grid, block, lds, k, bytes, flops);
+        case 6: return emit(ctx, name, k_gemv8<WT, 6>, grid, block, lds, k, bytes, flops);
+        case 7: return emit(ctx, name, k_gemv8<WT, 7>, grid, block, lds, k, bytes, flops);
+        case 8: return emit(ctx, name, k_gemv8<WT, 8>, grid, block, lds, k, bytes, flops);
+        default: return MI355X_E_UNSUPPORTED;
+    }
+}
+
+// second-generation entry: returns MI355X_E_UNSUPPORTED for anything it does not cover (caller falls back to k_gemv)
+int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
+    if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
+    const int wt = d->seg[0].wtype, K = d->K, T = d->T;
+    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0) return MI355X_E_UNSUPPORTED;
+    if (K <= 0 || K % 32) return MI355X_E_UNSUPPORTED;
+    const bool from_part = d->attn_part_o != nullptr;
+    if (from_part) {
+        if (d->x || !d->attn_part_ml || d->attn_nparts < 1 || d->attn_nparts > 64 || K % 64 || d->has_norm) return MI355X_E_UNSUPPORTED;
+    } else if (!d->x || ((uintptr_t) d->x % 16) || (d->x_nb1 % 16)) return MI355X_E_UNSUPPORTED;
+    if (d->has_norm && (!d->ln_w || !d->ln_b || ((uintptr_t) d->ln_w % 16) || ((uintptr_t) d->ln_b % 16))) return MI355X_E_UNSUPPORTED;
+    const bool staged = from_part || d->has_norm;
+    const size_t lds = dg_lds_bytes(K, T, staged);
+    if (lds > 64*1024) return MI355X_E_UNSUPPORTED;
+    if (staged && ((size_t) T * (K/32) * 40) % 16) return MI355X_E_UNSUPPORTED;      // float4 alignment of the staging area
+
+    DGArgs k; memset(&k, 0, sizeof(k));
+    k.x = from_part ? nullptr : d->x; k.x_nb1 = d->x_nb1; k.K = K; k.has_norm = d->has_norm; k.eps = d->eps; k.nseg = d->nseg;
+    k.ln_w = d->ln_w; k.ln_b = d->ln_b; k.gelu_tab = ctx->gelu_tab;
+    k.part_o = d->attn_part_o; k.part_ml = d->attn_part_ml; k.nparts = d->attn_nparts;
+    int ntot = 0; double wbytes = 0;
+    for (int s = 0; s < d->nseg; s++) {
+        const mi355x_gemv_seg & g = d->seg[s];
+        if (g.wtype != wt || g.N <= 0 || ((uintptr_t) g.w % 16)) return MI355X_E_UNSUPPORTED;
+        if (g.dst_type != MI355X_TYPE_F32 && g.dst_type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
+        k.row_start[s] = ntot;
+        DGSeg & o = k.seg[s];
+        o.w = g.w; o.N = g.N; o.nbt = (int64_t) g.N * (K / 32);
+        o.bias = g.ep.bias; o.scale = g.ep.scale; o.has_scale = g.ep.has_scale; o.gelu = g.ep.gelu;
+        o.residual = g.ep.residual; o.res_nb1 = g.ep.residual_nb1;
+        o.dst = g.dst; o.dst_nb1 = g.dst_nb1; o.dst_f16 = g.dst_type == MI355X_TYPE_F16;
+        ntot += g.N;
+        wbytes += (double) mi355x_type_row_bytes(wt, K) * g.N;
+    }
+    for (int s = d->nseg; s < 4; s++) k.row_start[s] = ntot;
+    // geometry: 8 rows per wave pass; ~8 waves per CU at most; 1, 2 or 4 waves per workgroup so that small matrices
+    // still spread over as many CUs as they have row groups (each workgroup repeats the activation prologue)
+    const int ngroups = (ntot + 7) / 8;
+    int passes = (ngroups + ctx->n_cu*8 - 1) / (ctx->n_cu*8);
+    if (passes < 1) passes = 1; if (passes > 16) passes = 16;
+    const int nw = (ngroups + passes - 1) / passes;
+    int wpb = nw >= ctx->n_cu*4 ? 4 : (nw >= ctx->n_cu*2 ? 2 : 1);
+    // tuning knobs (A/B on the GPU box): GGML_MI355X_GEMV_WPB = 1|2|4 forces the waves per workgroup,
+    // GGML_MI355X_GEMV_XFIRST=0 disables the activations-first load order
+    static const int env_wpb = getenv("GGML_MI355X_GEMV_WPB") ? atoi(getenv("GGML_MI355X_GEMV_WPB")) : 0;
+    static const int env_xfirst = getenv("GGML_MI355X_GEMV_XFIRST") ? atoi(getenv("GGML_MI355X_GEMV_XFIRST")) : 1;
+    if (env_wpb == 1 || env_wpb == 2 || env_wpb == 4) wpb = env_wpb;
+    if (from_part && wpb < 2) wpb = 2;                     // the combine prologue wants threads (K/4 outputs x nparts loads)
+    k.passes = passes;
+    k.xfirst = (!from_part && env_xfirst && (int64_t) T * (K/4) <= (int64_t) DG_XR * 64 * wpb) ? 1 : 0;
+    const int nblocks = (nw + wpb - 1) / wpb;
+    const double bytes = wbytes + (double) K*T*4 + (double) ntot*T*4;
+    const double flops = 2.0 * ntot * K * T;
+    const dim3 grid(nblocks), block(64*wpb);
+    switch (wt) {
+        case MI355X_TYPE_Q4_0: return launch_gemv8_T<MI355X_TYPE_Q4_0>(ctx, k, T, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q5_0: return launch_gemv8_T<MI355X_TYPE_Q5_0>(ctx, k, T, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q8_0: return launch_gemv8_T<MI355X_TYPE_Q8_0>(ctx, k, T, grid, block, (uint32_t) lds, bytes, flops);
+    }
+    return MI355X_E_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// decode attention: partial records per (head, query, 128-key chunk)
+//   part_o [((h*T + t)*nparts + p)*64 + d]     un-normalised sum_k exp(s_k - m) v_k[d]
+//   part_ml[((h*T + t)*nparts + p)*2 + {0,1}]  m = max score of the chunk (or -1e30), l = sum_k exp(s_k - m)
+// ---------------------------------------------------------------------------------------------------
+struct FDArgs {
+    dtensor q, k, v, m;
+    int has_mask; float scale;
+    int T, n_kv, H, rk2, rv2, nparts;
+    float * part_o; float * part_ml;
+};
+
+template <int T>
+__global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
+    __shared__ __attribute__((aligned(16))) float wo[4][T][64];
+    __shared__ float wml[4][T][2];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kg = lane >> 3, dc = lane & 7;                       // key group 0..7, dim chunk (8 dims = 16 bytes)
+    const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2;
+    const int p = blockIdx.x;
+    const int kbeg = p*128 + wave*32;
+
+    // all K and V rows of this wave are requested up front: 8 x 16 B per lane in flight
+    const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2] + dc*16;
+    const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2] + dc*16;
+    uint4 kr[4], vr[4];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int key = kbeg + kg + 8*i;
+        const bool ok = key < a.n_kv;
+        kr[i] = ok ? *(const uint4 *) (kbase + (int64_t) key*a.k.nb[1]) : make_uint4(0, 0, 0, 0);
+        vr[i] = ok ? *(const uint4 *) (vbase + (int64_t) key*a.v.nb[1]) : make_uint4(0, 0, 0, 0);
+    }
+    // q (rounded to f16 like the CPU's q_to_vec_dot), this lane's 8 dims of every query
+    float qf[T][8];
+    #pragma unroll
+    for (int t = 0; t < T; t++) {
+        const float * qp = (const float *) (a.q.data + (int64_t) t*a.q.nb[1] + (int64_t) hq*a.q.nb[2]) + dc*8;
+        const float4 q0 = *(const float4 *) qp, q1 = *(const float4 *) (qp + 4);
+        qf[t][0] = round_f16(q0.x); qf[t][1] = round_f16(q0.y); qf[t][2] = round_f16(q0.z); qf[t][3] = round_f16(q0.w);
+        qf[t][4] = round_f16(q1.x); qf[t][5] = round_f16(q1.y); qf[t][6] = round_f16(q1.z); qf[t][7] = round_f16(q1.w);
+    }
+    float sc[T][4];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int key = kbeg + kg + 8*i;
+        const uint32_t w[4] = { kr[i].x, kr[i].y, kr[i].z, kr[i].w };
+        float kf[8];
+        #pragma unroll
+        for (int e = 0; e < 4; e++) { kf[2*e] = h2f((uint16_t) (w[e] & 0xFFFF)); kf[2*e+1] = h2f((uint16_t) (w[e] >> 16)); }
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            float s = 0.0f;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[t][e], s);
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            float x = s * a.scale;
+            if (a.has_mask && key < a.n_kv) x += h2f(*(const uint16_t *) (a.m.data + (int64_t) t*a.m.nb[1] + (int64_t) key*2));
+            sc[t][i] = key < a.n_kv ? x : -INFINITY;
+        }
+    }
+    #pragma unroll
+    for (int t = 0; t < T; t++) {
+        float m = fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3]));
+        m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = fmaxf(m, -1e30f);
+        float l = 0.0f, o[8];
+        #pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float pk = __expf(sc[t][i] - m);
+            l += pk;
+            const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o[2*e]   = fmaf(pk, h2f((uint16_t) (w[e] & 0xFFFF)), o[2*e]);
+                o[2*e+1] = fmaf(pk, h2f((uint16_t) (w[e] >> 16)),    o[2*e+1]);
+            }
+        }
+        // sum over the 8 key groups (lanes with equal dc)
+        l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+        #pragma unroll
+        for (int e = 0; e < 8; e++) { float v = o[e]; v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); o[e] = v; }
+        if (kg == 0) {
+            *(float4 *) &wo[wave][t][dc*8]     = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4 *) &wo[wave][t][dc*8 + 4] = make_float4(o[4], o[5], o[6], o[7]);
+            if (dc == 0) { wml[wave][t][0] = m; wml[wave][t][1] = l; }
+        }
+    }
+    __syncthreads();
+    // merge the 4 waves: thread (t, d) for t*64 + d < T*64
+    for (int idx = tid; idx < T*64; idx += 256) {
+        const int t = idx >> 6, d = idx & 63;
+        const float m0 = wml[0][t][0], m1 = wml[1][t][0], m2 = wml[2][t][0], m3 = wml[3][t][0];
+        const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float w0 = __expf(m0 - M), w1 = __expf(m1 - M), w2 = __expf(m2 - M), w3 = __expf(m3 - M);
+        const float o = fmaf(w3, wo[3][t][d], fmaf(w2, wo[2][t][d], fmaf(w1, wo[1][t][d], w0 * wo[0][t][d])));
+        const int64_t rec = ((int64_t) hq*T + t) * a.nparts + p;
+        a.part_o[rec*64 + d] = o;
+        if (d == 0) {
+            a.part_ml[rec*2]     = M;
+            a.part_ml[rec*2 + 1] = fmaf(w3, wml[3][t][1], fmaf(w2, wml[2][t][1], fmaf(w1, wml[1][t][1], w0 * wml[0][t][1])));
+        }
+    }
+}
+
+struct FC2Args { const float * part_o; const float * part_ml; int nparts, T, H; dtensor d; };
+__global__ void __launch_bounds__(64) k_fattn_combine2(const FC2Args a) {
+    const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const int64_t base = ((int64_t) h*a.T + t) * a.nparts;
+    float M = -1e30f;
+    for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
+    float L = 0.0f, O = 0.0f;
+    for (int p = 0; p < a.nparts; p++) {
+        const float w = __expf(a.part_ml[(base + p)*2] - M);
+        L = fmaf(w, a.part_ml[(base + p)*2 + 1], L);
+        O = fmaf(w, a.part_o[(base + p)*64 + lane], O);
+    }
+    float * dp = (float *) (a.d.data + (int64_t) h*a.d.nb[1] + (int64_t) t*a.d.nb[2]);
+    dp[lane] = L == 0.0f ? 0.0f : O * (1.0f / L);
+}
+
+static int fattn_dec_check(const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v, const mi355x_tensor * mask) {
+    if (q->type != MI355X_TYPE_F32 || k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
+    if (q->ne[0] != 64 || k->ne[0] != 64 || v->ne[0] != 64 || q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return MI355X_E_UNSUPPORTED;
+    if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2) return MI355X_E_UNSUPPORTED;
+    const int64_t T = q->ne[1], H = q->ne[2], n_kv = k->ne[1];
+    if (T < 1 || T > 8 || H < 1 || n_kv < 1 || v->ne[1] != n_kv) return MI355X_E_UNSUPPORTED;
+    if (k->ne[2] <= 0 || H % k->ne[2] || v->ne[2] <= 0 || H % v->ne[2]) return MI355X_E_UNSUPPORTED;
+    if (((uintptr_t) q->data | q->nb[1] | q->nb[2]) % 16 || ((uintptr_t) k->data | k->nb[1] | k->nb[2]) % 16 ||
+        ((uintptr_t) v->data | v->nb[1] | v->nb[2]) % 16) return MI355X_E_UNSUPPORTED;
+    if (mask && (mask->type != MI355X_TYPE_F16 || mask->ne[0] < n_kv || mask->ne[1] < T || mask->nb[0] != 2 || mask->ne[2] != 1 || mask->ne[3] != 1)) return MI355X_E_UNSUPPORTED;
+    return 0;
+}
+
+extern "C" int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
+                                         const mi355x_tensor * mask, float scale, mi355x_attn_partials * out) {
+    const int rc0 = fattn_dec_check(q, k, v, mask);
+    if (rc0) return rc0;
+    const int T = (int) q->ne[1], H = (int) q->ne[2], n_kv = (int) k->ne[1];
+    FDArgs a; memset(&a, 0, sizeof(a));
+    a.q = to_d(q); a.k = to_d(k); a.v = to_d(v);
+    if (mask) a.m = to_d(mask);
+    a.has_mask = mask != nullptr; a.scale = scale; a.T = T; a.n_kv = n_kv; a.H = H;
+    a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
+    a.nparts = (n_kv + 127) / 128;
+    mi355x_scratch_reset(ctx);
+    const size_t nrec = (size_t) H * T * a.nparts;
+    a.part_o  = (float *) mi355x_scratch_alloc(ctx, nrec * 64 * 4);
+    a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
+    if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
+    const dim3 grid(a.nparts, H), block(256);
+    const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) T*H*64*4 + (double) nrec*66*4;
+    const double flops = 4.0 * T * (double) n_kv * 64 * H;
+    int rc;
+    switch (T) {
+        case 1: rc = emit(ctx, "fattn_dec", k_fattn_dec<1>, grid, block, 0, a, bytes, flops); break;
+        case 2: rc = emit(ctx, "fattn_dec", k_fattn_dec<2>, grid, block, 0, a, bytes, flops); break;
+        case 3: rc = emit(ctx, "fattn_dec", k_fattn_dec<3>, grid, block, 0, a, bytes, flops); break;
+        case 4: rc = emit(ctx, "fattn_dec", k_fattn_dec<4>, grid, block, 0, a, bytes, flops); break;
+        case 5: rc = emit(ctx, "fattn_dec", k_fattn_dec<5>, grid, block, 0, a, bytes, flops); break;
+        case 6: rc = emit(ctx, "fattn_dec", k_fattn_dec<6>, grid, block, 0, a, bytes, flops); break;
+        case 7: rc = emit(ctx, "fattn_dec", k_fattn_dec<7>, grid, block, 0, a, bytes, flops); break;
+        default: rc = emit(ctx, "fattn_dec", k_fattn_dec<8>, grid, block, 0, a, bytes, flops); break;
+    }
+    if (rc) return rc;
+    out->part_o = a.part_o; out->part_ml = a.part_ml; out->nparts = a.nparts; out->T = T; out->H = H;
+    return 0;
+}
+
+extern "C" int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_partials * p, const mi355x_tensor * dst) {
+    if (dst->type != MI355X_TYPE_F32 || dst->ne[0] != 64 || dst->ne[1] != p->H || dst->ne[2] != p->T || dst->nb[0] != 4) return MI355X_E_UNSUPPORTED;
+    FC2Args c = { p->part_o, p->part_ml, p->nparts, p->T, p->H, to_d(dst) };
+    return emit(ctx, "fattn_combine", k_fattn_combine2, dim3(p->T, p->H), dim3(64), 0, c, 0, 0);
+}

@@ -14,6 +14,7 @@
 //                  to cover all CUs; partial (max, sum, O) records are merged by k_fattn_combine.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 #define FA_D 64
 
@@ -310,6 +311,13 @@ extern "C" int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, 
     const double flops = 4.0 * T * (double) n_kv * FA_D * H;
     if (n_kv == 0) return mi355x_memset(ctx, dst->data, 0, (size_t) dst->nb[3]*dst->ne[3]);
 
+    static const bool dec_v2 = !(getenv("GGML_MI355X_FATTN_V1") && atoi(getenv("GGML_MI355X_FATTN_V1")));
+    if (T <= 8 && dec_v2) {
+        mi355x_attn_partials parts;
+        const int rc = mi355x_flash_attn_partial(ctx, q, k, v, mask, scale, &parts);
+        if (rc == 0) return mi355x_flash_attn_combine(ctx, &parts, dst);
+        if (rc != MI355X_E_UNSUPPORTED) return rc;
+    }
     if (T <= 8) {
         const int nparts = (n_kv + 31) / 32, nblk = (nparts + 3) / 4;
         mi355x_scratch_reset(ctx);

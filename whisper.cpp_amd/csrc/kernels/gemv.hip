@@ -12,6 +12,7 @@
 // wave reduction, fused LayerNorm prologue and bias/scale/GELU/residual/f16 epilogue.  No LDS staging of
 // weights: each weight byte is used exactly once.
 #include "common.h"
+#include <stdlib.h>
 
 struct GemvSeg {
     const void *  w;  int64_t nbt;  int N;  int has_scale;
@@ -356,6 +357,12 @@ static int launch_gemv_T(mi355x_ctx * ctx, const GemvArgs & k, int T, dim3 grid,
 
 extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
+    static const bool use_v2 = !(getenv("GGML_MI355X_GEMV_V1") && atoi(getenv("GGML_MI355X_GEMV_V1")));
+    if (use_v2) {
+        const int rc = mi355x_gemv8(ctx, d);
+        if (rc != MI355X_E_UNSUPPORTED) return rc;
+    }
+    if (d->attn_part_o || !d->x) return MI355X_E_UNSUPPORTED;      // only the v2 kernel reads attention partials
     const int wt = d->seg[0].wtype, K = d->K, T = d->T;
     const int blk = wt == MI355X_TYPE_Q4_K ? 256 : (wt == MI355X_TYPE_F16 ? 8 : 32);
     if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K && wt != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
