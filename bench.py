@@ -235,7 +235,7 @@ def main():
 
     stats = (C.c_uint64 * 4)()
     p.ggml_backend_mi355x_stats(stats)
-    host_ms = (C.c_double * 4)()
+    host_ms = (C.c_double * 12)()
     p.ggml_backend_mi355x_host_times.argtypes = [C.POINTER(C.c_double)]
     p.ggml_backend_mi355x_host_times(host_ms)
     prof = profile_chunk() if (rank == 0 and not a.no_profile) else []
@@ -254,7 +254,9 @@ def main():
             "batchd_ms_per_token": round(batchd_ms, 4), "prompt_ms_per_token": round(prompt_ms, 4),
             "weight_broadcast": bcast,
             "hip_graph": {"graph_computes": int(stats[0]), "replays": int(stats[1]), "patched_nodes": int(stats[2]), "builds": int(stats[3]),
-                          "host_ms_total": {"plan": round(host_ms[0], 2), "patch": round(host_ms[1], 2), "launch": round(host_ms[2], 2), "eager": round(host_ms[3], 2)}},
+                          "host_ms_total": {"plan": round(host_ms[0], 2), "patch": round(host_ms[1], 2), "launch": round(host_ms[2], 2), "eager": round(host_ms[3], 2),
+                                            "set_tensor": round(host_ms[4], 2), "get_tensor": round(host_ms[5], 2), "cpy_tensor": round(host_ms[6], 2), "synchronize": round(host_ms[7], 2),
+                                            "calls": [int(host_ms[8 + i]) for i in range(4)]}},
         }
         if prof:
             dom = max(prof, key=lambda r: r["total_ms"])

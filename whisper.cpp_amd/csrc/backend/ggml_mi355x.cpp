@@ -63,6 +63,16 @@ static int                        g_n_devices = -1;
 
 static bool is_quant_type(ggml_type t) { return mi355x_type_is_quantized((int) t) != 0; }
 
+// host-side time spent in the buffer callbacks (set/get/cpy: the per-step H2D of ids / positions / mask and the D2H of
+// the logits row) and in synchronize — reported by ggml_backend_mi355x_host_times
+static std::atomic<uint64_t> g_io_ns[4] = {};      // set_tensor, get_tensor, cpy_tensor, synchronize
+static std::atomic<uint64_t> g_io_calls[4] = {};
+struct io_timer {
+    int slot; std::chrono::steady_clock::time_point t0;
+    explicit io_timer(int s) : slot(s), t0(std::chrono::steady_clock::now()) {}
+    ~io_timer() { g_io_ns[slot] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_io_calls[slot]++; }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // buffer
 // ---------------------------------------------------------------------------------------------------
@@ -83,6 +93,7 @@ static void * mi_buffer_get_base(ggml_backend_buffer_t buffer) { return ((mi_buf
 // quantized tensors are stored planar (include/mi355x_kernels.h); whole-tensor transfers re-layout on the host,
 // partial ones go through read-modify-write of the whole tensor (never happens in whisper.cpp: W:1934-1938)
 static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    io_timer tm(0);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
@@ -106,6 +117,7 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
 }
 
 static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    io_timer tm(1);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
@@ -139,6 +151,7 @@ static bool mi_buffer_is_ours(ggml_backend_buffer_t buffer) { return buffer && b
 static bool mi_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * src, ggml_tensor * dst) {
     ggml_backend_buffer_t sbuf = src->view_src ? src->view_src->buffer : src->buffer;
     if (!mi_buffer_is_ours(sbuf)) return false;
+    io_timer tm(2);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     // same layout on both sides (ggml_are_same_layout is asserted by the caller) => raw bytes, planar included
@@ -756,6 +769,7 @@ static void mi_backend_free(ggml_backend_t backend) {
 }
 
 static void mi_backend_synchronize(ggml_backend_t backend) {
+    io_timer tm(3);
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     (void) hipSetDevice(b->device);
     mi355x_ctx_synchronize(b->k);
@@ -964,11 +978,13 @@ void ggml_backend_mi355x_stats(uint64_t * out) {
 }
 
 // out[0..3] = host milliseconds spent inside graph_compute: planning (graph walk + launch recording), hipGraph node
-// patching, hipGraphLaunch, eager launches — over all backends so far
+// patching, hipGraphLaunch, eager launches — over all backends so far; out[4..7] = milliseconds inside set_tensor,
+// get_tensor, cpy_tensor, synchronize; out[8..11] = their call counts
 void ggml_backend_mi355x_host_times(double * out) {
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     for (int i = 0; i < 4; i++) out[i] = g_total_host_ms[i];
     for (auto * b : g_backends) { out[0] += b->t_plan_ms; out[1] += b->t_patch_ms; out[2] += b->t_launch_ms; out[3] += b->t_eager_ms; }
+    for (int i = 0; i < 4; i++) { out[4 + i] = g_io_ns[i].load() * 1e-6; out[8 + i] = (double) g_io_calls[i].load(); }
 }
 
 int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {

@@ -41,7 +41,11 @@ struct DGArgs {
     const uint16_t * gelu_tab;
 };
 
-#define DG_U 5            // 32-element blocks per lane per chunk (8 lanes x 5 = 40 blocks = one K=1280 row)
+// LPR = lanes per weight row (8/16/32/64 => 8/4/2/1 rows per wave pass).  Decode mat-vecs are latency-bound: what counts
+// is how many waves have loads in flight right after launch, so small matrices use more lanes (= more waves) per row and
+// only the big ones (logits) use the 8-lane layout.  DG_U(LPR) = 32-element blocks per lane per chunk: LPR*DG_U blocks
+// cover a K = 1280 row in one chunk for every LPR and a K = 5120 row in one (LPR 64) to four (LPR 8) chunks.
+#define DG_U(LPR) ((LPR) == 8 ? 5 : 3)
 #define DG_XR 5           // float4 activation registers per thread in the "activations first" order
 
 static inline size_t dg_lds_bytes(int K, int T, bool staged) {
@@ -109,21 +113,22 @@ __device__ __forceinline__ void dg_q8_0_store(const float v[4], int e, int t, in
     if (w == 0) { dx[t*nb + b] = round_f16(d); sx[t*nb + b] = s; }
 }
 
-template <int WT, int T>
+template <int WT, int T, int LPR>
 __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
+    constexpr int U = DG_U(LPR), RPW = 64 / LPR;                      // blocks per lane per chunk, rows per wave pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int wave = tid >> 6, lane = tid & 63;
     const int K = a.K, nb = K >> 5;
-    const int r8 = lane >> 3, j8 = lane & 7;
+    const int r8 = lane / LPR, j8 = lane % LPR;
     const int ntot = a.row_start[a.nseg];
-    const int nchunks = (nb + 8*DG_U - 1) / (8*DG_U);
+    const int nchunks = (nb + LPR*U - 1) / (LPR*U);
     const int total = a.passes * nchunks;
     const int wg = blockIdx.x * nwaves + wave;
 
     // ---- per-lane row bookkeeping for pass p: returns weight base / block count of this lane's row ----
     auto row_of = [&](int pass, int & s, int & row) -> bool {
-        const int grow = (wg * a.passes + pass) * 8 + r8;
+        const int grow = (wg * a.passes + pass) * RPW + r8;
         s = 0;
         if (a.nseg > 1 && grow >= a.row_start[1]) s = 1;
         if (a.nseg > 2 && grow >= a.row_start[2]) s = 2;
@@ -136,8 +141,8 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
         const char * base = (const char *) (s == 0 ? a.seg[0].w : (s == 1 ? a.seg[1].w : a.seg[2].w));
         const int64_t nbt = s == 0 ? a.seg[0].nbt : (s == 1 ? a.seg[1].nbt : a.seg[2].nbt);
         #pragma unroll
-        for (int u = 0; u < DG_U; u++) {
-            const int g = j8 + 8*(c*DG_U + u);
+        for (int u = 0; u < U; u++) {
+            const int g = j8 + LPR*(c*U + u);
             wblk_load<WT>(r[u], base, nbt, (int64_t) row * nb + g, rok && g < nb);
         }
     };
@@ -156,7 +161,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
     // of weights (HBM misses) right behind them: the prologue then runs while the weights are still in flight.
     // xfirst: the whole activation fits DG_XR float4 registers per thread; otherwise the weights are requested first and
     // the activation streams through behind them.
-    wblk<WT> cur[DG_U], nxt[DG_U];
+    wblk<WT> cur[U], nxt[U];
     float4 xr[DG_XR];
     if (a.xfirst) {
         #pragma unroll
@@ -277,8 +282,8 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
         if (it + 1 < total) load_chunk(nxt, it + 1);
         const int pass = it / nchunks, c = it - pass*nchunks;
         #pragma unroll
-        for (int u = 0; u < DG_U; u++) {
-            const int g = j8 + 8*(c*DG_U + u);
+        for (int u = 0; u < U; u++) {
+            const int g = j8 + LPR*(c*U + u);
             if (g < nb) {
                 uint32_t vlo[4], vhi[4];
                 wblk_unpack<WT>(cur[u], vlo, vhi);
@@ -302,11 +307,12 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
             }
         }
         if (c == nchunks - 1) {
-            // reduce over the 8 lanes of the row, lane j8 == t finishes column t
+            // reduce over the LPR lanes of the row, lane j8 == t finishes column t
             #pragma unroll
             for (int t = 0; t < T; t++) {
                 float v = acc[t];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                #pragma unroll
+                for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
                 acc[t] = v;
             }
             float v = acc[0];
@@ -326,23 +332,32 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
             for (int t = 0; t < T; t++) acc[t] = 0.0f;
         }
         #pragma unroll
-        for (int u = 0; u < DG_U; u++) cur[u] = nxt[u];
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
     }
 }
 
-template <int WT>
+template <int WT, int LPR>
 static int launch_gemv8_T(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv";
     switch (T) {
-        case 1: return emit(ctx, name, k_gemv8<WT, 1>, grid, block, lds, k, bytes, flops);
-        case 2: return emit(ctx, name, k_gemv8<WT, 2>, grid, block, lds, k, bytes, flops);
-        case 3: return emit(ctx, name, k_gemv8<WT, 3>, grid, block, lds, k, bytes, flops);
-        case 4: return emit(ctx, name, k_gemv8<WT, 4>, grid, block, lds, k, bytes, flops);
-        case 5: return emit(ctx, name, k_gemv8<WT, 5>, grid, block, lds, k, bytes, flops);
-        case 6: return emit(ctx, name, k_gemv8<WT, 6>, grid, block, lds, k, bytes, flops);
-        case 7: return emit(ctx, name, k_gemv8<WT, 7>, grid, block, lds, k, bytes, flops);
-        case 8: return emit(ctx, name, k_gemv8<WT, 8>, grid, block, lds, k, bytes, flops);
+        case 1: return emit(ctx, name, k_gemv8<WT, 1, LPR>, grid, block, lds, k, bytes, flops);
+        case 2: return emit(ctx, name, k_gemv8<WT, 2, LPR>, grid, block, lds, k, bytes, flops);
+        case 3: return emit(ctx, name, k_gemv8<WT, 3, LPR>, grid, block, lds, k, bytes, flops);
+        case 4: return emit(ctx, name, k_gemv8<WT, 4, LPR>, grid, block, lds, k, bytes, flops);
+        case 5: return emit(ctx, name, k_gemv8<WT, 5, LPR>, grid, block, lds, k, bytes, flops);
+        case 6: return emit(ctx, name, k_gemv8<WT, 6, LPR>, grid, block, lds, k, bytes, flops);
+        case 7: return emit(ctx, name, k_gemv8<WT, 7, LPR>, grid, block, lds, k, bytes, flops);
+        case 8: return emit(ctx, name, k_gemv8<WT, 8, LPR>, grid, block, lds, k, bytes, flops);
         default: return MI355X_E_UNSUPPORTED;
+    }
+}
+template <int WT>
+static int launch_gemv8(mi355x_ctx * ctx, const DGArgs & k, int T, int lpr, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
+    switch (lpr) {
+        case 8:  return launch_gemv8_T<WT, 8>(ctx, k, T, grid, block, lds, bytes, flops);
+        case 16: return launch_gemv8_T<WT, 16>(ctx, k, T, grid, block, lds, bytes, flops);
+        case 32: return launch_gemv8_T<WT, 32>(ctx, k, T, grid, block, lds, bytes, flops);
+        default: return launch_gemv8_T<WT, 64>(ctx, k, T, grid, block, lds, bytes, flops);
     }
 }
 
@@ -381,19 +396,24 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         wbytes += (double) mi355x_type_row_bytes(wt, K) * g.N;
     }
     for (int s = d->nseg; s < 4; s++) k.row_start[s] = ntot;
-    // geometry: 8 rows per wave pass; ~8 waves per CU at most; 1, 2 or 4 waves per workgroup so that small matrices
-    // still spread over as many CUs as they have row groups (each workgroup repeats the activation prologue)
-    const int ngroups = (ntot + 7) / 8;
-    int passes = (ngroups + ctx->n_cu*8 - 1) / (ctx->n_cu*8);
-    if (passes < 1) passes = 1; if (passes > 16) passes = 16;
-    const int nw = (ngroups + passes - 1) / passes;
-    int wpb = nw >= ctx->n_cu*4 ? 4 : (nw >= ctx->n_cu*2 ? 2 : 1);
-    // tuning knobs (A/B on the GPU box): GGML_MI355X_GEMV_WPB = 1|2|4 forces the waves per workgroup,
-    // GGML_MI355X_GEMV_XFIRST=0 disables the activations-first load order
+    // geometry: latency-bound regime => as many waves as the matrix allows, up to ~16 per CU: lanes per row LPR such that
+    // N * LPR / 64 waves >= 8 per CU (but no more lanes than the row has blocks), 4 waves per workgroup (each workgroup
+    // repeats the activation prologue; 256 threads keep it short), several passes per wave only for huge N
+    static const int env_lpr = getenv("GGML_MI355X_GEMV_LPR") ? atoi(getenv("GGML_MI355X_GEMV_LPR")) : 0;
     static const int env_wpb = getenv("GGML_MI355X_GEMV_WPB") ? atoi(getenv("GGML_MI355X_GEMV_WPB")) : 0;
     static const int env_xfirst = getenv("GGML_MI355X_GEMV_XFIRST") ? atoi(getenv("GGML_MI355X_GEMV_XFIRST")) : 1;
+    static const int env_wpc = getenv("GGML_MI355X_GEMV_WAVES_PER_CU") ? atoi(getenv("GGML_MI355X_GEMV_WAVES_PER_CU")) : 8;
+    int lpr = 8;
+    while (lpr < 64 && (int64_t) ntot * lpr / 64 < (int64_t) ctx->n_cu * env_wpc) lpr *= 2;
+    while (lpr > 8 && lpr / 2 >= K / 32) lpr /= 2;
+    if (env_lpr == 8 || env_lpr == 16 || env_lpr == 32 || env_lpr == 64) lpr = env_lpr;
+    const int rpw = 64 / lpr;
+    const int ngroups = (ntot + rpw - 1) / rpw;
+    int passes = (ngroups + ctx->n_cu*32 - 1) / (ctx->n_cu*32);
+    if (passes < 1) passes = 1; if (passes > 16) passes = 16;
+    const int nw = (ngroups + passes - 1) / passes;
+    int wpb = 4;
     if (env_wpb == 1 || env_wpb == 2 || env_wpb == 4) wpb = env_wpb;
-    if (from_part && wpb < 2) wpb = 2;                     // the combine prologue wants threads (K/4 outputs x nparts loads)
     k.passes = passes;
     k.xfirst = (!from_part && env_xfirst && (int64_t) T * (K/4) <= (int64_t) DG_XR * 64 * wpb) ? 1 : 0;
     const int nblocks = (nw + wpb - 1) / wpb;
@@ -401,9 +421,9 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const double flops = 2.0 * ntot * K * T;
     const dim3 grid(nblocks), block(64*wpb);
     switch (wt) {
-        case MI355X_TYPE_Q4_0: return launch_gemv8_T<MI355X_TYPE_Q4_0>(ctx, k, T, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q5_0: return launch_gemv8_T<MI355X_TYPE_Q5_0>(ctx, k, T, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q8_0: return launch_gemv8_T<MI355X_TYPE_Q8_0>(ctx, k, T, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q4_0: return launch_gemv8<MI355X_TYPE_Q4_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q5_0: return launch_gemv8<MI355X_TYPE_Q5_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q8_0: return launch_gemv8<MI355X_TYPE_Q8_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
     }
     return MI355X_E_UNSUPPORTED;
 }
