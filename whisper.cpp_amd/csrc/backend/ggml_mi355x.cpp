@@ -74,6 +74,75 @@ struct io_timer {
 };
 
 // ---------------------------------------------------------------------------------------------------
+// small host <-> device transfers.  The scheduler copies the graph inputs (token ids, positions, mask) into our buffers
+// before EVERY decode step (ggml-backend.cpp:1625-1632) and whisper reads one logits row back after it (W:2957-2963).
+// A synchronous hipMemcpy from pageable memory costs ~50 us per call; these go through a pinned ring buffer and an
+// upload stream instead: set_tensor returns as soon as the copy is enqueued (the source has been copied into the ring, so
+// the caller may reuse it), compute streams wait on the upload event, every other reader drains the upload stream first.
+// ---------------------------------------------------------------------------------------------------
+struct mi_io_ctx {
+    std::mutex  mtx;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev = nullptr;
+    char *      pinned = nullptr;
+    size_t      cap = 0, off = 0;
+    std::atomic<uint64_t> seq{0};          // number of uploads enqueued so far
+    std::atomic<uint64_t> drained{0};      // uploads known to be complete
+    bool        ok = false, tried = false;
+};
+static mi_io_ctx g_io[MI_MAX_DEVICES];
+#define MI_IO_SMALL (256u << 10)
+
+static mi_io_ctx * mi_io(int device) {          // caller holds no lock; device already current
+    mi_io_ctx & io = g_io[device];
+    std::lock_guard<std::mutex> lk(io.mtx);
+    if (!io.tried) {
+        io.tried = true;
+        static const bool enabled = env_flag("GGML_MI355X_ASYNC_IO", true);
+        io.cap = (size_t) 4 << 20;
+        if (enabled && hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&io.ev, hipEventDisableTiming) == hipSuccess &&
+            hipHostMalloc((void **) &io.pinned, io.cap, hipHostMallocDefault) == hipSuccess) io.ok = true;
+    }
+    return io.ok ? &io : nullptr;
+}
+// wait until every enqueued upload has landed (readers other than the compute streams)
+static void mi_io_drain(int device) {
+    mi_io_ctx & io = g_io[device];
+    if (!io.ok || io.drained.load() == io.seq.load()) return;
+    std::lock_guard<std::mutex> lk(io.mtx);
+    const uint64_t s = io.seq.load();
+    (void) hipStreamSynchronize(io.stream);
+    io.drained.store(s); io.off = 0;
+}
+static bool mi_io_upload(int device, void * dst, const void * src, size_t size) {
+    mi_io_ctx * io = mi_io(device);
+    if (!io) return false;
+    std::lock_guard<std::mutex> lk(io->mtx);
+    const size_t need = (size + 255) & ~(size_t) 255;
+    if (io->off + need > io->cap) { (void) hipStreamSynchronize(io->stream); io->drained.store(io->seq.load()); io->off = 0; }
+    memcpy(io->pinned + io->off, src, size);
+    if (hipMemcpyAsync(dst, io->pinned + io->off, size, hipMemcpyHostToDevice, io->stream) != hipSuccess) return false;
+    io->off += need;
+    (void) hipEventRecord(io->ev, io->stream);
+    io->seq++;
+    return true;
+}
+static bool mi_io_download(int device, void * dst, const void * src, size_t size) {
+    mi_io_ctx * io = mi_io(device);
+    if (!io || size > io->cap / 2) return false;
+    std::lock_guard<std::mutex> lk(io->mtx);
+    // the ring is used from its upper half for downloads after draining the stream (uploads in flight keep the lower part)
+    (void) hipStreamSynchronize(io->stream);
+    io->drained.store(io->seq.load()); io->off = 0;
+    char * stage = io->pinned + io->cap / 2;
+    if (hipMemcpyAsync(stage, src, size, hipMemcpyDeviceToHost, io->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(io->stream) != hipSuccess) return false;
+    memcpy(dst, stage, size);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // buffer
 // ---------------------------------------------------------------------------------------------------
 static void mi_buffer_free(ggml_backend_buffer_t buffer) {
@@ -83,6 +152,7 @@ static void mi_buffer_free(ggml_backend_buffer_t buffer) {
         for (size_t i = 0; i < g_buffers.size(); i++) if (g_buffers[i].base == ctx->base) { g_buffers.erase(g_buffers.begin() + i); break; }
     }
     (void) hipSetDevice(ctx->device);
+    mi_io_drain(ctx->device);
     (void) hipDeviceSynchronize();
     (void) hipFree(ctx->base);
     delete ctx;
@@ -97,6 +167,7 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
+        mi_io_drain(ctx->device);
         const size_t nbytes = ggml_nbytes(tensor);
         std::vector<uint8_t> planar(nbytes);
         if (offset == 0 && size == nbytes) {
@@ -112,6 +183,8 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
         if (e != hipSuccess) GGML_LOG_ERROR("ggml-mi355x: set_tensor failed: %s\n", hipGetErrorString(e));
         return;
     }
+    if (size <= MI_IO_SMALL && mi_io_upload(ctx->device, (char *) tensor->data + offset, data, size)) return;
+    mi_io_drain(ctx->device);
     hipError_t e = hipMemcpy((char *) tensor->data + offset, data, size, hipMemcpyHostToDevice);
     if (e != hipSuccess) GGML_LOG_ERROR("ggml-mi355x: set_tensor failed: %s\n", hipGetErrorString(e));
 }
@@ -120,6 +193,7 @@ static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
     io_timer tm(1);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
+    mi_io_drain(ctx->device);
     if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
         const size_t nbytes = ggml_nbytes(tensor);
         std::vector<uint8_t> planar(nbytes), blocks(nbytes);
@@ -128,6 +202,7 @@ static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
         memcpy(data, blocks.data() + offset, size);
         return;
     }
+    if (size >= 4096 && mi_io_download(ctx->device, data, (const char *) tensor->data + offset, size)) return;
     hipError_t e = hipMemcpy(data, (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost);
     if (e != hipSuccess) GGML_LOG_ERROR("ggml-mi355x: get_tensor failed: %s\n", hipGetErrorString(e));
 }
@@ -135,6 +210,7 @@ static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
 static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
+    mi_io_drain(ctx->device);
     (void) hipMemset((char *) tensor->data + offset, value, size);
     (void) hipDeviceSynchronize();
 }
@@ -142,6 +218,7 @@ static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * 
 static void mi_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
+    mi_io_drain(ctx->device);
     (void) hipMemset(ctx->base, value, ctx->size);
     (void) hipDeviceSynchronize();
 }
@@ -154,6 +231,7 @@ static bool mi_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
     io_timer tm(2);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
+    mi_io_drain(ctx->device);
     // same layout on both sides (ggml_are_same_layout is asserted by the caller) => raw bytes, planar included
     hipError_t e = hipMemcpy(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice);
     (void) hipDeviceSynchronize();
@@ -232,6 +310,7 @@ struct mi_backend_ctx {
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
     // hipGraph replay, keyed by number of launches (decoder step / encoder graphs differ in length)
     std::vector<mi_graph_cache> gcache;
+    uint64_t io_seen = 0;                                       // uploads (mi_io_ctx::seq) this stream already waits behind
     uint64_t n_graph_compute = 0, n_replay = 0, n_update = 0, n_rebuild = 0;
     bool     recording = false, record_abort = false;
     double   t_plan_ms = 0, t_patch_ms = 0, t_launch_ms = 0, t_eager_ms = 0;    // host time inside graph_compute
@@ -779,6 +858,15 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     if (hipSetDevice(b->device) != hipSuccess) return GGML_STATUS_FAILED;
     b->n_graph_compute++;
+    {   // order this stream behind every input upload enqueued so far
+        mi_io_ctx & io = g_io[b->device];
+        const uint64_t seq = io.ok ? io.seq.load() : 0;
+        if (seq != b->io_seen) {
+            std::lock_guard<std::mutex> lk(io.mtx);
+            (void) hipStreamWaitEvent((hipStream_t) mi355x_ctx_stream(b->k), io.ev, 0);
+            b->io_seen = io.seq.load();
+        }
+    }
     // graphs pay off when the launch sequence is long and launch-bound (decoder step); profiling needs eager launches
     const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32;
     if (use_graph) {

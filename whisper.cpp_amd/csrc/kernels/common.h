@@ -114,21 +114,78 @@ __device__ __forceinline__ float h2f(uint16_t h) { half_t x; __builtin_memcpy(&x
 __device__ __forceinline__ uint16_t f2h(float f) { half_t x = (half_t) f; uint16_t h; __builtin_memcpy(&h, &x, 2); return h; }
 __device__ __forceinline__ float round_f16(float f) { return (float) (half_t) f; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-    #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane exchange on the VALU (no LDS crossbar): DPP inside a 16-lane row, v_permlane{16,32}_swap across rows.
+// dpp_x<CTRL>(v) returns v of the partner lane: 0xB1 = quad_perm[1,0,3,2] (lane^1), 0x4E = quad_perm[2,3,0,1] (lane^2),
+// 0x141 = row_half_mirror (i <-> 7-i), 0x140 = row_mirror (i <-> 15-i).  In a butterfly reduction the mirror partners
+// hold the same partial result as the xor-4 / xor-8 partners would, so the sums are bit-identical to a __shfl_xor
+// butterfly at a fraction of its latency (a ds_bpermute round trip per step).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ float dpp_x(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int dpp_xi(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// value of lane^16 / lane^32
+__device__ __forceinline__ float lane_xor16(float v) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0] ^ r[1] ^ __float_as_uint(v));       // {own, partner} in some order: xor out the own value
+}
+__device__ __forceinline__ float lane_xor32(float v) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0] ^ r[1] ^ __float_as_uint(v));
+}
+__device__ __forceinline__ int lane_xor16_i(int v) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap((unsigned) v, (unsigned) v, false, false);
+    return (int) (r[0] ^ r[1] ^ (unsigned) v);
+}
+__device__ __forceinline__ int lane_xor32_i(int v) {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap((unsigned) v, (unsigned) v, false, false);
+    return (int) (r[0] ^ r[1] ^ (unsigned) v);
+}
+// reductions over aligned groups of G lanes (G = 2..64), result in every lane of the group
+template <int G> __device__ __forceinline__ float group_sum(float v) {
+    if (G >= 2)  v += dpp_x<0xB1>(v);
+    if (G >= 4)  v += dpp_x<0x4E>(v);
+    if (G >= 8)  v += dpp_x<0x141>(v);
+    if (G >= 16) v += dpp_x<0x140>(v);
+    // after the swap the two results are {own row's value, partner row's value} in some order: add both
+    if (G >= 32) { const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    if (G >= 64) { const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-    #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+template <int G> __device__ __forceinline__ float group_max(float v) {
+    if (G >= 2)  v = fmaxf(v, dpp_x<0xB1>(v));
+    if (G >= 4)  v = fmaxf(v, dpp_x<0x4E>(v));
+    if (G >= 8)  v = fmaxf(v, dpp_x<0x141>(v));
+    if (G >= 16) v = fmaxf(v, dpp_x<0x140>(v));
+    if (G >= 32) { const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    if (G >= 64) { const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
     return v;
 }
-__device__ __forceinline__ int wave_sum_i(int v) {
-    #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+template <int G> __device__ __forceinline__ int group_sum_i(int v) {
+    if (G >= 2)  v += dpp_xi<0xB1>(v);
+    if (G >= 4)  v += dpp_xi<0x4E>(v);
+    if (G >= 8)  v += dpp_xi<0x141>(v);
+    if (G >= 16) v += dpp_xi<0x140>(v);
+    if (G >= 32) { const u32x2_t r = __builtin_amdgcn_permlane16_swap((unsigned) v, (unsigned) v, false, false); v = (int) (r[0] + r[1]); }
+    if (G >= 64) { const u32x2_t r = __builtin_amdgcn_permlane32_swap((unsigned) v, (unsigned) v, false, false); v = (int) (r[0] + r[1]); }
     return v;
 }
+// sum / max over the 8 lanes that share (lane & 7): lane^8 (row_ror:8), lane^16, lane^32
+__device__ __forceinline__ float stride8_sum(float v) {
+    v += dpp_x<0x128>(v);
+    { const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    { const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+    return v;
+}
+__device__ __forceinline__ float stride8_max(float v) {
+    v = fmaxf(v, dpp_x<0x128>(v));
+    { const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    { const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])); }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
+__device__ __forceinline__ int wave_sum_i(int v) { return group_sum_i<64>(v); }
 
 // spread the low 4 bits of b to bit 4 of each byte of a dword: bit k -> byte k, bit 4
 __device__ __forceinline__ uint32_t spread4_to_bit4(uint32_t b) {

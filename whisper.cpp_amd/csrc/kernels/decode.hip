@@ -98,14 +98,11 @@ __device__ __forceinline__ void wblk_unpack(const wblk<WT> & r, uint32_t vlo[4],
 // quantize 4 consecutive values (one lane of an 8-lane group = one 32-block) to Q8_0 and store to LDS
 __device__ __forceinline__ void dg_q8_0_store(const float v[4], int e, int t, int nb, uint32_t * lo, uint32_t * hi, float * dx, int * sx) {
     float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-    amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+    amax = group_max<8>(amax);
     const float d  = amax / 127.0f;
     const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
     const int q0 = (int) rintf(v[0]*id), q1 = (int) rintf(v[1]*id), q2 = (int) rintf(v[2]*id), q3 = (int) rintf(v[3]*id);
-    int s = q0 + q1 + q2 + q3;
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    int s = group_sum_i<8>(q0 + q1 + q2 + q3);
     const uint32_t packed = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
     const int b = e >> 5, w = (e & 31) >> 2;
     uint32_t * plane = w < 4 ? lo : hi;
@@ -310,10 +307,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
             // reduce over the LPR lanes of the row, lane j8 == t finishes column t
             #pragma unroll
             for (int t = 0; t < T; t++) {
-                float v = acc[t];
-                #pragma unroll
-                for (int o = 1; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
-                acc[t] = v;
+                acc[t] = group_sum<LPR>(acc[t]);
             }
             float v = acc[0];
             #pragma unroll
@@ -361,6 +355,209 @@ static int launch_gemv8(mi355x_ctx * ctx, const DGArgs & k, int T, int lpr, dim3
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// k_gemv_row: the lean mat-vec for the per-layer projections (N <= 8192 rows): ONE weight row per wave, 4 rows per
+// workgroup, so a 1280-row matrix puts 1280 waves' loads in flight right after launch.  Everything that depends on the
+// row is wave-uniform (scalar); activations are held in registers from load to quantization (no staging, no integer
+// division, three barriers with LayerNorm, one without); all cross-lane traffic is DPP / permlane.
+// ---------------------------------------------------------------------------------------------------
+template <int WT, int T, int XS>                                        // XS = float4 activation slots per column per thread (K <= XS*1024)
+__global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int K = a.K, nb = K >> 5, K4 = K >> 2;
+    const int ntot = a.row_start[a.nseg];
+    const int grow = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    int s = 0;
+    if (a.nseg > 1 && grow >= a.row_start[1]) s = 1;
+    if (a.nseg > 2 && grow >= a.row_start[2]) s = 2;
+    const bool rok = grow < ntot;
+    const int row = grow - a.row_start[s];
+    const DGSeg & sg = a.seg[s];
+
+    // ---- 1. activation loads (L2 hits) first, 2. weight loads (HBM) right behind them ----
+    float4 xr[T][XS];
+    if (a.x != nullptr) {
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            const char * xp = (const char *) a.x + (int64_t) t*a.x_nb1;
+            #pragma unroll
+            for (int i = 0; i < XS; i++) {
+                const int e4 = tid + i*256;
+                xr[t][i] = e4 < K4 ? *(const float4 *) (xp + (size_t) e4*16) : make_float4(0, 0, 0, 0);
+            }
+        }
+    }
+    wblk<WT> wr[3];
+    {
+        const char * base = (const char *) sg.w;
+        const int64_t nbt = sg.nbt;
+        const int ib0 = row * nb;
+        #pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int g = lane + 64*u;
+            wblk_load<WT>(wr[u], base, nbt, (int64_t) (ib0 + g), rok && g < nb);
+        }
+    }
+    float * red = (float *) smem;                                       // [2][T][4]
+    uint32_t * lo = (uint32_t *) (smem + 256);
+    uint32_t * hi = lo + (size_t) T*nb*4;
+    float * dx = (float *) (hi + (size_t) T*nb*4);
+    int *   sx = (int *) (dx + T*nb);
+
+    if (a.x == nullptr) {
+        // activations = combine of the attention partial records (see k_gemv8)
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            #pragma unroll
+            for (int i = 0; i < XS; i++) {
+                const int e4 = tid + i*256;
+                float4 o = make_float4(0, 0, 0, 0);
+                if (e4 < K4) {
+                    const int h = e4 >> 4, d = (e4 & 15) << 2;
+                    const int64_t base = ((int64_t) h*T + t) * a.nparts;
+                    float M = -1e30f;
+                    for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
+                    float L = 0.0f;
+                    for (int p = 0; p < a.nparts; p++) {
+                        const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
+                        const float w = __expf(ml.x - M);
+                        const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + d);
+                        L = fmaf(w, ml.y, L);
+                        o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
+                    }
+                    const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+                    o = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
+                }
+                xr[t][i] = o;
+            }
+        }
+    }
+    if (a.has_norm) {
+        // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine, two passes over the registers
+        float mean[T], rstd[T];
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            float p = 0.0f;
+            #pragma unroll
+            for (int i = 0; i < XS; i++) p += (xr[t][i].x + xr[t][i].y) + (xr[t][i].z + xr[t][i].w);     // slots beyond K hold zeros
+            p = wave_sum(p);
+            if (lane == 0) red[t*4 + wave] = p;
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            const float4 r = *(const float4 *) (red + t*4);
+            mean[t] = ((r.x + r.y) + (r.z + r.w)) / K;
+            float p = 0.0f;
+            #pragma unroll
+            for (int i = 0; i < XS; i++) {
+                if (tid + i*256 < K4) {
+                    const float d0 = xr[t][i].x - mean[t], d1 = xr[t][i].y - mean[t], d2 = xr[t][i].z - mean[t], d3 = xr[t][i].w - mean[t];
+                    p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+                }
+            }
+            p = wave_sum(p);
+            if (lane == 0) red[T*4 + t*4 + wave] = p;
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            const float4 r = *(const float4 *) (red + T*4 + t*4);
+            rstd[t] = 1.0f / sqrtf(((r.x + r.y) + (r.z + r.w)) / K + a.eps);
+            #pragma unroll
+            for (int i = 0; i < XS; i++) {
+                const int e4 = tid + i*256;
+                if (e4 < K4) {
+                    const float4 w = *(const float4 *) (a.ln_w + e4*4);
+                    const float4 b = *(const float4 *) (a.ln_b + e4*4);
+                    float o[4] = { (xr[t][i].x - mean[t]) * rstd[t], (xr[t][i].y - mean[t]) * rstd[t], (xr[t][i].z - mean[t]) * rstd[t], (xr[t][i].w - mean[t]) * rstd[t] };
+                    o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
+                    o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
+                    dg_q8_0_store(o, e4*4, t, nb, lo, hi, dx, sx);
+                }
+            }
+        }
+    } else {
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            #pragma unroll
+            for (int i = 0; i < XS; i++) {
+                const int e4 = tid + i*256;
+                if (e4 < K4) {
+                    const float v[4] = { xr[t][i].x, xr[t][i].y, xr[t][i].z, xr[t][i].w };
+                    dg_q8_0_store(v, e4*4, t, nb, lo, hi, dx, sx);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- dot products: lane handles blocks lane, lane+64, lane+128 of the wave's row ----
+    const uint4 * alo = (const uint4 *) lo;
+    const uint4 * ahi = (const uint4 *) hi;
+    float acc[T];
+    #pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = 0.0f;
+    #pragma unroll
+    for (int u = 0; u < 3; u++) {
+        const int g = lane + 64*u;
+        if (g < nb) {
+            uint32_t vlo[4], vhi[4];
+            wblk_unpack<WT>(wr[u], vlo, vhi);
+            const float dw = h2f(wr[u].d);
+            constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+            #pragma unroll
+            for (int t = 0; t < T; t++) {
+                const uint4 al = alo[(size_t) t*nb + g], ah = ahi[(size_t) t*nb + g];
+                int sum = 0;
+                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
+                if (off) sum -= off * sx[t*nb + g];
+                acc[t] = fmaf(dw * dx[t*nb + g], (float) sum, acc[t]);
+            }
+        }
+    }
+    #pragma unroll
+    for (int t = 0; t < T; t++) acc[t] = wave_sum(acc[t]);
+    float v = acc[0];
+    #pragma unroll
+    for (int t = 1; t < T; t++) v = (lane == t) ? acc[t] : v;
+    if (rok && lane < T) {
+        if (sg.bias)      v = v + sg.bias[row];
+        if (sg.has_scale) v = v * sg.scale;
+        if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
+        if (sg.residual)  v = v + *(const float *) ((const char *) sg.residual + (int64_t) lane*sg.res_nb1 + (int64_t) row*4);
+        char * dp = (char *) sg.dst + (int64_t) lane*sg.dst_nb1;
+        if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
+    }
+}
+
+template <int WT>
+static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
+    const char * name = "gemv";
+    const dim3 block(256);
+    if (k.K > 2048) return T == 1 ? emit(ctx, name, k_gemv_row<WT, 1, 5>, grid, block, lds, k, bytes, flops) : MI355X_E_UNSUPPORTED;
+    switch (T) {
+        case 1: return emit(ctx, name, k_gemv_row<WT, 1, 2>, grid, block, lds, k, bytes, flops);
+        case 2: return emit(ctx, name, k_gemv_row<WT, 2, 2>, grid, block, lds, k, bytes, flops);
+        case 3: return emit(ctx, name, k_gemv_row<WT, 3, 2>, grid, block, lds, k, bytes, flops);
+        case 4: return emit(ctx, name, k_gemv_row<WT, 4, 2>, grid, block, lds, k, bytes, flops);
+        case 5: return emit(ctx, name, k_gemv_row<WT, 5, 2>, grid, block, lds, k, bytes, flops);
+        case 6: return emit(ctx, name, k_gemv_row<WT, 6, 2>, grid, block, lds, k, bytes, flops);
+        case 7: return emit(ctx, name, k_gemv_row<WT, 7, 2>, grid, block, lds, k, bytes, flops);
+        case 8: return emit(ctx, name, k_gemv_row<WT, 8, 2>, grid, block, lds, k, bytes, flops);
+        default: return MI355X_E_UNSUPPORTED;
+    }
+}
+
 // second-generation entry: returns MI355X_E_UNSUPPORTED for anything it does not cover (caller falls back to k_gemv)
 int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
@@ -374,8 +571,6 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (d->has_norm && (!d->ln_w || !d->ln_b || ((uintptr_t) d->ln_w % 16) || ((uintptr_t) d->ln_b % 16))) return MI355X_E_UNSUPPORTED;
     const bool staged = from_part || d->has_norm;
     const size_t lds = dg_lds_bytes(K, T, staged);
-    if (lds > 64*1024) return MI355X_E_UNSUPPORTED;
-    if (staged && ((size_t) T * (K/32) * 40) % 16) return MI355X_E_UNSUPPORTED;      // float4 alignment of the staging area
 
     DGArgs k; memset(&k, 0, sizeof(k));
     k.x = from_part ? nullptr : d->x; k.x_nb1 = d->x_nb1; k.K = K; k.has_norm = d->has_norm; k.eps = d->eps; k.nseg = d->nseg;
@@ -396,6 +591,20 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         wbytes += (double) mi355x_type_row_bytes(wt, K) * g.N;
     }
     for (int s = d->nseg; s < 4; s++) k.row_start[s] = ntot;
+    const double bytes0 = wbytes + (double) K*T*4 + (double) ntot*T*4;
+    const double flops0 = 2.0 * ntot * K * T;
+    static const int env_lean = getenv("GGML_MI355X_GEMV_LEAN") ? atoi(getenv("GGML_MI355X_GEMV_LEAN")) : 1;
+    if (env_lean && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
+        const size_t lds_row = dg_lds_bytes(K, T, false);
+        const dim3 grid((ntot + 3) / 4);
+        switch (wt) {
+            case MI355X_TYPE_Q4_0: return launch_gemv_row<MI355X_TYPE_Q4_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0);
+            case MI355X_TYPE_Q5_0: return launch_gemv_row<MI355X_TYPE_Q5_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0);
+            case MI355X_TYPE_Q8_0: return launch_gemv_row<MI355X_TYPE_Q8_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0);
+        }
+    }
+    if (lds > 64*1024) return MI355X_E_UNSUPPORTED;
+    if (staged && ((size_t) T * (K/32) * 40) % 16) return MI355X_E_UNSUPPORTED;      // float4 alignment of the staging area
     // geometry: latency-bound regime => as many waves as the matrix allows, up to ~16 per CU: lanes per row LPR such that
     // N * LPR / 64 waves >= 8 per CU (but no more lanes than the row has blocks), 4 waves per workgroup (each workgroup
     // repeats the activation prologue; 256 threads keep it short), several passes per wave only for huge N
@@ -483,7 +692,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
             float s = 0.0f;
             #pragma unroll
             for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[t][e], s);
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+            s = group_sum<8>(s);
             float x = s * a.scale;
             if (a.has_mask && key < a.n_kv) x += h2f(*(const uint16_t *) (a.m.data + (int64_t) t*a.m.nb[1] + (int64_t) key*2));
             sc[t][i] = key < a.n_kv ? x : -INFINITY;
@@ -492,7 +701,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     #pragma unroll
     for (int t = 0; t < T; t++) {
         float m = fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3]));
-        m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = stride8_max(m);
         m = fmaxf(m, -1e30f);
         float l = 0.0f, o[8];
         #pragma unroll
@@ -509,9 +718,9 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
             }
         }
         // sum over the 8 key groups (lanes with equal dc)
-        l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+        l = stride8_sum(l);
         #pragma unroll
-        for (int e = 0; e < 8; e++) { float v = o[e]; v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); o[e] = v; }
+        for (int e = 0; e < 8; e++) o[e] = stride8_sum(o[e]);
         if (kg == 0) {
             *(float4 *) &wo[wave][t][dc*8]     = make_float4(o[0], o[1], o[2], o[3]);
             *(float4 *) &wo[wave][t][dc*8 + 4] = make_float4(o[4], o[5], o[6], o[7]);
