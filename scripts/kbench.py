@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--qtype", default="q5_0")
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--T", type=int, default=1)
+    ap.add_argument("--cycle", action="store_true", help="add the cache-level experiment (needs ~0.6 GB)")
     a = ap.parse_args()
     import torch
     tid = ka.TYPE_NAMES[a.qtype]
@@ -67,6 +68,28 @@ def main():
     gemv_case("ln+fc1 1280->5120 gelu", n, [4 * n], True, x, gelu=1)
     gemv_case("fc2 5120->1280 +res", 4 * n, [n], False, x4, resid=True)
     gemv_case("ln+logits 1280->51866", n, [51866], True, x)
+
+    # cache-level experiment: the same O-projection over `copies` distinct weight matrices visited round-robin
+    # (1: L2-hot, 16: 18 MB = L2-resident, 64: 72 MB = Infinity-Cache-resident, 400: 450 MB = HBM-cold)
+    if a.cycle:
+        for copies in (1, 16, 64, 400):
+            ws = [wq(n, n) for _ in range(copies)]
+            y = torch.zeros((T, n), device="cuda:0")
+            descs = []
+            for w_ in ws:
+                d = ka.GemvDesc()
+                d.x, d.x_nb1, d.K, d.T, d.has_norm, d.eps = x.data_ptr(), n * 4, n, T, 0, 1e-5
+                d.nseg = 1
+                d.seg[0].w, d.seg[0].wtype, d.seg[0].N = w_.data_ptr(), tid, n
+                d.seg[0].dst, d.seg[0].dst_type, d.seg[0].dst_nb1 = y.data_ptr(), ka.F32, n * 4
+                descs.append(d)
+            state = {"i": 0}
+
+            def cyc(descs=descs, state=state):
+                d = descs[state["i"] % len(descs)]
+                state["i"] += 1
+                return L.mi355x_gemv_fused(ctx.h, C.byref(d))
+            cases[f"oproj cycle x{copies}"] = (cyc, (ws, y, descs), n * ka.row_bytes(tid, n))
 
     H, D = 20, 64
     for nm, n_kv in (("xattn kv1536", 1536), ("self kv64", 64), ("self kv300", 300)):
@@ -108,18 +131,22 @@ def main():
         ctx.sync()
         if rc:
             continue
+        iters = a.iters if "cycle" not in name else max(a.iters, 2 * int(name.split("x")[-1]))
+        for _ in range(iters if "cycle" in name else 0):      # one full pass first: page-table / first-touch effects out of the way
+            fn()
+        ctx.sync()
         ctx.prof(True)
         ctx.prof_reset()
-        for _ in range(a.iters):
+        for _ in range(iters):
             fn()
         rows = ctx.prof_report()
         ctx.prof(False)
         tot = sum(r["total_ms"] for r in rows)
-        out.append({"case": name, "us_per_call_events": round(tot * 1e3 / a.iters, 2), "algo_MB": round(nbytes / 1e6, 3),
-                    "GBps": round(nbytes / (tot * 1e-3 / a.iters) / 1e9, 1) if tot else None,
+        out.append({"case": name, "us_per_call_events": round(tot * 1e3 / iters, 2), "algo_MB": round(nbytes / 1e6, 3),
+                    "GBps": round(nbytes / (tot * 1e-3 / iters) / 1e9, 1) if tot else None,
                     "kernels": {r["name"]: round(r["total_ms"] * 1e3 / max(r["calls"], 1), 2) for r in rows}})
         # the same launches without event bracketing (what rocprofv3 sees as back-to-back dispatches)
-        for _ in range(a.iters):
+        for _ in range(iters):
             fn()
         ctx.sync()
     print(json.dumps({"qtype": a.qtype, "T": T, "iters": a.iters, "cases": out}, indent=1))

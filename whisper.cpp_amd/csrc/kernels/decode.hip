@@ -389,6 +389,23 @@ __global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
             }
         }
     }
+    // every other load that does not depend on computed data is requested NOW as well: the per-layer LayerNorm vectors,
+    // bias and residual are cold in HBM on every decode step (the model is swept once per token), and a cold miss in the
+    // middle of the barrier chain costs about a microsecond each
+    float4 lw[XS], lb[XS];
+    if (a.has_norm) {
+        #pragma unroll
+        for (int i = 0; i < XS; i++) {
+            const int e4 = tid + i*256;
+            lw[i] = e4 < K4 ? *(const float4 *) (a.ln_w + e4*4) : make_float4(0, 0, 0, 0);
+            lb[i] = e4 < K4 ? *(const float4 *) (a.ln_b + e4*4) : make_float4(0, 0, 0, 0);
+        }
+    }
+    float bias_v = 0.0f, res_v = 0.0f;
+    if (rok && lane < T) {
+        if (sg.bias)     bias_v = sg.bias[row];
+        if (sg.residual) res_v  = *(const float *) ((const char *) sg.residual + (int64_t) lane*sg.res_nb1 + (int64_t) row*4);
+    }
     wblk<WT> wr[3];
     {
         const char * base = (const char *) sg.w;
@@ -417,15 +434,34 @@ __global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
                 if (e4 < K4) {
                     const int h = e4 >> 4, d = (e4 & 15) << 2;
                     const int64_t base = ((int64_t) h*T + t) * a.nparts;
-                    float M = -1e30f;
-                    for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
-                    float L = 0.0f;
-                    for (int p = 0; p < a.nparts; p++) {
-                        const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
-                        const float w = __expf(ml.x - M);
-                        const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + d);
-                        L = fmaf(w, ml.y, L);
-                        o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
+                    float M = -1e30f, L = 0.0f;
+                    if (a.nparts <= 12) {
+                        // all records requested at once (one miss latency instead of two dependent passes); absent
+                        // records are neutral: m = -1e30 -> weight exp(-1e30 - M) = 0
+                        float2 ml[12]; float4 ov[12];
+                        #pragma unroll
+                        for (int p = 0; p < 12; p++) {
+                            const bool ok = p < a.nparts;
+                            ml[p] = ok ? *(const float2 *) (a.part_ml + (base + p)*2) : make_float2(-1e30f, 0.0f);
+                            ov[p] = ok ? *(const float4 *) (a.part_o + (base + p)*64 + d) : make_float4(0, 0, 0, 0);
+                        }
+                        #pragma unroll
+                        for (int p = 0; p < 12; p++) M = fmaxf(M, ml[p].x);
+                        #pragma unroll
+                        for (int p = 0; p < 12; p++) {
+                            const float w = p < a.nparts ? __expf(ml[p].x - M) : 0.0f;
+                            L = fmaf(w, ml[p].y, L);
+                            o.x = fmaf(w, ov[p].x, o.x); o.y = fmaf(w, ov[p].y, o.y); o.z = fmaf(w, ov[p].z, o.z); o.w = fmaf(w, ov[p].w, o.w);
+                        }
+                    } else {
+                        for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
+                        for (int p = 0; p < a.nparts; p++) {
+                            const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
+                            const float w = __expf(ml.x - M);
+                            const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + d);
+                            L = fmaf(w, ml.y, L);
+                            o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
+                        }
                     }
                     const float inv = L == 0.0f ? 0.0f : 1.0f / L;
                     o = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
@@ -470,8 +506,7 @@ __global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
             for (int i = 0; i < XS; i++) {
                 const int e4 = tid + i*256;
                 if (e4 < K4) {
-                    const float4 w = *(const float4 *) (a.ln_w + e4*4);
-                    const float4 b = *(const float4 *) (a.ln_b + e4*4);
+                    const float4 w = lw[i], b = lb[i];
                     float o[4] = { (xr[t][i].x - mean[t]) * rstd[t], (xr[t][i].y - mean[t]) * rstd[t], (xr[t][i].z - mean[t]) * rstd[t], (xr[t][i].w - mean[t]) * rstd[t] };
                     o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
                     o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
@@ -531,10 +566,10 @@ __global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
     #pragma unroll
     for (int t = 1; t < T; t++) v = (lane == t) ? acc[t] : v;
     if (rok && lane < T) {
-        if (sg.bias)      v = v + sg.bias[row];
+        if (sg.bias)      v = v + bias_v;
         if (sg.has_scale) v = v * sg.scale;
         if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
-        if (sg.residual)  v = v + *(const float *) ((const char *) sg.residual + (int64_t) lane*sg.res_nb1 + (int64_t) row*4);
+        if (sg.residual)  v = v + res_v;
         char * dp = (char *) sg.dst + (int64_t) lane*sg.dst_nb1;
         if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
     }
@@ -679,6 +714,16 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
         qf[t][0] = round_f16(q0.x); qf[t][1] = round_f16(q0.y); qf[t][2] = round_f16(q0.z); qf[t][3] = round_f16(q0.w);
         qf[t][4] = round_f16(q1.x); qf[t][5] = round_f16(q1.y); qf[t][6] = round_f16(q1.z); qf[t][7] = round_f16(q1.w);
     }
+    // mask values of this lane's keys: requested together with everything else (a dependent load later would be a
+    // serialized miss: the mask was written by the preceding cast kernel, on another XCD)
+    float mk[T][4];
+    #pragma unroll
+    for (int t = 0; t < T; t++)
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int key = kbeg + kg + 8*i;
+            mk[t][i] = (a.has_mask && key < a.n_kv) ? h2f(*(const uint16_t *) (a.m.data + (int64_t) t*a.m.nb[1] + (int64_t) key*2)) : 0.0f;
+        }
     float sc[T][4];
     #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -693,8 +738,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
             #pragma unroll
             for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[t][e], s);
             s = group_sum<8>(s);
-            float x = s * a.scale;
-            if (a.has_mask && key < a.n_kv) x += h2f(*(const uint16_t *) (a.m.data + (int64_t) t*a.m.nb[1] + (int64_t) key*2));
+            const float x = s * a.scale + mk[t][i];
             sc[t][i] = key < a.n_kv ? x : -INFINITY;
         }
     }
