@@ -91,6 +91,22 @@ def main():
                 return L.mi355x_gemv_fused(ctx.h, C.byref(d))
             cases[f"oproj cycle x{copies}"] = (cyc, (ws, y, descs), n * ka.row_bytes(tid, n))
 
+    # producer -> consumer: the activation vector is (re)written by a preceding kernel on the same stream, as in the decode graph
+    if a.cycle:
+        wp = wq(n, n)
+        x2 = torch.zeros((T, n), device="cuda:0")
+        yp = torch.zeros((T, n), device="cuda:0")
+        tx1, tx2 = ka.tensor(x.data_ptr(), ka.F32, [n, T]), ka.tensor(x2.data_ptr(), ka.F32, [n, T])
+        dp = ka.GemvDesc()
+        dp.x, dp.x_nb1, dp.K, dp.T, dp.has_norm, dp.eps, dp.nseg = x2.data_ptr(), n * 4, n, T, 0, 1e-5, 1
+        dp.seg[0].w, dp.seg[0].wtype, dp.seg[0].N = wp.data_ptr(), tid, n
+        dp.seg[0].dst, dp.seg[0].dst_type, dp.seg[0].dst_nb1 = yp.data_ptr(), ka.F32, n * 4
+
+        def prodcons():
+            rc = L.mi355x_scale(ctx.h, C.byref(tx1), C.byref(tx2), 1.0001, 0.0)
+            return rc or L.mi355x_gemv_fused(ctx.h, C.byref(dp))
+        cases["scale -> oproj (fresh activations)"] = (prodcons, (wp, x2, yp, dp), n * ka.row_bytes(tid, n))
+
     H, D = 20, 64
     for nm, n_kv in (("xattn kv1536", 1536), ("self kv64", 64), ("self kv300", 300)):
         q = torch.randn((T, H, D), device="cuda:0", generator=g)

@@ -24,7 +24,46 @@ def main(d):
         v.sort()
         print(f"{key[0][:44]:44s} {key[1] + 'x' + key[2]:>14s} {key[3]:>4s} {key[4]:>6s} {len(v):7d} {sum(v)/len(v):8.2f} {v[0]:8.2f} {v[len(v)//2]:8.2f} {v[-1]:8.2f} {sum(v)/1e3:9.3f} {100*sum(v)/tot:5.1f}%")
     print(f"total kernel time: {tot/1e3:.3f} ms")
+    per_step(files)
     return 0
+
+
+def per_step(files, marker="k_get_rows<6>"):
+    """decode-step anatomy: kernels between two token-embedding gathers form one decode graph; for the most common step
+    length print, per position, the mean duration and the mean gap to the previous kernel's end"""
+    rows = []
+    for f in files:
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Grid_Size_X", "?")))
+    rows.sort()
+    steps, cur = [], None
+    for r in rows:
+        if r[2].startswith(marker):
+            if cur:
+                steps.append(cur)
+            cur = []
+        if cur is not None:
+            cur.append(r)
+    if not steps:
+        return
+    from collections import Counter
+    L = Counter(len(s) for s in steps).most_common(1)[0][0]
+    sel = [s for s in steps if len(s) == L and all(a[2] == b[2] and a[3] == b[3] for a, b in zip(s, steps[[len(x) for x in steps].index(L)]))]
+    if len(sel) < 4:
+        return
+    print(f"\ndecode-step anatomy: {len(sel)} steps of {L} kernels (marker {marker})")
+    span = sum(s[-1][1] - s[0][0] for s in sel) / len(sel) / 1e3
+    busy = sum(sum(k[1] - k[0] for k in s) for s in sel) / len(sel) / 1e3
+    print(f"mean span first-start..last-end = {span:.1f} us, kernel-busy = {busy:.1f} us, gaps = {span - busy:.1f} us")
+    print(f"{'pos':>4s} {'kernel':40s} {'grid':>8s} {'dur_us':>8s} {'gap_us':>8s}")
+    for i in range(L):
+        dur = sum(s[i][1] - s[i][0] for s in sel) / len(sel) / 1e3
+        gap = sum((s[i][0] - s[i - 1][1]) for s in sel) / len(sel) / 1e3 if i else 0.0
+        if i < 30 or i >= L - 6:
+            print(f"{i:4d} {sel[0][i][2][:40]:40s} {sel[0][i][3]:>8s} {dur:8.2f} {gap:8.2f}")
+        elif i == 30:
+            print("   ... (layers repeat)")
 
 
 if __name__ == "__main__":

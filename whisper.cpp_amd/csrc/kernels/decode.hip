@@ -77,6 +77,25 @@ __device__ __forceinline__ void wblk_load(wblk<WT> & r, const char * base, int64
     }
 }
 
+// unconditional form: the caller passes an always-valid block index (clamped) and zeroes the scale of duplicates
+template <int WT>
+__device__ __forceinline__ void wblk_load(wblk<WT> & r, const char * base, int64_t nbt, int64_t ib) {
+    if constexpr (WT == MI355X_TYPE_Q8_0) {
+        const u32x4 * q = (const u32x4 *) (base + ib*32);
+        r.q  = __builtin_nontemporal_load(q);
+        r.q1 = __builtin_nontemporal_load(q + 1);
+        r.d  = *((const uint16_t *) (base + nbt*32) + ib);
+    } else {
+        r.q = __builtin_nontemporal_load((const u32x4 *) (base + ib*16));
+        if constexpr (WT == MI355X_TYPE_Q5_0) {
+            r.qh = *((const uint32_t *) (base + nbt*16) + ib);
+            r.d  = *((const uint16_t *) (base + nbt*20) + ib);
+        } else {
+            r.d  = *((const uint16_t *) (base + nbt*16) + ib);
+        }
+    }
+}
+
 // integer dot of one weight block with the Q8_0 activation block (al = elements 0..15, ah = 16..31), minus the offset term
 template <int WT>
 __device__ __forceinline__ void wblk_unpack(const wblk<WT> & r, uint32_t vlo[4], uint32_t vhi[4]) {
@@ -140,7 +159,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
         #pragma unroll
         for (int u = 0; u < U; u++) {
             const int g = j8 + LPR*(c*U + u);
-            wblk_load<WT>(r[u], base, nbt, (int64_t) row * nb + g, rok && g < nb);
+            wblk_load<WT>(r[u], base, nbt, (int64_t) (rok ? row : 0) * nb + (g < nb ? g : nb - 1));      // clamped, never predicated
         }
     };
 
@@ -361,150 +380,180 @@ static int launch_gemv8(mi355x_ctx * ctx, const DGArgs & k, int T, int lpr, dim3
 // workgroup, so a 1280-row matrix puts 1280 waves' loads in flight right after launch.  Everything that depends on the
 // row is wave-uniform (scalar); activations are held in registers from load to quantization (no staging, no integer
 // division, three barriers with LayerNorm, one without); all cross-lane traffic is DPP / permlane.
+//
+// EVERY global load of the kernel is issued in one straight-line burst at the top, in the order short-latency first
+// (activations / attention partials: L2 or Infinity-Cache hits) ... weights last (HBM), with clamped always-valid
+// addresses instead of predicates.  Two compiler facts force this shape (ROCm 7.2): a load inside a conditional whose
+// result merges with another value (phi) is waited for at the end of its basic block, i.e. `ok ? *p : 0` serializes
+// every such load behind an `s_waitcnt vmcnt(0)`; and loads return in issue order, so anything requested after the
+// weights cannot be consumed before they arrive.  MODE selects the activation source at compile time for the same
+// reason (no phi between the sources): 0 plain x, 1 LayerNorm(x)*w+b, 2 combine of attention partial records.
 // ---------------------------------------------------------------------------------------------------
-template <int WT, int T, int XS>                                        // XS = float4 activation slots per column per thread (K <= XS*1024)
-__global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
+template <int WT, int T, int XS, int MODE>                              // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads)
+__global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
+    constexpr int NU = XS == 1 ? 1 : 3;                                  // 32-element blocks per lane: K <= 2048 -> 1, K <= 5120 -> 3
+    constexpr int MAXP = 12;                                             // attention partial records per (head, query) handled in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // 4..8 waves per workgroup, one row each; the launcher picks ceil(K/256) waves when that lets a single activation slot
+    // per thread cover the whole vector (K = 1280 -> 5 waves = 320 threads)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int K = a.K, nb = K >> 5, K4 = K >> 2;
     const int ntot = a.row_start[a.nseg];
-    const int grow = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    const int grow = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
     int s = 0;
     if (a.nseg > 1 && grow >= a.row_start[1]) s = 1;
     if (a.nseg > 2 && grow >= a.row_start[2]) s = 2;
     const bool rok = grow < ntot;
-    const int row = grow - a.row_start[s];
+    const int row = rok ? grow - a.row_start[s] : 0;                     // clamped: always a valid row of segment s
     const DGSeg & sg = a.seg[s];
 
-    // ---- 1. activation loads (L2 hits) first, 2. weight loads (HBM) right behind them ----
+    // ---- the load burst -------------------------------------------------------------------------------------------
     float4 xr[T][XS];
-    if (a.x != nullptr) {
+    float2 pml[MODE == 2 ? MAXP : 1];
+    float4 pov[MODE == 2 ? MAXP : 1];
+    const int pe4 = tid < K4 ? tid : K4 - 1, ph = pe4 >> 4, pd = (pe4 & 15) << 2;      // MODE 2: this thread's slot-0 element
+    if constexpr (MODE == 2) {
+        // slot 0 of column 0: all records at once (the other columns / slots follow after the weights are requested)
+        const int64_t base = ((int64_t) ph*T + 0) * a.nparts;
+        #pragma unroll
+        for (int p = 0; p < MAXP; p++) {
+            const int pc = p < a.nparts ? p : a.nparts - 1;
+            pml[p] = *(const float2 *) (a.part_ml + (base + pc)*2);
+            pov[p] = *(const float4 *) (a.part_o + (base + pc)*64 + pd);
+        }
+    } else {
         #pragma unroll
         for (int t = 0; t < T; t++) {
             const char * xp = (const char *) a.x + (int64_t) t*a.x_nb1;
             #pragma unroll
             for (int i = 0; i < XS; i++) {
-                const int e4 = tid + i*256;
-                xr[t][i] = e4 < K4 ? *(const float4 *) (xp + (size_t) e4*16) : make_float4(0, 0, 0, 0);
+                const int e4 = tid + i*nthreads;
+                xr[t][i] = *(const float4 *) (xp + (size_t) (e4 < K4 ? e4 : K4 - 1)*16);
             }
         }
     }
-    // every other load that does not depend on computed data is requested NOW as well: the per-layer LayerNorm vectors,
-    // bias and residual are cold in HBM on every decode step (the model is swept once per token), and a cold miss in the
-    // middle of the barrier chain costs about a microsecond each
-    float4 lw[XS], lb[XS];
-    if (a.has_norm) {
+    __builtin_amdgcn_sched_barrier(0);          // pin the issue order: the scheduler otherwise sinks / reorders these loads
+    float4 lw[MODE == 1 ? XS : 1], lb[MODE == 1 ? XS : 1];
+    if constexpr (MODE == 1) {
         #pragma unroll
         for (int i = 0; i < XS; i++) {
-            const int e4 = tid + i*256;
-            lw[i] = e4 < K4 ? *(const float4 *) (a.ln_w + e4*4) : make_float4(0, 0, 0, 0);
-            lb[i] = e4 < K4 ? *(const float4 *) (a.ln_b + e4*4) : make_float4(0, 0, 0, 0);
+            const int e4 = tid + i*nthreads, e4c = e4 < K4 ? e4 : K4 - 1;
+            lw[i] = *(const float4 *) (a.ln_w + e4c*4);
+            lb[i] = *(const float4 *) (a.ln_b + e4c*4);
         }
     }
-    float bias_v = 0.0f, res_v = 0.0f;
-    if (rok && lane < T) {
-        if (sg.bias)     bias_v = sg.bias[row];
-        if (sg.residual) res_v  = *(const float *) ((const char *) sg.residual + (int64_t) lane*sg.res_nb1 + (int64_t) row*4);
-    }
-    wblk<WT> wr[3];
+    // bias / residual of (row, column lane): clamped column, dummy (valid) address when absent
+    const int tcol = lane < T ? lane : T - 1;
+    const float * bptr = sg.bias ? sg.bias + row : (const float *) a.gelu_tab;
+    const float * rptr = sg.residual ? (const float *) ((const char *) sg.residual + (int64_t) tcol*sg.res_nb1) + row : (const float *) a.gelu_tab;
+    const float bias_v = *bptr, res_v = *rptr;
+    __builtin_amdgcn_sched_barrier(0);
+    wblk<WT> wr[NU];
     {
         const char * base = (const char *) sg.w;
         const int64_t nbt = sg.nbt;
         const int ib0 = row * nb;
         #pragma unroll
-        for (int u = 0; u < 3; u++) {
+        for (int u = 0; u < NU; u++) {
             const int g = lane + 64*u;
-            wblk_load<WT>(wr[u], base, nbt, (int64_t) (ib0 + g), rok && g < nb);
+            wblk_load<WT>(wr[u], base, nbt, (int64_t) (ib0 + (g < nb ? g : nb - 1)));
         }
     }
-    float * red = (float *) smem;                                       // [2][T][4]
-    uint32_t * lo = (uint32_t *) (smem + 256);
+    __builtin_amdgcn_sched_barrier(0);
+
+    float * red = (float *) smem;                                       // [2][T][8]
+    uint32_t * lo = (uint32_t *) (smem + 512);
     uint32_t * hi = lo + (size_t) T*nb*4;
     float * dx = (float *) (hi + (size_t) T*nb*4);
     int *   sx = (int *) (dx + T*nb);
 
-    if (a.x == nullptr) {
-        // activations = combine of the attention partial records (see k_gemv8)
+    // ---- activations -> registers ---------------------------------------------------------------------------------
+    if constexpr (MODE == 2) {
+        // x[t][h*64 + d] = sum_p w_p o_p[d] / sum_p w_p l_p,  w_p = exp(m_p - max_p m_p)   (k_fattn_dec records)
         #pragma unroll
         for (int t = 0; t < T; t++) {
+            if (t > 0) {                                                        // one burst per further column
+                const int64_t base = ((int64_t) ph*T + t) * a.nparts;
+                #pragma unroll
+                for (int p = 0; p < MAXP; p++) {
+                    const int pc = p < a.nparts ? p : a.nparts - 1;
+                    pml[p] = *(const float2 *) (a.part_ml + (base + pc)*2);
+                    pov[p] = *(const float4 *) (a.part_o + (base + pc)*64 + pd);
+                }
+            }
+            float M = -1e30f, L = 0.0f;
+            float4 o = make_float4(0, 0, 0, 0);
             #pragma unroll
-            for (int i = 0; i < XS; i++) {
-                const int e4 = tid + i*256;
-                float4 o = make_float4(0, 0, 0, 0);
+            for (int p = 0; p < MAXP; p++) M = fmaxf(M, pml[p].x);              // duplicates of the last record do not change the max
+            #pragma unroll
+            for (int p = 0; p < MAXP; p++) {
+                const float w = p < a.nparts ? __expf(pml[p].x - M) : 0.0f;
+                L = fmaf(w, pml[p].y, L);
+                o.x = fmaf(w, pov[p].x, o.x); o.y = fmaf(w, pov[p].y, o.y); o.z = fmaf(w, pov[p].z, o.z); o.w = fmaf(w, pov[p].w, o.w);
+            }
+            const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+            xr[t][0] = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
+            #pragma unroll
+            for (int i = 1; i < XS; i++) {
+                const int e4 = tid + i*nthreads;
+                float4 o2 = make_float4(0, 0, 0, 0);
                 if (e4 < K4) {
                     const int h = e4 >> 4, d = (e4 & 15) << 2;
                     const int64_t base = ((int64_t) h*T + t) * a.nparts;
-                    float M = -1e30f, L = 0.0f;
-                    if (a.nparts <= 12) {
-                        // all records requested at once (one miss latency instead of two dependent passes); absent
-                        // records are neutral: m = -1e30 -> weight exp(-1e30 - M) = 0
-                        float2 ml[12]; float4 ov[12];
-                        #pragma unroll
-                        for (int p = 0; p < 12; p++) {
-                            const bool ok = p < a.nparts;
-                            ml[p] = ok ? *(const float2 *) (a.part_ml + (base + p)*2) : make_float2(-1e30f, 0.0f);
-                            ov[p] = ok ? *(const float4 *) (a.part_o + (base + p)*64 + d) : make_float4(0, 0, 0, 0);
-                        }
-                        #pragma unroll
-                        for (int p = 0; p < 12; p++) M = fmaxf(M, ml[p].x);
-                        #pragma unroll
-                        for (int p = 0; p < 12; p++) {
-                            const float w = p < a.nparts ? __expf(ml[p].x - M) : 0.0f;
-                            L = fmaf(w, ml[p].y, L);
-                            o.x = fmaf(w, ov[p].x, o.x); o.y = fmaf(w, ov[p].y, o.y); o.z = fmaf(w, ov[p].z, o.z); o.w = fmaf(w, ov[p].w, o.w);
-                        }
-                    } else {
-                        for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
-                        for (int p = 0; p < a.nparts; p++) {
-                            const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
-                            const float w = __expf(ml.x - M);
-                            const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + d);
-                            L = fmaf(w, ml.y, L);
-                            o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
-                        }
+                    float M2 = -1e30f, L2 = 0.0f;
+                    for (int p = 0; p < a.nparts; p++) M2 = fmaxf(M2, a.part_ml[(base + p)*2]);
+                    for (int p = 0; p < a.nparts; p++) {
+                        const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
+                        const float w = __expf(ml.x - M2);
+                        const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + d);
+                        L2 = fmaf(w, ml.y, L2);
+                        o2.x = fmaf(w, v.x, o2.x); o2.y = fmaf(w, v.y, o2.y); o2.z = fmaf(w, v.z, o2.z); o2.w = fmaf(w, v.w, o2.w);
                     }
-                    const float inv = L == 0.0f ? 0.0f : 1.0f / L;
-                    o = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
+                    const float inv2 = L2 == 0.0f ? 0.0f : 1.0f / L2;
+                    o2 = make_float4(o2.x*inv2, o2.y*inv2, o2.z*inv2, o2.w*inv2);
                 }
-                xr[t][i] = o;
+                xr[t][i] = o2;
             }
         }
     }
-    if (a.has_norm) {
+    if constexpr (MODE == 1) {
         // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine, two passes over the registers
         float mean[T], rstd[T];
         #pragma unroll
         for (int t = 0; t < T; t++) {
             float p = 0.0f;
             #pragma unroll
-            for (int i = 0; i < XS; i++) p += (xr[t][i].x + xr[t][i].y) + (xr[t][i].z + xr[t][i].w);     // slots beyond K hold zeros
+            for (int i = 0; i < XS; i++) if (tid + i*nthreads < K4) p += (xr[t][i].x + xr[t][i].y) + (xr[t][i].z + xr[t][i].w);
             p = wave_sum(p);
-            if (lane == 0) red[t*4 + wave] = p;
+            if (lane == 0) red[t*8 + wave] = p;
         }
         __syncthreads();
         #pragma unroll
         for (int t = 0; t < T; t++) {
-            const float4 r = *(const float4 *) (red + t*4);
-            mean[t] = ((r.x + r.y) + (r.z + r.w)) / K;
+            float rs = 0.0f;
+            for (int w = 0; w < nwaves; w++) rs += red[t*8 + w];
+            mean[t] = rs / K;
             float p = 0.0f;
             #pragma unroll
             for (int i = 0; i < XS; i++) {
-                if (tid + i*256 < K4) {
+                if (tid + i*nthreads < K4) {
                     const float d0 = xr[t][i].x - mean[t], d1 = xr[t][i].y - mean[t], d2 = xr[t][i].z - mean[t], d3 = xr[t][i].w - mean[t];
                     p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
                 }
             }
             p = wave_sum(p);
-            if (lane == 0) red[T*4 + t*4 + wave] = p;
+            if (lane == 0) red[T*8 + t*8 + wave] = p;
         }
         __syncthreads();
         #pragma unroll
         for (int t = 0; t < T; t++) {
-            const float4 r = *(const float4 *) (red + T*4 + t*4);
-            rstd[t] = 1.0f / sqrtf(((r.x + r.y) + (r.z + r.w)) / K + a.eps);
+            float rs = 0.0f;
+            for (int w = 0; w < nwaves; w++) rs += red[T*8 + t*8 + w];
+            rstd[t] = 1.0f / sqrtf(rs / K + a.eps);
             #pragma unroll
             for (int i = 0; i < XS; i++) {
-                const int e4 = tid + i*256;
+                const int e4 = tid + i*nthreads;
                 if (e4 < K4) {
                     const float4 w = lw[i], b = lb[i];
                     float o[4] = { (xr[t][i].x - mean[t]) * rstd[t], (xr[t][i].y - mean[t]) * rstd[t], (xr[t][i].z - mean[t]) * rstd[t], (xr[t][i].w - mean[t]) * rstd[t] };
@@ -519,7 +568,7 @@ __global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
         for (int t = 0; t < T; t++) {
             #pragma unroll
             for (int i = 0; i < XS; i++) {
-                const int e4 = tid + i*256;
+                const int e4 = tid + i*nthreads;
                 if (e4 < K4) {
                     const float v[4] = { xr[t][i].x, xr[t][i].y, xr[t][i].z, xr[t][i].w };
                     dg_q8_0_store(v, e4*4, t, nb, lo, hi, dx, sx);
@@ -529,35 +578,33 @@ __global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
     }
     __syncthreads();
 
-    // ---- dot products: lane handles blocks lane, lane+64, lane+128 of the wave's row ----
+    // ---- dot products: lane handles blocks lane (+64, +128) of the wave's row; clamped duplicates carry weight 0 ----
     const uint4 * alo = (const uint4 *) lo;
     const uint4 * ahi = (const uint4 *) hi;
     float acc[T];
     #pragma unroll
     for (int t = 0; t < T; t++) acc[t] = 0.0f;
     #pragma unroll
-    for (int u = 0; u < 3; u++) {
-        const int g = lane + 64*u;
-        if (g < nb) {
-            uint32_t vlo[4], vhi[4];
-            wblk_unpack<WT>(wr[u], vlo, vhi);
-            const float dw = h2f(wr[u].d);
-            constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
-            #pragma unroll
-            for (int t = 0; t < T; t++) {
-                const uint4 al = alo[(size_t) t*nb + g], ah = ahi[(size_t) t*nb + g];
-                int sum = 0;
-                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
-                if (off) sum -= off * sx[t*nb + g];
-                acc[t] = fmaf(dw * dx[t*nb + g], (float) sum, acc[t]);
-            }
+    for (int u = 0; u < NU; u++) {
+        const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+        uint32_t vlo[4], vhi[4];
+        wblk_unpack<WT>(wr[u], vlo, vhi);
+        const float dw = g < nb ? h2f(wr[u].d) : 0.0f;
+        constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            const uint4 al = alo[(size_t) t*nb + gc], ah = ahi[(size_t) t*nb + gc];
+            int sum = 0;
+            sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
+            if (off) sum -= off * sx[t*nb + gc];
+            acc[t] = fmaf(dw * dx[t*nb + gc], (float) sum, acc[t]);
         }
     }
     #pragma unroll
@@ -575,22 +622,37 @@ __global__ void __launch_bounds__(256) k_gemv_row(const DGArgs a) {
     }
 }
 
-template <int WT>
-static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
+// waves (= rows) per workgroup of k_gemv_row: enough threads for one float4 activation slot each when K <= 2048
+static inline int gemv_row_waves(int K) {
+    if (K > 2048) return 4;
+    const int w = (K/4 + 63) / 64;
+    return w < 4 ? 4 : (w > 8 ? 8 : w);
+}
+
+template <int WT, int MODE>
+static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv";
-    const dim3 block(256);
-    if (k.K > 2048) return T == 1 ? emit(ctx, name, k_gemv_row<WT, 1, 5>, grid, block, lds, k, bytes, flops) : MI355X_E_UNSUPPORTED;
+    if (k.K > 2048) return T == 1 ? emit(ctx, name, k_gemv_row<WT, 1, 5, MODE>, grid, dim3(256), lds, k, bytes, flops) : MI355X_E_UNSUPPORTED;
+    const dim3 block(64 * gemv_row_waves(k.K));
     switch (T) {
-        case 1: return emit(ctx, name, k_gemv_row<WT, 1, 2>, grid, block, lds, k, bytes, flops);
-        case 2: return emit(ctx, name, k_gemv_row<WT, 2, 2>, grid, block, lds, k, bytes, flops);
-        case 3: return emit(ctx, name, k_gemv_row<WT, 3, 2>, grid, block, lds, k, bytes, flops);
-        case 4: return emit(ctx, name, k_gemv_row<WT, 4, 2>, grid, block, lds, k, bytes, flops);
-        case 5: return emit(ctx, name, k_gemv_row<WT, 5, 2>, grid, block, lds, k, bytes, flops);
-        case 6: return emit(ctx, name, k_gemv_row<WT, 6, 2>, grid, block, lds, k, bytes, flops);
-        case 7: return emit(ctx, name, k_gemv_row<WT, 7, 2>, grid, block, lds, k, bytes, flops);
-        case 8: return emit(ctx, name, k_gemv_row<WT, 8, 2>, grid, block, lds, k, bytes, flops);
+        case 1: return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE>, grid, block, lds, k, bytes, flops);
+        case 2: return emit(ctx, name, k_gemv_row<WT, 2, 1, MODE>, grid, block, lds, k, bytes, flops);
+        case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE>, grid, block, lds, k, bytes, flops);
+        case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE>, grid, block, lds, k, bytes, flops);
+        case 5: return emit(ctx, name, k_gemv_row<WT, 5, 1, MODE>, grid, block, lds, k, bytes, flops);
+        case 6: return emit(ctx, name, k_gemv_row<WT, 6, 1, MODE>, grid, block, lds, k, bytes, flops);
+        case 7: return emit(ctx, name, k_gemv_row<WT, 7, 1, MODE>, grid, block, lds, k, bytes, flops);
+        case 8: return emit(ctx, name, k_gemv_row<WT, 8, 1, MODE>, grid, block, lds, k, bytes, flops);
         default: return MI355X_E_UNSUPPORTED;
     }
+}
+template <int WT>
+static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
+    if (k.x == nullptr) {
+        if (k.nparts > 12) return MI355X_E_UNSUPPORTED;                // records of one column are held in registers, 12 at most
+        return launch_gemv_row_m<WT, 2>(ctx, k, T, grid, lds, bytes, flops);
+    }
+    return k.has_norm ? launch_gemv_row_m<WT, 1>(ctx, k, T, grid, lds, bytes, flops) : launch_gemv_row_m<WT, 0>(ctx, k, T, grid, lds, bytes, flops);
 }
 
 // second-generation entry: returns MI355X_E_UNSUPPORTED for anything it does not cover (caller falls back to k_gemv)
@@ -630,13 +692,16 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const double flops0 = 2.0 * ntot * K * T;
     static const int env_lean = getenv("GGML_MI355X_GEMV_LEAN") ? atoi(getenv("GGML_MI355X_GEMV_LEAN")) : 1;
     if (env_lean && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
-        const size_t lds_row = dg_lds_bytes(K, T, false);
-        const dim3 grid((ntot + 3) / 4);
+        const size_t lds_row = dg_lds_bytes(K, T, false) + 256;      // 512-byte reduction header
+        const int rpb = gemv_row_waves(K);
+        const dim3 grid((ntot + rpb - 1) / rpb);
+        int rc = MI355X_E_UNSUPPORTED;
         switch (wt) {
-            case MI355X_TYPE_Q4_0: return launch_gemv_row<MI355X_TYPE_Q4_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0);
-            case MI355X_TYPE_Q5_0: return launch_gemv_row<MI355X_TYPE_Q5_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0);
-            case MI355X_TYPE_Q8_0: return launch_gemv_row<MI355X_TYPE_Q8_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0);
+            case MI355X_TYPE_Q4_0: rc = launch_gemv_row<MI355X_TYPE_Q4_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
+            case MI355X_TYPE_Q5_0: rc = launch_gemv_row<MI355X_TYPE_Q5_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
+            case MI355X_TYPE_Q8_0: rc = launch_gemv_row<MI355X_TYPE_Q8_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
         }
+        if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
     if (lds > 64*1024) return MI355X_E_UNSUPPORTED;
     if (staged && ((size_t) T * (K/32) * 40) % 16) return MI355X_E_UNSUPPORTED;      // float4 alignment of the staging area
@@ -697,13 +762,13 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     // all K and V rows of this wave are requested up front: 8 x 16 B per lane in flight
     const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2] + dc*16;
     const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2] + dc*16;
+    // (clamped key index instead of a predicate: a predicated load is waited for at the end of its basic block)
     uint4 kr[4], vr[4];
     #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int key = kbeg + kg + 8*i;
-        const bool ok = key < a.n_kv;
-        kr[i] = ok ? *(const uint4 *) (kbase + (int64_t) key*a.k.nb[1]) : make_uint4(0, 0, 0, 0);
-        vr[i] = ok ? *(const uint4 *) (vbase + (int64_t) key*a.v.nb[1]) : make_uint4(0, 0, 0, 0);
+        const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
+        kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k.nb[1]);
+        vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v.nb[1]);
     }
     // q (rounded to f16 like the CPU's q_to_vec_dot), this lane's 8 dims of every query
     float qf[T][8];
@@ -716,13 +781,15 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     }
     // mask values of this lane's keys: requested together with everything else (a dependent load later would be a
     // serialized miss: the mask was written by the preceding cast kernel, on another XCD)
-    float mk[T][4];
+    uint16_t mkh[T][4];
+    const char * mbase = a.has_mask ? a.m.data : (const char *) a.k.data;       // dummy (valid) address without a mask
+    const int64_t mnb1 = a.has_mask ? a.m.nb[1] : 0;
     #pragma unroll
     for (int t = 0; t < T; t++)
         #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int key = kbeg + kg + 8*i;
-            mk[t][i] = (a.has_mask && key < a.n_kv) ? h2f(*(const uint16_t *) (a.m.data + (int64_t) t*a.m.nb[1] + (int64_t) key*2)) : 0.0f;
+            const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
+            mkh[t][i] = *(const uint16_t *) (mbase + (int64_t) t*mnb1 + (int64_t) kc*2);
         }
     float sc[T][4];
     #pragma unroll
@@ -738,7 +805,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
             #pragma unroll
             for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[t][e], s);
             s = group_sum<8>(s);
-            const float x = s * a.scale + mk[t][i];
+            const float x = s * a.scale + (a.has_mask ? h2f(mkh[t][i]) : 0.0f);
             sc[t][i] = key < a.n_kv ? x : -INFINITY;
         }
     }
