@@ -265,7 +265,7 @@ def main():
             dom = max(prof, key=lambda r: r["total_ms"])
             total = sum(r["total_ms"] for r in prof)
             avg_ms = dom["total_ms"] / max(dom["calls"], 1)
-            if dom["name"] in ("gemm_mfma", "fattn_mfma"):
+            if "gemm_mfma" in dom["name"] or "fattn_mfma" in dom["name"]:
                 ach = dom["algo_flops"] / (dom["total_ms"] * 1e-3) / 1e12
                 out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None}
@@ -276,6 +276,12 @@ def main():
             out["roofline"].update({"launches": dom["calls"], "avg_launch_us": round(avg_ms * 1e3, 3), "share_of_gpu_time": round(dom["total_ms"] / total, 4),
                                     "algorithmic_per_launch": (dom["algo_bytes"] if out["roofline"]["bound"] == "hbm" else dom["algo_flops"]) / max(dom["calls"], 1)})
             out["kernel_time_ms_per_chunk"] = {r["name"]: round(r["total_ms"], 3) for r in sorted(prof, key=lambda r: -r["total_ms"])}
+            # every kernel with >= 2 % of the GPU time: launches, mean duration, achieved algorithmic GB/s and TFLOP/s
+            out["kernels"] = [{"name": r["name"], "launches": r["calls"], "avg_us": round(r["total_ms"] * 1e3 / max(r["calls"], 1), 3),
+                               "share": round(r["total_ms"] / total, 4),
+                               "GBps": round(r["algo_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1) if r["total_ms"] > 0 else None,
+                               "TFLOPs": round(r["algo_flops"] / (r["total_ms"] * 1e-3) / 1e12, 2) if r["total_ms"] > 0 else None}
+                              for r in sorted(prof, key=lambda r: -r["total_ms"]) if r["total_ms"] >= 0.02 * total]
             dec_bytes = figs["decode_bytes_per_token"]
             out["step_roofline"] = {"decode_algorithmic_MB_per_token": round(dec_bytes / 1e6, 2),
                                     "decode_GBps_at_measured_ms": round(dec_bytes / (decode_ms * 1e-3) / 1e9, 1) if decode_ms > 0 else None,

@@ -1,6 +1,8 @@
 // Context, launch emission, profiling, host-side re-layout of quantized blocks.
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <cxxabi.h>
+#include <mutex>
 
 #include <math.h>
 #include <stdarg.h>
@@ -155,6 +157,25 @@ int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 gri
     }
     if (e != hipSuccess) { mi355x_set_error("launch of %s failed: %s", name, hipGetErrorString(e)); return (int) e; }
     if (ctx->prof) {
+        // profile rows are keyed by the kernel's own (demangled) symbol, i.e. exactly the name rocprofv3 reports
+        static std::map<const void *, const char *> names;
+        static std::mutex names_mtx;
+        {
+            std::lock_guard<std::mutex> lk(names_mtx);
+            auto it = names.find(func);
+            if (it == names.end()) {
+                const char * mangled = hipKernelNameRefByPtr(func, ctx->stream);
+                const char * shown = name;
+                if (mangled) {
+                    int status = 0;
+                    char * dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+                    shown = strdup(status == 0 && dem ? dem : mangled);       // lives for the process lifetime
+                    free(dem);
+                }
+                it = names.emplace(func, shown).first;
+            }
+            name = it->second;
+        }
         ctx->ev_pending.push_back({name, ev, algo_bytes, algo_flops});
         if (ctx->ev_pending.size() >= 4096) { HIP_OK(hipStreamSynchronize(ctx->stream)); prof_drain(ctx); }
     }
