@@ -273,6 +273,15 @@ def main():
                 ach = dom["algo_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
                 out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
+            # MI355X_MICROARCH.md prescribes; profiles/pmc_traffic.json says how it was collected); null if not measured
+            try:
+                pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["kernels"]
+                key = dom["name"].split("(")[0].strip()
+                if key in pmc:
+                    out["roofline"]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                pass
             out["roofline"].update({"launches": dom["calls"], "avg_launch_us": round(avg_ms * 1e3, 3), "share_of_gpu_time": round(dom["total_ms"] / total, 4),
                                     "algorithmic_per_launch": (dom["algo_bytes"] if out["roofline"]["bound"] == "hbm" else dom["algo_flops"]) / max(dom["calls"], 1)})
             out["kernel_time_ms_per_chunk"] = {r["name"]: round(r["total_ms"], 3) for r in sorted(prof, key=lambda r: -r["total_ms"])}

@@ -242,6 +242,10 @@ MI355X_API int mi355x_concat(mi355x_ctx * ctx, const mi355x_tensor * a, const mi
  * computed on the host; exposed so that tests can compare it with the reference's table without a GPU */
 MI355X_API void mi355x_gelu_table_host(uint16_t * out65536);
 
+/* debug: with GGML_MI355X_KTIME=1 the decode mat-vec stamps s_memtime at its phase boundaries (workgroup 0, wave 0);
+ * copies the 16 stamps of the last launch to the host.  MI355X_E_UNSUPPORTED when the mode is off. */
+MI355X_API int mi355x_debug_read_stamps(mi355x_ctx * ctx, unsigned long long * out16);
+
 /* memset / memcpy helpers on the context stream */
 MI355X_API int mi355x_memset(mi355x_ctx * ctx, void * dptr, int value, size_t n);
 

@@ -147,6 +147,9 @@ def main():
         ctx.sync()
         if rc:
             continue
+        st = (C.c_uint64 * 16)()
+        if L.mi355x_debug_read_stamps(ctx.h, st) == 0 and st[6] > st[0] > 0:
+            print(f"anatomy {name}: " + " ".join(f"{st[i + 1] - st[i]}" for i in range(6)) + f"  total={st[6] - st[0]} ticks (s_memtime)", file=sys.stderr)
         iters = a.iters if "cycle" not in name else max(a.iters, 2 * int(name.split("x")[-1]))
         for _ in range(iters if "cycle" in name else 0):      # one full pass first: page-table / first-touch effects out of the way
             fn()

@@ -46,7 +46,9 @@ struct mi355x_ctx {
     std::vector<pending>                 ev_pending;
     std::map<std::string, prof_acc>      prof_rows;
     int                                  n_cu = 256;
+    void *                               dbg_stamps = nullptr;   // 16 x u64 (device), GGML_MI355X_KTIME=1 only
 };
+void * mi355x_debug_stamps(mi355x_ctx * ctx);
 
 void   mi355x_set_error(const char * fmt, ...);
 // scratch: returns a device pointer valid until the NEXT mi355x_scratch_reset on this ctx

@@ -81,6 +81,19 @@ extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
 
 extern "C" void * mi355x_ctx_stream(mi355x_ctx * ctx) { return (void *) ctx->stream; }
 
+// kernel-anatomy stamps (debug): allocated on first use when GGML_MI355X_KTIME=1, else kernels get a null pointer
+void * mi355x_debug_stamps(mi355x_ctx * ctx) {
+    static const bool on = getenv("GGML_MI355X_KTIME") && atoi(getenv("GGML_MI355X_KTIME"));
+    if (!on) return nullptr;
+    if (!ctx->dbg_stamps && hipMalloc(&ctx->dbg_stamps, 16*8) == hipSuccess) (void) hipMemset(ctx->dbg_stamps, 0, 16*8);
+    return ctx->dbg_stamps;
+}
+extern "C" int mi355x_debug_read_stamps(mi355x_ctx * ctx, unsigned long long * out16) {
+    if (!ctx->dbg_stamps) return MI355X_E_UNSUPPORTED;
+    (void) hipStreamSynchronize(ctx->stream);
+    return (int) hipMemcpy(out16, ctx->dbg_stamps, 16*8, hipMemcpyDeviceToHost);
+}
+
 static void prof_drain(mi355x_ctx * ctx) {
     for (auto & p : ctx->ev_pending) {
         float ms = 0;

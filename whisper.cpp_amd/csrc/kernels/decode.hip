@@ -36,10 +36,12 @@ struct DGArgs {
     const float * ln_w; const float * ln_b;
     const float * part_o; const float * part_ml; int nparts; int passes;     // x == nullptr: x = combine(attention partials)
     int row_start[4];
-    int xfirst; int pad1;
+    int xfirst; int ntot;
     DGSeg seg[3];
     const uint16_t * gelu_tab;
+    unsigned long long * dbg;          // GGML_MI355X_KTIME=1: s_memtime stamps of workgroup 0 / wave 0 (kernel anatomy, scripts/kbench.py)
 };
+#define DG_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // LPR = lanes per weight row (8/16/32/64 => 8/4/2/1 rows per wave pass).  Decode mat-vecs are latency-bound: what counts
 // is how many waves have loads in flight right after launch, so small matrices use more lanes (= more waves) per row and
@@ -389,7 +391,7 @@ static int launch_gemv8(mi355x_ctx * ctx, const DGArgs & k, int T, int lpr, dim3
 // weights cannot be consumed before they arrive.  MODE selects the activation source at compile time for the same
 // reason (no phi between the sources): 0 plain x, 1 LayerNorm(x)*w+b, 2 combine of attention partial records.
 // ---------------------------------------------------------------------------------------------------
-template <int WT, int T, int XS, int MODE>                              // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads)
+template <int WT, int T, int XS, int MODE, bool NSEG1>                              // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads)
 __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     constexpr int NU = XS == 1 ? 1 : 3;                                  // 32-element blocks per lane: K <= 2048 -> 1, K <= 5120 -> 3
     constexpr int MAXP = 12;                                             // attention partial records per (head, query) handled in registers
@@ -399,21 +401,40 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int K = a.K, nb = K >> 5, K4 = K >> 2;
-    const int ntot = a.row_start[a.nseg];
+    const int ntot = a.ntot;
     const int grow = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
     int s = 0;
-    if (a.nseg > 1 && grow >= a.row_start[1]) s = 1;
-    if (a.nseg > 2 && grow >= a.row_start[2]) s = 2;
+    if constexpr (!NSEG1) {
+        if (a.nseg > 1 && grow >= a.row_start[1]) s = 1;
+        if (a.nseg > 2 && grow >= a.row_start[2]) s = 2;
+    }
     const bool rok = grow < ntot;
-    const int row = rok ? grow - a.row_start[s] : 0;                     // clamped: always a valid row of segment s
-    const DGSeg & sg = a.seg[s];
+    const int row = rok ? grow - (NSEG1 ? 0 : a.row_start[s]) : 0;       // clamped: always a valid row of segment s
+    // Single-segment launches (NSEG1: everything but Q/K/V) read the segment at a static kernarg offset, so ALL scalar
+    // loads of the kernel form one batch; with several segments the (wave-uniform) segment index costs one more dependent
+    // scalar round trip.  Every field — the epilogue's parameters included — is pinned into SGPRs HERE: left to the
+    // compiler they are fetched one by one at their first use, i.e. serialized scalar-cache misses at the kernel tail.
+    const DGSeg & sgr = NSEG1 ? a.seg[0] : a.seg[s];
+    struct { const void * w; int64_t nbt; const float * bias; const float * residual; int64_t res_nb1; void * dst; int64_t dst_nb1;
+             float scale; int has_scale, gelu, dst_f16; } sg;
+    sg.w = sgr.w; sg.nbt = sgr.nbt; sg.bias = sgr.bias; sg.residual = sgr.residual; sg.res_nb1 = sgr.res_nb1;
+    sg.dst = sgr.dst; sg.dst_nb1 = sgr.dst_nb1; sg.scale = sgr.scale; sg.has_scale = sgr.has_scale; sg.gelu = sgr.gelu; sg.dst_f16 = sgr.dst_f16;
+    asm volatile("" :: "s"(sg.w), "s"(sg.nbt), "s"(sg.bias), "s"(sg.residual), "s"(sg.res_nb1), "s"(sg.dst), "s"(sg.dst_nb1),
+                       "s"(sg.scale), "s"(sg.has_scale), "s"(sg.gelu), "s"(sg.dst_f16), "s"(a.gelu_tab),
+                       "s"(a.x), "s"(a.x_nb1), "s"(a.ln_w), "s"(a.ln_b), "s"(a.part_o), "s"(a.part_ml), "s"(a.nparts), "s"(a.eps));
+    DG_STAMP(0);
 
     // ---- the load burst -------------------------------------------------------------------------------------------
     float4 xr[T][XS];
-    float2 pml[MODE == 2 ? MAXP : 1];
-    float4 pov[MODE == 2 ? MAXP : 1];
+    constexpr int XW = 8;                                                // MODE 3: float4 slots per lane covering K <= 2048
+    float4 xw[MODE == 3 ? T : 1][MODE == 3 ? XW : 1];
+    constexpr bool PBURST = MODE == 2 && T <= 2;                         // record bursts cost 72 registers per column
+    float2 pml[PBURST ? MAXP : 1];
+    float4 pov[PBURST ? MAXP : 1];
     const int pe4 = tid < K4 ? tid : K4 - 1, ph = pe4 >> 4, pd = (pe4 & 15) << 2;      // MODE 2: this thread's slot-0 element
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 2 && !PBURST) {
+        // T > 2 (beam search): plain two-pass combine per column after the weights have been requested (below)
+    } else if constexpr (MODE == 2) {
         // slot 0 of column 0: all records at once (the other columns / slots follow after the weights are requested)
         const int64_t base = ((int64_t) ph*T + 0) * a.nparts;
         #pragma unroll
@@ -421,6 +442,18 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
             const int pc = p < a.nparts ? p : a.nparts - 1;
             pml[p] = *(const float2 *) (a.part_ml + (base + pc)*2);
             pov[p] = *(const float4 *) (a.part_o + (base + pc)*64 + pd);
+        }
+    } else if constexpr (MODE == 3) {
+        // wave-local LayerNorm: every wave holds the whole vector (slot i = elements [64i, 64i+64) float4s), so the
+        // statistics need no LDS round trip and no workgroup barrier
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            const char * xp = (const char *) a.x + (int64_t) t*a.x_nb1;
+            #pragma unroll
+            for (int i = 0; i < XW; i++) {
+                const int e4 = lane + 64*i;
+                xw[t][i] = *(const float4 *) (xp + (size_t) (e4 < K4 ? e4 : K4 - 1)*16);
+            }
         }
     } else {
         #pragma unroll
@@ -434,8 +467,8 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);          // pin the issue order: the scheduler otherwise sinks / reorders these loads
-    float4 lw[MODE == 1 ? XS : 1], lb[MODE == 1 ? XS : 1];
-    if constexpr (MODE == 1) {
+    float4 lw[(MODE == 1 || MODE == 3) ? XS : 1], lb[(MODE == 1 || MODE == 3) ? XS : 1];
+    if constexpr (MODE == 1 || MODE == 3) {
         #pragma unroll
         for (int i = 0; i < XS; i++) {
             const int e4 = tid + i*nthreads, e4c = e4 < K4 ? e4 : K4 - 1;
@@ -461,6 +494,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    DG_STAMP(1);                                                        // all loads issued
 
     float * red = (float *) smem;                                       // [2][T][8]
     uint32_t * lo = (uint32_t *) (smem + 512);
@@ -473,24 +507,36 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         // x[t][h*64 + d] = sum_p w_p o_p[d] / sum_p w_p l_p,  w_p = exp(m_p - max_p m_p)   (k_fattn_dec records)
         #pragma unroll
         for (int t = 0; t < T; t++) {
-            if (t > 0) {                                                        // one burst per further column
-                const int64_t base = ((int64_t) ph*T + t) * a.nparts;
-                #pragma unroll
-                for (int p = 0; p < MAXP; p++) {
-                    const int pc = p < a.nparts ? p : a.nparts - 1;
-                    pml[p] = *(const float2 *) (a.part_ml + (base + pc)*2);
-                    pov[p] = *(const float4 *) (a.part_o + (base + pc)*64 + pd);
-                }
-            }
             float M = -1e30f, L = 0.0f;
             float4 o = make_float4(0, 0, 0, 0);
-            #pragma unroll
-            for (int p = 0; p < MAXP; p++) M = fmaxf(M, pml[p].x);              // duplicates of the last record do not change the max
-            #pragma unroll
-            for (int p = 0; p < MAXP; p++) {
-                const float w = p < a.nparts ? __expf(pml[p].x - M) : 0.0f;
-                L = fmaf(w, pml[p].y, L);
-                o.x = fmaf(w, pov[p].x, o.x); o.y = fmaf(w, pov[p].y, o.y); o.z = fmaf(w, pov[p].z, o.z); o.w = fmaf(w, pov[p].w, o.w);
+            if constexpr (PBURST) {
+                if (t > 0) {                                                    // one burst per further column
+                    const int64_t base = ((int64_t) ph*T + t) * a.nparts;
+                    #pragma unroll
+                    for (int p = 0; p < MAXP; p++) {
+                        const int pc = p < a.nparts ? p : a.nparts - 1;
+                        pml[p] = *(const float2 *) (a.part_ml + (base + pc)*2);
+                        pov[p] = *(const float4 *) (a.part_o + (base + pc)*64 + pd);
+                    }
+                }
+                #pragma unroll
+                for (int p = 0; p < MAXP; p++) M = fmaxf(M, pml[p].x);          // duplicates of the last record do not change the max
+                #pragma unroll
+                for (int p = 0; p < MAXP; p++) {
+                    const float w = p < a.nparts ? __expf(pml[p].x - M) : 0.0f;
+                    L = fmaf(w, pml[p].y, L);
+                    o.x = fmaf(w, pov[p].x, o.x); o.y = fmaf(w, pov[p].y, o.y); o.z = fmaf(w, pov[p].z, o.z); o.w = fmaf(w, pov[p].w, o.w);
+                }
+            } else {
+                const int64_t base = ((int64_t) ph*T + t) * a.nparts;
+                for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
+                for (int p = 0; p < a.nparts; p++) {
+                    const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
+                    const float w = __expf(ml.x - M);
+                    const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + pd);
+                    L = fmaf(w, ml.y, L);
+                    o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
+                }
             }
             const float inv = L == 0.0f ? 0.0f : 1.0f / L;
             xr[t][0] = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
@@ -517,7 +563,40 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
             }
         }
     }
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 3) {
+        // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine; statistics per wave (identical in every wave: same order)
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            float p = 0.0f;
+            #pragma unroll
+            for (int i = 0; i < XW; i++) if (lane + 64*i < K4) p += (xw[t][i].x + xw[t][i].y) + (xw[t][i].z + xw[t][i].w);
+            const float mean = wave_sum(p) / K;
+            float q = 0.0f;
+            #pragma unroll
+            for (int i = 0; i < XW; i++) {
+                if (lane + 64*i < K4) {
+                    const float d0 = xw[t][i].x - mean, d1 = xw[t][i].y - mean, d2 = xw[t][i].z - mean, d3 = xw[t][i].w - mean;
+                    q += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+                }
+            }
+            const float rstd = 1.0f / sqrtf(wave_sum(q) / K + a.eps);
+            // this wave quantizes slot `wave` (element tid): value select, no dynamic register indexing
+            float4 sel = xw[t][0];
+            #pragma unroll
+            for (int i = 1; i < XW; i++) {
+                const bool m = wave == i;
+                sel.x = m ? xw[t][i].x : sel.x; sel.y = m ? xw[t][i].y : sel.y; sel.z = m ? xw[t][i].z : sel.z; sel.w = m ? xw[t][i].w : sel.w;
+            }
+            if (tid < K4) {
+                const float4 w = lw[0], b = lb[0];
+                float o[4] = { (sel.x - mean) * rstd, (sel.y - mean) * rstd, (sel.z - mean) * rstd, (sel.w - mean) * rstd };
+                o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
+                o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
+                dg_q8_0_store(o, tid*4, t, nb, lo, hi, dx, sx);
+            }
+        }
+        DG_STAMP(2);
+    } else if constexpr (MODE == 1) {
         // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine, two passes over the registers
         float mean[T], rstd[T];
         #pragma unroll
@@ -528,6 +607,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
             p = wave_sum(p);
             if (lane == 0) red[t*8 + wave] = p;
         }
+        DG_STAMP(2);                                                    // activations arrived, first reduction done
         __syncthreads();
         #pragma unroll
         for (int t = 0; t < T; t++) {
@@ -576,7 +656,9 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
             }
         }
     }
+    DG_STAMP(3);                                                        // activations quantized into LDS
     __syncthreads();
+    DG_STAMP(4);
 
     // ---- dot products: lane handles blocks lane (+64, +128) of the wave's row; clamped duplicates carry weight 0 ----
     const uint4 * alo = (const uint4 *) lo;
@@ -607,6 +689,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
             acc[t] = fmaf(dw * dx[t*nb + gc], (float) sum, acc[t]);
         }
     }
+    DG_STAMP(5);                                                        // weights arrived, dots done
     #pragma unroll
     for (int t = 0; t < T; t++) acc[t] = wave_sum(acc[t]);
     float v = acc[0];
@@ -620,6 +703,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         char * dp = (char *) sg.dst + (int64_t) lane*sg.dst_nb1;
         if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
     }
+    DG_STAMP(6);
 }
 
 // waves (= rows) per workgroup of k_gemv_row: enough threads for one float4 activation slot each when K <= 2048
@@ -629,30 +713,46 @@ static inline int gemv_row_waves(int K) {
     return w < 4 ? 4 : (w > 8 ? 8 : w);
 }
 
-template <int WT, int MODE>
+template <int WT, int MODE, bool NSEG1>
 static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv";
-    if (k.K > 2048) return T == 1 ? emit(ctx, name, k_gemv_row<WT, 1, 5, MODE>, grid, dim3(256), lds, k, bytes, flops) : MI355X_E_UNSUPPORTED;
+    if (k.K > 2048) {
+        if constexpr (MODE == 0 || MODE == 1) { if (T == 1) return emit(ctx, name, k_gemv_row<WT, 1, 5, MODE, NSEG1>, grid, dim3(256), lds, k, bytes, flops); }
+        return MI355X_E_UNSUPPORTED;
+    }
     const dim3 block(64 * gemv_row_waves(k.K));
-    switch (T) {
-        case 1: return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE>, grid, block, lds, k, bytes, flops);
-        case 2: return emit(ctx, name, k_gemv_row<WT, 2, 1, MODE>, grid, block, lds, k, bytes, flops);
-        case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE>, grid, block, lds, k, bytes, flops);
-        case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE>, grid, block, lds, k, bytes, flops);
-        case 5: return emit(ctx, name, k_gemv_row<WT, 5, 1, MODE>, grid, block, lds, k, bytes, flops);
-        case 6: return emit(ctx, name, k_gemv_row<WT, 6, 1, MODE>, grid, block, lds, k, bytes, flops);
-        case 7: return emit(ctx, name, k_gemv_row<WT, 7, 1, MODE>, grid, block, lds, k, bytes, flops);
-        case 8: return emit(ctx, name, k_gemv_row<WT, 8, 1, MODE>, grid, block, lds, k, bytes, flops);
-        default: return MI355X_E_UNSUPPORTED;
+    if constexpr (MODE == 3) {              // wave-local LayerNorm: whole vector in every wave's registers, T <= 2
+        if (T == 1) return emit(ctx, name, k_gemv_row<WT, 1, 1, 3, NSEG1>, grid, block, lds, k, bytes, flops);
+        if (T == 2) return emit(ctx, name, k_gemv_row<WT, 2, 1, 3, NSEG1>, grid, block, lds, k, bytes, flops);
+        return MI355X_E_UNSUPPORTED;
+    } else {
+        switch (T) {
+            case 1: return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 2: return emit(ctx, name, k_gemv_row<WT, 2, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 5: return emit(ctx, name, k_gemv_row<WT, 5, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 6: return emit(ctx, name, k_gemv_row<WT, 6, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 7: return emit(ctx, name, k_gemv_row<WT, 7, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 8: return emit(ctx, name, k_gemv_row<WT, 8, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            default: return MI355X_E_UNSUPPORTED;
+        }
     }
 }
 template <int WT>
 static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
+    static const bool wave_ln = !(getenv("GGML_MI355X_GEMV_WAVE_LN") && !atoi(getenv("GGML_MI355X_GEMV_WAVE_LN")));
     if (k.x == nullptr) {
-        if (k.nparts > 12) return MI355X_E_UNSUPPORTED;                // records of one column are held in registers, 12 at most
-        return launch_gemv_row_m<WT, 2>(ctx, k, T, grid, lds, bytes, flops);
+        if (k.nparts > 12 || k.nseg != 1) return MI355X_E_UNSUPPORTED;   // records of one column are held in registers, 12 at most
+        return launch_gemv_row_m<WT, 2, true>(ctx, k, T, grid, lds, bytes, flops);
     }
-    return k.has_norm ? launch_gemv_row_m<WT, 1>(ctx, k, T, grid, lds, bytes, flops) : launch_gemv_row_m<WT, 0>(ctx, k, T, grid, lds, bytes, flops);
+    if (k.has_norm) {
+        if (wave_ln && k.K <= 2048 && T <= 2)
+            return k.nseg == 1 ? launch_gemv_row_m<WT, 3, true>(ctx, k, T, grid, lds, bytes, flops) : launch_gemv_row_m<WT, 3, false>(ctx, k, T, grid, lds, bytes, flops);
+        return k.nseg == 1 ? launch_gemv_row_m<WT, 1, true>(ctx, k, T, grid, lds, bytes, flops) : launch_gemv_row_m<WT, 1, false>(ctx, k, T, grid, lds, bytes, flops);
+    }
+    if (k.nseg != 1) return MI355X_E_UNSUPPORTED;                        // several segments without LayerNorm: generic kernel
+    return launch_gemv_row_m<WT, 0, true>(ctx, k, T, grid, lds, bytes, flops);
 }
 
 // second-generation entry: returns MI355X_E_UNSUPPORTED for anything it does not cover (caller falls back to k_gemv)
@@ -672,6 +772,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     DGArgs k; memset(&k, 0, sizeof(k));
     k.x = from_part ? nullptr : d->x; k.x_nb1 = d->x_nb1; k.K = K; k.has_norm = d->has_norm; k.eps = d->eps; k.nseg = d->nseg;
     k.ln_w = d->ln_w; k.ln_b = d->ln_b; k.gelu_tab = ctx->gelu_tab;
+    k.dbg = (unsigned long long *) mi355x_debug_stamps(ctx);
     k.part_o = d->attn_part_o; k.part_ml = d->attn_part_ml; k.nparts = d->attn_nparts;
     int ntot = 0; double wbytes = 0;
     for (int s = 0; s < d->nseg; s++) {
@@ -688,6 +789,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         wbytes += (double) mi355x_type_row_bytes(wt, K) * g.N;
     }
     for (int s = d->nseg; s < 4; s++) k.row_start[s] = ntot;
+    k.ntot = ntot;
     const double bytes0 = wbytes + (double) K*T*4 + (double) ntot*T*4;
     const double flops0 = 2.0 * ntot * K * T;
     static const int env_lean = getenv("GGML_MI355X_GEMV_LEAN") ? atoi(getenv("GGML_MI355X_GEMV_LEAN")) : 1;
