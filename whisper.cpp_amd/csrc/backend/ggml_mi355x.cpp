@@ -292,6 +292,7 @@ static const ggml_backend_buffer_type_i mi_buft_iface = {
 // backend (stream)
 // ---------------------------------------------------------------------------------------------------
 struct mi_graph_cache {
+    uint64_t                   key = 0;           // (cgraph node count, segment index)
     hipGraph_t                 graph = nullptr;
     hipGraphExec_t             exec  = nullptr;
     std::vector<hipGraphNode_t> nodes;
@@ -707,10 +708,13 @@ static int run_node(mi_backend_ctx * b, const ggml_tensor * n) {
     }
 }
 
-// walk the graph and emit kernels (eagerly, or into the context's launch record)
-static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
-    b->act_src = nullptr;
-    for (int i = 0; i < g->n_nodes; i++) {
+// walk nodes [i0, i_stop) and emit kernels (eagerly, or into the context's launch record).  While recording with
+// max_launches > 0 the walk also stops, at a node boundary, once that many launches have been recorded; *i_next receives the
+// index of the first node not processed.
+static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop, int max_launches, int * i_next) {
+    int i = i0;
+    for (; i < i_stop; i++) {
+        if (max_launches > 0 && b->recording && mi355x_record_count(b->k) >= max_launches) break;
         const ggml_tensor * n = g->nodes[i];
         if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
         int rc = MI355X_E_UNSUPPORTED;
@@ -745,7 +749,12 @@ static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
             return rc;
         }
     }
+    if (i_next) *i_next = i < i_stop ? i : i_stop;
     return 0;
+}
+static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
+    b->act_src = nullptr;
+    return mi_emit_range(b, g, 0, g->n_nodes, 0, nullptr);
 }
 
 // ---- hipGraph replay ----------------------------------------------------------------------------------
@@ -754,17 +763,17 @@ static bool same_shape(const mi355x_launch & a, const mi355x_launch & b) {
            !memcmp(a.block, b.block, sizeof(a.block));
 }
 
-static int mi_run_recorded(mi_backend_ctx * b, const mi355x_launch * L, int n, const uint8_t * blob, size_t blob_size) {
+static int mi_run_recorded(mi_backend_ctx * b, uint64_t key, const mi355x_launch * L, int n, const uint8_t * blob, size_t blob_size) {
     hipStream_t stream = (hipStream_t) mi355x_ctx_stream(b->k);
     mi_graph_cache * gc = nullptr;
-    for (auto & c : b->gcache) if ((int) c.launches.size() == n) { gc = &c; break; }
+    for (auto & c : b->gcache) if (c.key == key && (int) c.launches.size() == n) { gc = &c; break; }
     bool rebuild = gc == nullptr;
     if (gc) {
         for (int i = 0; i < n && !rebuild; i++) if (!same_shape(gc->launches[i], L[i])) rebuild = true;
     }
     if (rebuild) {
         if (!gc) {
-            if (b->gcache.size() >= 8) {            // bounded cache: drop the least used entry
+            if (b->gcache.size() >= 48) {           // bounded cache: drop the least used entry
                 size_t worst = 0;
                 for (size_t i = 1; i < b->gcache.size(); i++) if (b->gcache[i].hits < b->gcache[worst].hits) worst = i;
                 if (b->gcache[worst].exec)  (void) hipGraphExecDestroy(b->gcache[worst].exec);
@@ -773,6 +782,7 @@ static int mi_run_recorded(mi_backend_ctx * b, const mi355x_launch * L, int n, c
             }
             b->gcache.emplace_back();
             gc = &b->gcache.back();
+            gc->key = key;
         } else {
             if (gc->exec)  (void) hipGraphExecDestroy(gc->exec);
             if (gc->graph) (void) hipGraphDestroy(gc->graph);
@@ -870,23 +880,44 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
     // graphs pay off when the launch sequence is long and launch-bound (decoder step); profiling needs eager launches
     const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32;
     if (use_graph) {
-        const double t0 = now_ms();
-        mi355x_record_begin(b->k);
-        b->recording = true; b->record_abort = false;
-        int rc = mi_emit_graph(b, cgraph);
-        b->recording = false;
-        b->t_plan_ms += now_ms() - t0;
-        const mi355x_launch * L; const uint8_t * blob; size_t bsz;
-        const int n = mi355x_record_end(b->k, &L, &blob, &bsz);
-        if (rc != 0) return GGML_STATUS_FAILED;
-        if (n < 0 || b->record_abort) {
-            // a scratch buffer had to grow: this call runs eagerly, the next one records again
-        } else if (n > 0) {
-            rc = mi_run_recorded(b, L, n, blob, bsz);
-            if (rc == 0) return GGML_STATUS_SUCCESS;
-            MI_LOG("graph replay unavailable (rc=%d); falling back to eager launches", rc);
-            b->graphs = false;
-        } else return GGML_STATUS_SUCCESS;
+        // The launch sequence is replayed as hipGraphs of ~seg launches each: the first segment starts executing while the
+        // host is still planning / patching / launching the following ones, so only 1/n-th of the per-step host work sits in
+        // front of the GPU (a decode step of large-v3 is 264 launches and ~145 us of host work in here).
+        static const int seg = getenv("GGML_MI355X_GRAPH_SEG") ? atoi(getenv("GGML_MI355X_GRAPH_SEG")) : 64;
+        b->act_src = nullptr;
+        int i = 0, iseg = 0;
+        bool ok = true;
+        while (i < cgraph->n_nodes && ok) {
+            const double t0 = now_ms();
+            mi355x_record_begin(b->k);
+            b->recording = true; b->record_abort = false;
+            int i_next = cgraph->n_nodes;
+            int rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, seg, &i_next);
+            b->recording = false;
+            b->t_plan_ms += now_ms() - t0;
+            const mi355x_launch * L; const uint8_t * blob; size_t bsz;
+            const int n = mi355x_record_end(b->k, &L, &blob, &bsz);
+            if (rc != 0) return GGML_STATUS_FAILED;
+            if (n < 0 || b->record_abort) {
+                // a scratch buffer had to grow while recording: this segment runs eagerly (the next call records again)
+                const double t1 = now_ms();
+                rc = mi_emit_range(b, cgraph, i, i_next, 0, nullptr);
+                b->t_eager_ms += now_ms() - t1;
+                if (rc != 0) return GGML_STATUS_FAILED;
+            } else if (n > 0) {
+                rc = mi_run_recorded(b, ((uint64_t) cgraph->n_nodes << 16) | (uint64_t) iseg, L, n, blob, bsz);
+                if (rc != 0) {
+                    MI_LOG("graph replay unavailable (rc=%d); falling back to eager launches", rc);
+                    b->graphs = false;
+                    const double t1 = now_ms();
+                    rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, 0, nullptr);
+                    b->t_eager_ms += now_ms() - t1;
+                    return rc == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+                }
+            }
+            i = i_next; iseg++;
+        }
+        return GGML_STATUS_SUCCESS;
     }
     const double t0 = now_ms();
     const int rc = mi_emit_graph(b, cgraph);

@@ -195,6 +195,7 @@ int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 gri
     return 0;
 }
 
+extern "C" int  mi355x_record_count(mi355x_ctx * ctx) { return ctx->recording ? (int) ctx->plan.size() : 0; }
 extern "C" void mi355x_record_begin(mi355x_ctx * ctx) { ctx->recording = true; ctx->record_invalid = false; ctx->plan.clear(); ctx->blob.clear(); }
 extern "C" int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size) {
     ctx->recording = false;

@@ -741,7 +741,9 @@ static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 gri
 }
 template <int WT>
 static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
-    static const bool wave_ln = !(getenv("GGML_MI355X_GEMV_WAVE_LN") && !atoi(getenv("GGML_MI355X_GEMV_WAVE_LN")));
+    // wave-local LayerNorm (MODE 3) measured no faster than the workgroup version and slower for N >= 3840 (every one of
+    // ~15 waves per CU repeats the statistics): off unless GGML_MI355X_GEMV_WAVE_LN=1
+    static const bool wave_ln = getenv("GGML_MI355X_GEMV_WAVE_LN") && atoi(getenv("GGML_MI355X_GEMV_WAVE_LN"));
     if (k.x == nullptr) {
         if (k.nparts > 12 || k.nseg != 1) return MI355X_E_UNSUPPORTED;   // records of one column are held in registers, 12 at most
         return launch_gemv_row_m<WT, 2, true>(ctx, k, T, grid, lds, bytes, flops);
