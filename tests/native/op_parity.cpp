@@ -399,6 +399,32 @@ int main(int argc, char ** argv) {
         }, false, true);
     }
 
+    // cross-attention block of whisper_build_graph_decoder (W:2684-2770): LN -> Q (+bias, *scale) -> flash_attn over the
+    // F16 cross KV (no mask) -> O-projection + bias + residual.  T = 1 takes the single-launch LN+Q+attention kernel.
+    for (ggml_type wt : wtypes) for (int T : { 1, 5 }) for (int n_kv : { 1536, 200 }) {
+        const int n_state = 1280, n_head = 20;
+        char nm[128]; snprintf(nm, sizeof(nm), "xattnlayer_%s_T%d_kv%d", tname(wt), T, n_kv);
+        run_case(nm, [=](builder & b) {
+            ggml_context * c = b.ctx;
+            const int D = n_state / n_head;
+            auto W = [&](int k, int n) { return b.randn(wt, {k, n}, 1.0f / sqrtf((float) k)); };
+            auto V = [&](int n, float s = 0.05f) { return b.randn(GGML_TYPE_F32, {n}, s); };
+            ggml_tensor * inpCA = b.randn(GGML_TYPE_F32, {n_state, T}, 1.5f);
+            ggml_tensor * kc = b.randn(GGML_TYPE_F16, {(int64_t) n_state * n_kv}, 0.4f);
+            ggml_tensor * vc = b.randn(GGML_TYPE_F16, {(int64_t) n_state * n_kv}, 0.8f);
+            const float KQscale = powf((float) D, -0.25f);
+            ggml_tensor * cur = ggml_norm(c, inpCA, 1e-5f);
+            cur = ggml_add(c, ggml_mul(c, cur, V(n_state, 1.0f)), V(n_state));
+            ggml_tensor * Qcur = ggml_scale(c, ggml_add(c, ggml_mul_mat(c, W(n_state, n_state), cur), V(n_state)), KQscale);
+            ggml_tensor * Q = ggml_permute(c, ggml_reshape_3d(c, Qcur, D, n_head, T), 0, 2, 1, 3);
+            ggml_tensor * Kv = ggml_view_3d(c, kc, D, n_kv, n_head, 2 * n_state, 2 * D, 0);
+            ggml_tensor * Vv = ggml_view_3d(c, vc, D, n_kv, n_head, 2 * n_state, 2 * D, 0);
+            ggml_tensor * att = ggml_reshape_2d(c, ggml_flash_attn_ext(c, Q, Kv, Vv, nullptr, KQscale, 0.0f, 0.0f), n_state, T);
+            ggml_tensor * proj = ggml_add(c, ggml_mul_mat(c, W(n_state, n_state), att), V(n_state));
+            return std::vector<ggml_tensor *>{ ggml_add(c, proj, inpCA) };
+        }, false, true);
+    }
+
     ggml_backend_free(g_gpu);
     ggml_backend_free(g_cpu);
     return 0;

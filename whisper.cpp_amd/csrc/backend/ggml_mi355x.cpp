@@ -502,6 +502,8 @@ static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c) {
     return mi355x_norm(b->k, &mx, &md, eps, c.w, c.b);
 }
 
+static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const mi355x_attn_partials & parts, int & end_out, int & rc_out);
+
 // decoder step: LayerNorm fused into the mat-vec products that consume it (Q/K/V, cross-Q, fc1)
 static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chain & ln, int & end_out, int & rc_out) {
     if (!ln.w || !ln.b) return false;
@@ -521,6 +523,7 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
         n++;
     }
     if (n != nuse) return false;
+    const int j_after = j;                                   // first real node after the last chain
     mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
     d.x = (const float *) x->data; d.x_nb1 = (int64_t) x->nb[1]; d.K = (int) K; d.T = (int) T;
     d.has_norm = 1; memcpy(&d.eps, ln.norm->op_params, sizeof(float)); d.ln_w = ln.w; d.ln_b = ln.b; d.nseg = n;
@@ -535,11 +538,39 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
         sg.dst = ch[s].last->data; sg.dst_type = (int32_t) ch[s].last->type;
         sg.dst_nb1 = ch[s].last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch[s].last == ch[s].mm ? (int64_t) ch[s].mm->nb[1] : (int64_t) ch[s].last->nb[1]);
     }
+    // cross-attention, T = 1: LN -> Q projection -> flash_attn_ext whose q is a pure view of the projection's result and
+    // nothing else reads it => one launch computes the attention partials directly (k_qattn)
+    if (n == 1 && T == 1 && b->fuse && j_after < g->n_nodes && g->nodes[j_after]->op == GGML_OP_FLASH_ATTN_EXT) {
+        const ggml_tensor * fa = g->nodes[j_after], * q = fa->src[0], * qsrc = ch[0].last;
+        bool ok = q->view_src == qsrc && q->view_offs == 0 && qsrc->type == GGML_TYPE_F32 && ggml_is_contiguous(qsrc) && !qsrc->view_src &&
+                  q->ne[0] == 64 && q->ne[1] == 1 && q->ne[3] == 1 && q->ne[2]*64 == qsrc->ne[0] && q->nb[0] == 4 && q->nb[2] == 64*4 &&
+                  use_count(g, qsrc) == 1 && !(qsrc->flags & GGML_TENSOR_FLAG_OUTPUT) && !fa->src[4] && ggml_is_contiguous(fa) && fa->type == GGML_TYPE_F32;
+        for (const ggml_tensor * t = q; ok && t != qsrc; t = t->src[0]) {             // the view chain q -> ... -> projection result
+            if (!op_is_empty(t) || !t->src[0] || use_count(g, t) != 1 || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) ok = false;
+        }
+        if (ok) {
+            float max_bias, softcap, scale;
+            memcpy(&scale, fa->op_params, 4); memcpy(&max_bias, (const float *) fa->op_params + 1, 4); memcpy(&softcap, (const float *) fa->op_params + 2, 4);
+            if (max_bias == 0.0f && softcap == 0.0f) {
+                mi355x_tensor mk = to_mt(fa->src[1]), mv = to_mt(fa->src[2]), mm_;
+                if (fa->src[3]) mm_ = to_mt(fa->src[3]);
+                mi355x_attn_partials parts;
+                const int rc = mi355x_ln_q_attn_partial(b->k, &d, &mk, &mv, fa->src[3] ? &mm_ : nullptr, scale, &parts);
+                if (rc != MI355X_E_UNSUPPORTED) {
+                    rc_out = rc; end_out = j_after;
+                    if (rc == 0) attn_consume(b, g, j_after, parts, end_out, rc_out);
+                    return true;
+                }
+            }
+        }
+    }
     const int rc = mi355x_gemv_fused(b->k, &d);
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = ch[n - 1].end;
     return true;
 }
+
+static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const mi355x_attn_partials & parts, int & end_out, int & rc_out);
 
 // decoder step: flash_attn_ext (T <= 8) -> reshape -> mul_mat chain (the O-projection).  The attention kernel leaves
 // per-128-key partial records; their combine runs in the prologue of the projection mat-vec (one kernel less per
@@ -557,8 +588,17 @@ static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = i;
     if (rc) return true;
+    attn_consume(b, g, i, parts, end_out, rc_out);
+    return true;
+}
 
-    // from here on the partials exist: either the projection consumes them, or they are combined into fa's memory
+// the partial records of flash_attn_ext node i exist: either the projection that follows consumes them (combine in its
+// prologue), or they are combined into the node's own memory
+static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const mi355x_attn_partials & parts, int & end_out, int & rc_out) {
+    const ggml_tensor * fa = g->nodes[i];
+    const int64_t T = fa->src[0]->ne[1], H = fa->src[0]->ne[2];
+    int rc;
+    end_out = i;
     bool fused = false;
     const int j = next_real(g, i);
     mm_chain ch;
@@ -584,7 +624,6 @@ static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int
         mi355x_tensor md = to_mt(fa);
         rc_out = mi355x_flash_attn_combine(b->k, &parts, &md);
     }
-    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -959,6 +959,230 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// k_qattn: LayerNorm + Q projection + decode attention in ONE launch (decoder cross-attention, T = 1,
+// src/whisper.cpp:2684-2726).  Workgroup (chunk c, head h), 8 waves: recomputes the 64 rows of W_q that make up head h
+// (56 KB of Q5_0 weights, identical for the workgroups of all key chunks of that head: one HBM read, the rest L2 hits),
+// then attends to its 128 keys exactly like k_fattn_dec and leaves the same partial record.  Replaces the separate
+// "LN + Q_cross" mat-vec: one launch (~4.5 us + ~1.1 us boundary) less per decoder layer.
+// Same arithmetic as the unfused sequence: LN -> Q8_0 activations -> int8 dots -> +bias -> *scale -> f16 rounding of q
+// -> f32 scores, softmax, f32 P.V.
+// ---------------------------------------------------------------------------------------------------
+struct QAArgs {
+    const float * x; const float * ln_w; const float * ln_b; float eps; int K;         // activation row (T = 1) and LayerNorm
+    const void * w; int64_t nbt; const float * bias; float qscale; int has_qscale;     // W_q [K, H*64] planar, bias, ggml_scale
+    dtensor k, v, m; int has_mask; float scale; int n_kv, H, rk2, rv2, nparts;
+    float * part_o; float * part_ml;
+    const uint16_t * dummy;                                                            // any valid address (absent bias / mask)
+};
+
+template <int WT>
+__global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int K = a.K, nb = K >> 5, K4 = K >> 2;
+    const int kg = lane >> 3, dc = lane & 7;
+    const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2, p = blockIdx.x;
+    const int kbeg = p*128 + wave*16;
+
+    // ---- load burst: activations, LN vectors, bias, K/V rows, mask, then the weights --------------------------------
+    const int e4c = tid < K4 ? tid : K4 - 1;
+    const float4 xv = *(const float4 *) (a.x + e4c*4);
+    const float4 lw = *(const float4 *) (a.ln_w + e4c*4);
+    const float4 lb = *(const float4 *) (a.ln_b + e4c*4);
+    const int qrow0 = hq*64 + wave*8;                                  // this wave's 8 rows of W_q
+    const float * bptr = a.bias ? a.bias + qrow0 + (lane & 7) : (const float *) a.dummy;
+    const float bias_v = *bptr;
+    const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2] + dc*16;
+    const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2] + dc*16;
+    const char * mbase = a.has_mask ? a.m.data : (const char *) a.dummy;
+    uint4 kr[2], vr[2]; uint16_t mkh[2];
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
+        kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k.nb[1]);
+        vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v.nb[1]);
+        mkh[i] = *(const uint16_t *) (mbase + (a.has_mask ? (int64_t) kc*2 : 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wblk<WT> wr[8];
+    {
+        const int gc = lane < nb ? lane : nb - 1;
+        #pragma unroll
+        for (int r = 0; r < 8; r++) wblk_load<WT>(wr[r], (const char *) a.w, a.nbt, (int64_t) (qrow0 + r) * nb + gc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float * red = (float *) smem;                                       // [2][8]
+    float * qs  = red + 16;                                             // [64] projected, f16-rounded q of this head
+    float * wo  = qs + 64;                                              // [8 waves][64] + [8][2] wave partials
+    float * wml = wo + 8*64;
+    uint32_t * lo = (uint32_t *) (smem + 4096);
+    uint32_t * hi = lo + (size_t) nb*4;
+    float * dx = (float *) (hi + (size_t) nb*4);
+    int *   sx = (int *) (dx + nb);
+
+    // ---- LayerNorm + Q8_0 quantization of the activation (ggml-cpu/ops.cpp:3698-3765, arch/x86/quants.c:302-398) ----
+    {
+        float ps = tid < K4 ? (xv.x + xv.y) + (xv.z + xv.w) : 0.0f;
+        ps = wave_sum(ps);
+        if (lane == 0) red[wave] = ps;
+        __syncthreads();
+        float rs = 0.0f;
+        #pragma unroll
+        for (int w = 0; w < 8; w++) rs += red[w];
+        const float mean = rs / K;
+        const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
+        float pv = tid < K4 ? (d0*d0 + d1*d1) + (d2*d2 + d3*d3) : 0.0f;
+        pv = wave_sum(pv);
+        if (lane == 0) red[8 + wave] = pv;
+        __syncthreads();
+        float rv = 0.0f;
+        #pragma unroll
+        for (int w = 0; w < 8; w++) rv += red[8 + w];
+        const float rstd = 1.0f / sqrtf(rv / K + a.eps);
+        if (tid < K4) {
+            float o[4] = { d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd };
+            o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
+            o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
+            dg_q8_0_store(o, tid*4, 0, nb, lo, hi, dx, sx);
+        }
+    }
+    __syncthreads();
+
+    // ---- q_h: 8 rows per wave ----------------------------------------------------------------------------------------
+    {
+        const int gc = lane < nb ? lane : nb - 1;
+        const uint4 al = ((const uint4 *) lo)[gc], ah = ((const uint4 *) hi)[gc];
+        const float dxa = dx[gc]; const int sxa = sx[gc];
+        float qv = 0.0f;
+        #pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint32_t vlo[4], vhi[4];
+            wblk_unpack<WT>(wr[r], vlo, vhi);
+            const float dw = lane < nb ? h2f(wr[r].d) : 0.0f;
+            constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+            int sum = 0;
+            sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
+            sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
+            if (off) sum -= off * sxa;
+            const float acc = wave_sum(fmaf(dw * dxa, (float) sum, 0.0f));
+            qv = (lane & 7) == r ? acc : qv;                            // lane r (mod 8) keeps row r
+        }
+        if (lane < 8) {
+            float v = qv;
+            if (a.bias)       v = v + bias_v;
+            if (a.has_qscale) v = v * a.qscale;
+            qs[wave*8 + lane] = round_f16(v);                           // the attention rounds q to f16 (q_to_vec_dot)
+        }
+    }
+    __syncthreads();
+
+    // ---- attention over this wave's 16 keys (k_fattn_dec with 2 keys per lane) ------------------------------------------
+    float qf[8];
+    #pragma unroll
+    for (int e = 0; e < 8; e++) qf[e] = qs[dc*8 + e];
+    float sc[2];
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int key = kbeg + kg + 8*i;
+        const uint32_t w[4] = { kr[i].x, kr[i].y, kr[i].z, kr[i].w };
+        float s = 0.0f;
+        #pragma unroll
+        for (int e = 0; e < 4; e++) { s = fmaf(h2f((uint16_t) (w[e] & 0xFFFF)), qf[2*e], s); s = fmaf(h2f((uint16_t) (w[e] >> 16)), qf[2*e+1], s); }
+        s = group_sum<8>(s);
+        const float x = s * a.scale + (a.has_mask ? h2f(mkh[i]) : 0.0f);
+        sc[i] = key < a.n_kv ? x : -INFINITY;
+    }
+    float m = stride8_max(fmaxf(sc[0], sc[1]));
+    m = fmaxf(m, -1e30f);
+    float l = 0.0f, o[8];
+    #pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float pk = __expf(sc[i] - m);
+        l += pk;
+        const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
+        #pragma unroll
+        for (int e = 0; e < 4; e++) {
+            o[2*e]   = fmaf(pk, h2f((uint16_t) (w[e] & 0xFFFF)), o[2*e]);
+            o[2*e+1] = fmaf(pk, h2f((uint16_t) (w[e] >> 16)),    o[2*e+1]);
+        }
+    }
+    l = stride8_sum(l);
+    #pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = stride8_sum(o[e]);
+    if (kg == 0) {
+        *(float4 *) &wo[wave*64 + dc*8]     = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4 *) &wo[wave*64 + dc*8 + 4] = make_float4(o[4], o[5], o[6], o[7]);
+        if (dc == 0) { wml[wave*2] = m; wml[wave*2 + 1] = l; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float M = -1e30f;
+        #pragma unroll
+        for (int w = 0; w < 8; w++) M = fmaxf(M, wml[w*2]);
+        float O = 0.0f, L = 0.0f;
+        #pragma unroll
+        for (int w = 0; w < 8; w++) {
+            const float ww = __expf(wml[w*2] - M);
+            O = fmaf(ww, wo[w*64 + tid], O);
+            L = fmaf(ww, wml[w*2 + 1], L);
+        }
+        const int64_t rec = (int64_t) hq * a.nparts + p;                // T == 1
+        a.part_o[rec*64 + tid] = O;
+        if (tid == 0) { a.part_ml[rec*2] = M; a.part_ml[rec*2 + 1] = L; }
+    }
+}
+
+extern "C" int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc * d, const mi355x_tensor * k, const mi355x_tensor * v,
+                                        const mi355x_tensor * mask, float scale, mi355x_attn_partials * out) {
+    static const bool enabled = !(getenv("GGML_MI355X_QATTN") && !atoi(getenv("GGML_MI355X_QATTN")));
+    if (!enabled || d->T != 1 || d->nseg != 1 || !d->has_norm || !d->x || d->attn_part_o) return MI355X_E_UNSUPPORTED;
+    const int wt = d->seg[0].wtype, K = d->K, N = d->seg[0].N;
+    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0) return MI355X_E_UNSUPPORTED;
+    if (K % 32 || K > 2048 || N % 64 || d->seg[0].ep.gelu || d->seg[0].ep.residual) return MI355X_E_UNSUPPORTED;
+    if (((uintptr_t) d->x | (uintptr_t) d->ln_w | (uintptr_t) d->ln_b | (uintptr_t) d->seg[0].w) % 16) return MI355X_E_UNSUPPORTED;
+    const int H = N / 64, n_kv = (int) k->ne[1];
+    if (k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16 || k->ne[0] != 64 || v->ne[0] != 64 || v->ne[1] != n_kv || n_kv < 1 ||
+        k->ne[3] != 1 || v->ne[3] != 1 || k->nb[0] != 2 || v->nb[0] != 2 || k->ne[2] <= 0 || H % k->ne[2] || v->ne[2] <= 0 || H % v->ne[2]) return MI355X_E_UNSUPPORTED;
+    if (((uintptr_t) k->data | k->nb[1] | k->nb[2]) % 16 || ((uintptr_t) v->data | v->nb[1] | v->nb[2]) % 16) return MI355X_E_UNSUPPORTED;
+    if (mask && (mask->type != MI355X_TYPE_F16 || mask->ne[0] < n_kv || mask->nb[0] != 2 || mask->ne[2] != 1 || mask->ne[3] != 1)) return MI355X_E_UNSUPPORTED;
+    QAArgs a; memset(&a, 0, sizeof(a));
+    a.x = d->x; a.ln_w = d->ln_w; a.ln_b = d->ln_b; a.eps = d->eps; a.K = K;
+    a.w = d->seg[0].w; a.nbt = (int64_t) N * (K/32); a.bias = d->seg[0].ep.bias; a.qscale = d->seg[0].ep.scale; a.has_qscale = d->seg[0].ep.has_scale;
+    a.k = to_d(k); a.v = to_d(v); if (mask) a.m = to_d(mask);
+    a.has_mask = mask != nullptr; a.scale = scale; a.n_kv = n_kv; a.H = H;
+    a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
+    a.nparts = (n_kv + 127) / 128; a.dummy = ctx->gelu_tab;
+    mi355x_scratch_reset(ctx);
+    const size_t nrec = (size_t) H * a.nparts;
+    a.part_o  = (float *) mi355x_scratch_alloc(ctx, nrec * 64 * 4);
+    a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
+    if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
+    const dim3 grid(a.nparts, H), block(512);
+    const uint32_t lds = 4096 + (uint32_t) (K/32) * 40;
+    const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) mi355x_type_row_bytes(wt, K) * N + (double) K*4 + (double) nrec*66*4;
+    const double flops = 4.0 * (double) n_kv * 64 * H + 2.0 * (double) N * K;
+    int rc;
+    switch (wt) {
+        case MI355X_TYPE_Q4_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_0>, grid, block, lds, a, bytes, flops); break;
+        case MI355X_TYPE_Q5_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q5_0>, grid, block, lds, a, bytes, flops); break;
+        default:               rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q8_0>, grid, block, lds, a, bytes, flops); break;
+    }
+    if (rc) return rc;
+    out->part_o = a.part_o; out->part_ml = a.part_ml; out->nparts = a.nparts; out->T = 1; out->H = H;
+    return 0;
+}
+
 struct FC2Args { const float * part_o; const float * part_ml; int nparts, T, H; dtensor d; };
 __global__ void __launch_bounds__(64) k_fattn_combine2(const FC2Args a) {
     const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
