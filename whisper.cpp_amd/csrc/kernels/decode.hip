@@ -131,6 +131,83 @@ __device__ __forceinline__ void dg_q8_0_store(const float v[4], int e, int t, in
     if (w == 0) { dx[t*nb + b] = round_f16(d); sx[t*nb + b] = s; }
 }
 
+// ---- Q4_K support of the lean decode kernels -------------------------------------------------------------------
+// weights: one lane-unit = 64 elements = 32 bytes of nibbles (sub-blocks 2c: low nibbles, 2c+1: high nibbles) of a
+// 256-element super-block (ggml-common.h:327-338); activations: Q8_K (ggml-quants.c:2768-2805) in four 16-byte planes per
+// 64-element chunk + per-super-block scale + per-32-element sums (for the mins), as in the first-generation k_gemv.
+template <> struct wblk<MI355X_TYPE_Q4_K> { u32x4 q, q1; uint32_t dm; uint32_t sc[3]; uint16_t d; };
+
+// unit index ch (64-element chunk) of row `row`; nbt = total super-blocks of the tensor, nsb = super-blocks per row
+__device__ __forceinline__ void wblk_load_q4k(wblk<MI355X_TYPE_Q4_K> & r, const char * base, int64_t nbt, int64_t row, int nsb, int ch) {
+    const int64_t isb = row * nsb + (ch >> 2);
+    const u32x4 * q = (const u32x4 *) (base + isb*128 + (ch & 3)*32);
+    r.q  = __builtin_nontemporal_load(q);
+    r.q1 = __builtin_nontemporal_load(q + 1);
+    const uint32_t * sc = (const uint32_t *) (base + nbt*128 + isb*12);
+    r.sc[0] = sc[0]; r.sc[1] = sc[1]; r.sc[2] = sc[2];
+    r.dm = *((const uint32_t *) (base + nbt*140) + isb);
+    r.d = 0;
+}
+
+// quantize 4 consecutive values (one lane of a WAVE = one 256-element super-block) to Q8_K and store to LDS
+__device__ __forceinline__ void dg_q8_K_store(const float v[4], int e, int t, int K, int T, uint32_t * pl, float * dx, int * bs) {
+    const float mx = group_max<64>(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+    const float mn = -group_max<64>(-fminf(fminf(v[0], v[1]), fminf(v[2], v[3])));
+    const float amax = fmaxf(mx, -mn);
+    const float maxv = (mx >= -mn) ? mx : mn;                          // value with the largest magnitude (sign kept)
+    const int nch = K >> 6, nsb = K >> 8;
+    int q[4] = { 0, 0, 0, 0 };
+    float d = 0.0f;
+    if (amax != 0.0f) {
+        const float iscale = -127.0f / maxv;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) { const int r = (int) rintf(iscale * v[i]); q[i] = r < 127 ? r : 127; }
+        d = 1.0f / iscale;
+    }
+    const int s = group_sum_i<8>(q[0] + q[1] + q[2] + q[3]);             // sum over 32 elements
+    const uint32_t packed = (uint32_t) (q[0] & 0xFF) | ((uint32_t) (q[1] & 0xFF) << 8) | ((uint32_t) (q[2] & 0xFF) << 16) | ((uint32_t) (q[3] & 0xFF) << 24);
+    const int ch = e >> 6, within = e & 63, plane = within >> 4, w = (within & 15) >> 2;
+    pl[(((size_t) plane*T + t)*nch + ch)*4 + w] = packed;
+    if ((e & 31) == 0)  bs[t*(nsb*8) + (e >> 5)] = s;
+    if ((e & 255) == 0) dx[t*nsb + (e >> 8)] = d;
+}
+
+// dot of one 64-element weight unit with the Q8_K activations of column t: acc += dx*d*isum, accm += -dx*dmin*msum
+// (vec_dot q4_K x q8_K: ggml-cpu/quants.c:696-769)
+template <int T>
+__device__ __forceinline__ void wblk_dot_q4k(const wblk<MI355X_TYPE_Q4_K> & r, int ch, float live, int nch, int nsb,
+                                             const uint4 * pl, const float * dx, const int * bs, float * acc, float * accm) {
+    const int sb = ch >> 2, c = ch & 3;
+    const float dw = h2f((uint16_t) (r.dm & 0xFFFF)) * live, dminw = h2f((uint16_t) (r.dm >> 16)) * live;
+    int sc_lo, m_lo, sc_hi, m_hi;
+    q4k_scale_min(2*c,     (const uint8_t *) r.sc, sc_lo, m_lo);
+    q4k_scale_min(2*c + 1, (const uint8_t *) r.sc, sc_hi, m_hi);
+    const uint32_t w[8] = { r.q[0], r.q[1], r.q[2], r.q[3], r.q1[0], r.q1[1], r.q1[2], r.q1[3] };
+    #pragma unroll
+    for (int t = 0; t < T; t++) {
+        const uint4 a0 = pl[((size_t) 0*T + t)*nch + ch], a1 = pl[((size_t) 1*T + t)*nch + ch];
+        const uint4 a2 = pl[((size_t) 2*T + t)*nch + ch], a3 = pl[((size_t) 3*T + t)*nch + ch];
+        const uint32_t al[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+        const uint32_t ah[8] = { a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w };
+        int dlo = 0, dhi = 0;
+        #pragma unroll
+        for (int i = 0; i < 8; i++) {
+            dlo = __builtin_amdgcn_sdot4((int) (w[i] & 0x0F0F0F0Fu),        (int) al[i], dlo, false);
+            dhi = __builtin_amdgcn_sdot4((int) ((w[i] >> 4) & 0x0F0F0F0Fu), (int) ah[i], dhi, false);
+        }
+        const int isum = sc_lo*dlo + sc_hi*dhi;
+        const int msum = m_lo*bs[t*(nsb*8) + sb*8 + 2*c] + m_hi*bs[t*(nsb*8) + sb*8 + 2*c + 1];
+        const float dxv = dx[t*nsb + sb];
+        acc[t]  = fmaf(dxv*dw, (float) isum, acc[t]);
+        accm[t] = fmaf(-dxv*dminw, (float) msum, accm[t]);
+    }
+}
+
+// LDS bytes of the activation planes: Q8_0 family 40 B per 32 elements, Q8_K K + 4*K/256 + 4*K/32 bytes per column
+static inline size_t dg_act_bytes(int wt, int K, int T) {
+    return wt == MI355X_TYPE_Q4_K ? (size_t) T * ((size_t) K + (K/256)*4 + (K/32)*4) : (size_t) T * (K/32) * 40;
+}
+
 template <int WT, int T, int LPR>
 __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
     constexpr int U = DG_U(LPR), RPW = 64 / LPR;                      // blocks per lane per chunk, rows per wave pass
@@ -393,14 +470,16 @@ static int launch_gemv8(mi355x_ctx * ctx, const DGArgs & k, int T, int lpr, dim3
 // ---------------------------------------------------------------------------------------------------
 template <int WT, int T, int XS, int MODE, bool NSEG1>                              // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads)
 __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
-    constexpr int NU = XS == 1 ? 1 : 3;                                  // 32-element blocks per lane: K <= 2048 -> 1, K <= 5120 -> 3
+    constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
+    constexpr int NU = Q4K ? (XS == 1 ? 1 : 2) : (XS == 1 ? 1 : 3);      // units per lane: 32-element blocks (64-element chunks for Q4_K)
     constexpr int MAXP = 12;                                             // attention partial records per (head, query) handled in registers
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 4..8 waves per workgroup, one row each; the launcher picks ceil(K/256) waves when that lets a single activation slot
     // per thread cover the whole vector (K = 1280 -> 5 waves = 320 threads)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    const int K = a.K, nb = K >> 5, K4 = K >> 2;
+    const int K = a.K, nb = Q4K ? K >> 6 : K >> 5, K4 = K >> 2;           // nb = lane-units per row
+    const int nsb = K >> 8;
     const int ntot = a.ntot;
     const int grow = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
     int s = 0;
@@ -489,18 +568,23 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         const int ib0 = row * nb;
         #pragma unroll
         for (int u = 0; u < NU; u++) {
-            const int g = lane + 64*u;
-            wblk_load<WT>(wr[u], base, nbt, (int64_t) (ib0 + (g < nb ? g : nb - 1)));
+            const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+            if constexpr (Q4K) wblk_load_q4k(wr[u], base, nbt, row, nsb, gc);
+            else               wblk_load<WT>(wr[u], base, nbt, (int64_t) (ib0 + gc));
         }
     }
     __builtin_amdgcn_sched_barrier(0);
     DG_STAMP(1);                                                        // all loads issued
 
     float * red = (float *) smem;                                       // [2][T][8]
-    uint32_t * lo = (uint32_t *) (smem + 512);
+    uint32_t * lo = (uint32_t *) (smem + 512);                           // Q4_K: the four Q8_K planes [4][T][K/64] uint4
     uint32_t * hi = lo + (size_t) T*nb*4;
-    float * dx = (float *) (hi + (size_t) T*nb*4);
-    int *   sx = (int *) (dx + T*nb);
+    float * dx = Q4K ? (float *) (smem + 512 + (size_t) T*K) : (float *) (hi + (size_t) T*nb*4);
+    int *   sx = Q4K ? (int *) (dx + T*nsb) : (int *) (dx + T*nb);       // Q4_K: per-32-element sums
+    auto act_store = [&](const float v[4], int e, int t) {
+        if constexpr (Q4K) dg_q8_K_store(v, e, t, K, T, lo, dx, sx);
+        else               dg_q8_0_store(v, e, t, nb, lo, hi, dx, sx);
+    };
 
     // ---- activations -> registers ---------------------------------------------------------------------------------
     if constexpr (MODE == 2) {
@@ -592,7 +676,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
                 float o[4] = { (sel.x - mean) * rstd, (sel.y - mean) * rstd, (sel.z - mean) * rstd, (sel.w - mean) * rstd };
                 o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
                 o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
-                dg_q8_0_store(o, tid*4, t, nb, lo, hi, dx, sx);
+                act_store(o, tid*4, t);
             }
         }
         DG_STAMP(2);
@@ -639,7 +723,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
                     float o[4] = { (xr[t][i].x - mean[t]) * rstd[t], (xr[t][i].y - mean[t]) * rstd[t], (xr[t][i].z - mean[t]) * rstd[t], (xr[t][i].w - mean[t]) * rstd[t] };
                     o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
                     o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
-                    dg_q8_0_store(o, e4*4, t, nb, lo, hi, dx, sx);
+                    act_store(o, e4*4, t);
                 }
             }
         }
@@ -651,7 +735,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
                 const int e4 = tid + i*nthreads;
                 if (e4 < K4) {
                     const float v[4] = { xr[t][i].x, xr[t][i].y, xr[t][i].z, xr[t][i].w };
-                    dg_q8_0_store(v, e4*4, t, nb, lo, hi, dx, sx);
+                    act_store(v, e4*4, t);
                 }
             }
         }
@@ -666,27 +750,40 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     float acc[T];
     #pragma unroll
     for (int t = 0; t < T; t++) acc[t] = 0.0f;
-    #pragma unroll
-    for (int u = 0; u < NU; u++) {
-        const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
-        uint32_t vlo[4], vhi[4];
-        wblk_unpack<WT>(wr[u], vlo, vhi);
-        const float dw = g < nb ? h2f(wr[u].d) : 0.0f;
-        constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+    if constexpr (Q4K) {
+        float accm[T];
         #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const uint4 al = alo[(size_t) t*nb + gc], ah = ahi[(size_t) t*nb + gc];
-            int sum = 0;
-            sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
-            if (off) sum -= off * sx[t*nb + gc];
-            acc[t] = fmaf(dw * dx[t*nb + gc], (float) sum, acc[t]);
+        for (int t = 0; t < T; t++) accm[t] = 0.0f;
+        #pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+            wblk_dot_q4k<T>(wr[u], gc, g < nb ? 1.0f : 0.0f, nb, nsb, alo, dx, sx, acc, accm);
+        }
+        #pragma unroll
+        for (int t = 0; t < T; t++) acc[t] += accm[t];
+    } else {
+        #pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+            uint32_t vlo[4], vhi[4];
+            wblk_unpack<WT>(wr[u], vlo, vhi);
+            const float dw = g < nb ? h2f(wr[u].d) : 0.0f;
+            constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+            #pragma unroll
+            for (int t = 0; t < T; t++) {
+                const uint4 al = alo[(size_t) t*nb + gc], ah = ahi[(size_t) t*nb + gc];
+                int sum = 0;
+                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
+                if (off) sum -= off * sx[t*nb + gc];
+                acc[t] = fmaf(dw * dx[t*nb + gc], (float) sum, acc[t]);
+            }
         }
     }
     DG_STAMP(5);                                                        // weights arrived, dots done
@@ -761,8 +858,8 @@ static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid,
 int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
     const int wt = d->seg[0].wtype, K = d->K, T = d->T;
-    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0) return MI355X_E_UNSUPPORTED;
-    if (K <= 0 || K % 32) return MI355X_E_UNSUPPORTED;
+    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;
+    if (K <= 0 || K % 32 || (wt == MI355X_TYPE_Q4_K && K % 256)) return MI355X_E_UNSUPPORTED;
     const bool from_part = d->attn_part_o != nullptr;
     if (from_part) {
         if (d->x || !d->attn_part_ml || d->attn_nparts < 1 || d->attn_nparts > 64 || K % 64 || d->has_norm) return MI355X_E_UNSUPPORTED;
@@ -783,7 +880,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         if (g.dst_type != MI355X_TYPE_F32 && g.dst_type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
         k.row_start[s] = ntot;
         DGSeg & o = k.seg[s];
-        o.w = g.w; o.N = g.N; o.nbt = (int64_t) g.N * (K / 32);
+        o.w = g.w; o.N = g.N; o.nbt = wt == MI355X_TYPE_Q4_K ? (int64_t) g.N * (K / 256) : (int64_t) g.N * (K / 32);
         o.bias = g.ep.bias; o.scale = g.ep.scale; o.has_scale = g.ep.has_scale; o.gelu = g.ep.gelu;
         o.residual = g.ep.residual; o.res_nb1 = g.ep.residual_nb1;
         o.dst = g.dst; o.dst_nb1 = g.dst_nb1; o.dst_f16 = g.dst_type == MI355X_TYPE_F16;
@@ -796,7 +893,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const double flops0 = 2.0 * ntot * K * T;
     static const int env_lean = getenv("GGML_MI355X_GEMV_LEAN") ? atoi(getenv("GGML_MI355X_GEMV_LEAN")) : 1;
     if (env_lean && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
-        const size_t lds_row = dg_lds_bytes(K, T, false) + 256;      // 512-byte reduction header
+        const size_t lds_row = 512 + dg_act_bytes(wt, K, T);          // 512-byte reduction header + activation planes
         const int rpb = gemv_row_waves(K);
         const dim3 grid((ntot + rpb - 1) / rpb);
         int rc = MI355X_E_UNSUPPORTED;
@@ -804,9 +901,11 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
             case MI355X_TYPE_Q4_0: rc = launch_gemv_row<MI355X_TYPE_Q4_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
             case MI355X_TYPE_Q5_0: rc = launch_gemv_row<MI355X_TYPE_Q5_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
             case MI355X_TYPE_Q8_0: rc = launch_gemv_row<MI355X_TYPE_Q8_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
+            case MI355X_TYPE_Q4_K: rc = launch_gemv_row<MI355X_TYPE_Q4_K>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
         }
         if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
+    if (wt == MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;            // k_gemv8 has no Q4_K path: first-generation kernel
     if (lds > 64*1024) return MI355X_E_UNSUPPORTED;
     if (staged && ((size_t) T * (K/32) * 40) % 16) return MI355X_E_UNSUPPORTED;      // float4 alignment of the staging area
     // geometry: latency-bound regime => as many waves as the matrix allows, up to ~16 per CU: lanes per row LPR such that
