@@ -223,6 +223,10 @@ MI355X_API int mi355x_cpy(mi355x_ctx * ctx, const mi355x_tensor * src, const mi3
 
 /* ggml_get_rows (ggml/src/ggml.c:3891; CPU ggml-cpu/ops.cpp:4850-5017): src F32/F16/quantized(planar), idx I32 */
 MI355X_API int mi355x_get_rows(mi355x_ctx * ctx, const mi355x_tensor * src, const mi355x_tensor * idx, const mi355x_tensor * dst);
+/* ggml_add(ggml_get_rows(src, idx), ggml_get_rows(add, add_idx)) in one launch: token + positional embedding of the
+ * decoder (src/whisper.cpp:2524-2526).  add: F32 rows; idx, add_idx: 1-D I32 of equal length */
+MI355X_API int mi355x_get_rows_add(mi355x_ctx * ctx, const mi355x_tensor * src, const mi355x_tensor * idx,
+                                   const mi355x_tensor * add, const mi355x_tensor * add_idx, const mi355x_tensor * dst);
 
 /* ggml_im2col, 1-D case used by ggml_conv_1d (ggml/src/ggml.c:4468-4565; CPU ggml-cpu/ops.cpp:6437-6517).
  * x: F32 [IW, IC, N], dst: F16 or F32 [IC*KW, OW, N] */

@@ -399,6 +399,18 @@ int main(int argc, char ** argv) {
         }, false, true);
     }
 
+    // token + positional embedding (W:2524-2526): get_rows(quantized) + get_rows(f32), fused into one launch by the planner
+    for (ggml_type wt : { GGML_TYPE_Q5_0, GGML_TYPE_Q8_0, GGML_TYPE_Q4_0, GGML_TYPE_Q4_K, GGML_TYPE_F16 }) for (int T : { 1, 5, 40 }) {
+        char nm[128]; snprintf(nm, sizeof(nm), "embed_%s_T%d", tname(wt), T);
+        run_case(nm, [=](builder & b) {
+            ggml_tensor * te = b.randn(wt, {1280, 900}, 0.05f);
+            ggml_tensor * pe = b.randn(GGML_TYPE_F32, {1280, 448}, 0.02f);
+            ggml_tensor * ids = b.leaf(GGML_TYPE_I32, {T}, [](int64_t i) { return (float) ((i * 131 + 7) % 900); });
+            ggml_tensor * pos = b.leaf(GGML_TYPE_I32, {T}, [](int64_t i) { return (float) (i + 3); });
+            return std::vector<ggml_tensor *>{ ggml_add(b.ctx, ggml_get_rows(b.ctx, te, ids), ggml_get_rows(b.ctx, pe, pos)) };
+        });
+    }
+
     // cross-attention block of whisper_build_graph_decoder (W:2684-2770): LN -> Q (+bias, *scale) -> flash_attn over the
     // F16 cross KV (no mask) -> O-projection + bias + residual.  T = 1 takes the single-launch LN+Q+attention kernel.
     for (ggml_type wt : wtypes) for (int T : { 1, 5 }) for (int n_kv : { 1536, 200 }) {

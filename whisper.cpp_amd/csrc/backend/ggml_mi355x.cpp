@@ -607,7 +607,7 @@ static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const
         const bool x_is_fa = x->view_src == fa && x->view_offs == 0 && x->type == GGML_TYPE_F32 && ggml_is_contiguous(x) &&
                              x->ne[0] == H*64 && x->ne[1] == T && x->ne[2] == 1 && x->ne[3] == 1 &&
                              use_count(g, x) == 1 && !(x->flags & GGML_TENSOR_FLAG_OUTPUT);
-        if (x_is_fa && is_quant_type(w->type) && w->type != GGML_TYPE_Q4_K && ggml_is_contiguous(w) && ggml_n_dims(w) <= 2 && w->ne[0] == H*64 &&
+        if (x_is_fa && is_quant_type(w->type) && ggml_is_contiguous(w) && ggml_n_dims(w) <= 2 && w->ne[0] == H*64 &&
             parse_mm_chain(g, j, true, ch)) {
             mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
             d.K = (int) (H*64); d.T = (int) T; d.nseg = 1;
@@ -774,6 +774,22 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
                 else i = c.end;
                 b->act_src = nullptr;
             }
+        } else if (n->op == GGML_OP_GET_ROWS && b->fuse) {
+            // token embedding + positional embedding: get_rows, get_rows, add -> one launch
+            rc = MI355X_E_UNSUPPORTED;
+            const int j1 = next_real(g, i), j2 = j1 < g->n_nodes ? next_real(g, j1) : g->n_nodes;
+            if (j2 < g->n_nodes && g->nodes[j1]->op == GGML_OP_GET_ROWS && g->nodes[j2]->op == GGML_OP_ADD) {
+                const ggml_tensor * ga = n, * gb = g->nodes[j1], * ad = g->nodes[j2];
+                const bool pair = (ad->src[0] == ga && ad->src[1] == gb) || (ad->src[0] == gb && ad->src[1] == ga);
+                if (pair && can_elide(g, ga, 1) && can_elide(g, gb, 1) && ggml_are_same_shape(ga, gb) && ggml_are_same_shape(ad, ga) &&
+                    ad->type == GGML_TYPE_F32 && ggml_is_contiguous(ad) && gb->src[0]->type == GGML_TYPE_F32) {
+                    mi355x_tensor sa = to_mt(ga->src[0]), ia = to_mt(ga->src[1]), sb = to_mt(gb->src[0]), ib = to_mt(gb->src[1]), d = to_mt(ad);
+                    rc = mi355x_get_rows_add(b->k, &sa, &ia, &sb, &ib, &d);
+                    if (rc != MI355X_E_UNSUPPORTED) i = j2;
+                }
+            }
+            if (rc == MI355X_E_UNSUPPORTED) rc = run_node(b, n);
+            b->act_src = nullptr;
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->fuse && n->src[0]->ne[1] <= 8) {
             int end = i, rc2 = MI355X_E_UNSUPPORTED;
             if (try_fattn_gemv(b, g, i, end, rc2)) { rc = rc2; i = end; }

@@ -2,6 +2,7 @@
 #include "common.h"
 #include <hip/hip_ext.h>
 #include <cxxabi.h>
+#include <chrono>
 #include <mutex>
 
 #include <math.h>
@@ -107,6 +108,18 @@ static void prof_drain(mi355x_ctx * ctx) {
 
 extern "C" int mi355x_ctx_synchronize(mi355x_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
+    // a decode step is ~1 ms of GPU work and the caller (whisper_decode) cannot do anything until it is done: poll the
+    // stream for a few milliseconds before falling back to the blocking wait (whose wake-up costs tens of microseconds)
+    static const int spin_us = getenv("GGML_MI355X_SYNC_SPIN_US") ? atoi(getenv("GGML_MI355X_SYNC_SPIN_US")) : 4000;
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) { if (ctx->prof) prof_drain(ctx); return 0; }
+            if (q != hipErrorNotReady) break;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+        }
+    }
     HIP_OK(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) prof_drain(ctx);
     return 0;

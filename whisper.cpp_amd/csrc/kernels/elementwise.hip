@@ -215,7 +215,9 @@ extern "C" int mi355x_cpy(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355
 // -------------------------------------------------------------------------------------------------
 // get_rows (ggml-cpu/ops.cpp:4850-5017): dst[:, i10, i11, i12] = src[:, idx[i10,i11,i12], i11, i12]
 // -------------------------------------------------------------------------------------------------
-struct GetRowsArgs { dtensor s, idx, d; int type; int64_t nbt; };
+// optional fused second gather + add (token embedding + positional embedding, src/whisper.cpp:2524-2526):
+//   dst[:, r] = src[:, idx[r]] + add[:, add_idx[r]]     (add: F32 rows, 1-D index of the same length)
+struct GetRowsArgs { dtensor s, idx, d; int type; int64_t nbt; const char * add; int64_t add_nb1; const int32_t * add_idx; int64_t add_rows; };
 template <int TYPE>
 __global__ void __launch_bounds__(256) k_get_rows(const GetRowsArgs a) {
     const int64_t r = blockIdx.x;     // flattened (i10, i11, i12)
@@ -224,26 +226,52 @@ __global__ void __launch_bounds__(256) k_get_rows(const GetRowsArgs a) {
     float * dst = (float *) (a.d.data + i10*a.d.nb[1] + i11*a.d.nb[2] + i12*a.d.nb[3]);
     const int64_t ne0 = a.s.ne[0];
     if (row < 0 || row >= a.s.ne[1]) return;
+    const float * addrow = nullptr;
+    if (a.add) {
+        const int32_t ar = a.add_idx[r];
+        if (ar < 0 || ar >= a.add_rows) return;
+        addrow = (const float *) (a.add + (int64_t) ar*a.add_nb1);
+    }
     if constexpr (TYPE == MI355X_TYPE_F32 || TYPE == MI355X_TYPE_F16) {
         const char * src = a.s.data + (int64_t) row*a.s.nb[1] + i11*a.s.nb[2] + i12*a.s.nb[3];
-        for (int64_t i = threadIdx.x; i < ne0; i += 256)
-            dst[i] = TYPE == MI355X_TYPE_F32 ? ((const float *) src)[i] : h2f(((const uint16_t *) src)[i]);
+        for (int64_t i = threadIdx.x; i < ne0; i += 256) {
+            const float v = TYPE == MI355X_TYPE_F32 ? ((const float *) src)[i] : h2f(((const uint16_t *) src)[i]);
+            dst[i] = addrow ? v + addrow[i] : v;
+        }
     } else {
         const qplanes<TYPE> p(a.s.data, a.nbt);
         const int64_t nb32 = ne0 / 32;                     // 32-element groups in a row
         for (int64_t g = threadIdx.x; g < nb32; g += 256) {
             float v[32];
             dequant_block32<TYPE>(p, (int64_t) row * nb32 + g, v);
+            if (addrow) {
+                #pragma unroll
+                for (int j = 0; j < 32; j += 4) { const float4 b = *(const float4 *) (addrow + g*32 + j); v[j] += b.x; v[j+1] += b.y; v[j+2] += b.z; v[j+3] += b.w; }
+            }
             #pragma unroll
             for (int j = 0; j < 32; j += 4) *(float4 *) (dst + g*32 + j) = make_float4(v[j], v[j+1], v[j+2], v[j+3]);
         }
     }
 }
+static int get_rows_impl(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx, const mi355x_tensor * d,
+                         const mi355x_tensor * add, const mi355x_tensor * add_idx);
 extern "C" int mi355x_get_rows(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx, const mi355x_tensor * d) {
+    return get_rows_impl(ctx, s, idx, d, nullptr, nullptr);
+}
+extern "C" int mi355x_get_rows_add(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx,
+                                   const mi355x_tensor * add, const mi355x_tensor * add_idx, const mi355x_tensor * d) {
+    if (!add || !add_idx || add->type != MI355X_TYPE_F32 || add->nb[0] != 4 || add->ne[0] != s->ne[0] || add->ne[2] != 1 || add->ne[3] != 1 ||
+        add_idx->type != MI355X_TYPE_I32 || add_idx->nb[0] != 4 || add_idx->ne[1] != 1 || add_idx->ne[2] != 1 || idx->ne[1] != 1 || idx->ne[2] != 1 ||
+        add_idx->ne[0] != idx->ne[0] || ((uintptr_t) add->data % 16) || (add->nb[1] % 16)) return MI355X_E_UNSUPPORTED;
+    return get_rows_impl(ctx, s, idx, d, add, add_idx);
+}
+static int get_rows_impl(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx, const mi355x_tensor * d,
+                         const mi355x_tensor * add, const mi355x_tensor * add_idx) {
     if (idx->type != MI355X_TYPE_I32 || d->type != MI355X_TYPE_F32 || d->nb[0] != 4) return MI355X_E_UNSUPPORTED;
     const int64_t nr = idx->ne[0]*idx->ne[1]*idx->ne[2];
     if (nr == 0) return 0;
-    GetRowsArgs k = { to_d(s), to_d(idx), to_d(d), s->type, 0 };
+    GetRowsArgs k = { to_d(s), to_d(idx), to_d(d), s->type, 0, nullptr, 0, nullptr, 0 };
+    if (add) { k.add = (const char *) add->data; k.add_nb1 = add->nb[1]; k.add_idx = (const int32_t *) add_idx->data; k.add_rows = add->ne[1]; }
     const double bytes = (double) nr * (mi355x_type_row_bytes(s->type, s->ne[0]) + s->ne[0]*4.0);
     const dim3 g((uint32_t) nr), b(256);
     if (mi355x_type_is_quantized(s->type)) {
