@@ -1,0 +1,73 @@
+// Full-pipeline drop-in check: whisper_full() — mel front end, encoder, greedy / beam-search decoding loop, token
+// timestamps bookkeeping, all of it the UNMODIFIED reference — once on the reference CPU backend and once with the MI355X
+// plugin, on the same synthetic 16 kHz signal and the same model file.  Prints one JSON object with the token sequences of
+// both runs.  Random-weight models produce meaningless text; what is compared is that both back ends walk the same path.
+// TEST code (links the reference libraries).
+#include "whisper.h"
+#include "ggml-backend.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+static void log_quiet(enum ggml_log_level level, const char * text, void *) { if (level == GGML_LOG_LEVEL_ERROR) fputs(text, stderr); }
+
+// deterministic speech-like signal: three modulated chirps + LCG noise, 16 kHz, f32 in [-1, 1]
+static std::vector<float> synth_pcm(int n) {
+    std::vector<float> x(n);
+    uint32_t lcg = 12345;
+    for (int i = 0; i < n; i++) {
+        const double t = i / 16000.0;
+        double v = 0.35 * sin(2*M_PI*(180 + 60*sin(2*M_PI*0.7*t))*t) + 0.20 * sin(2*M_PI*(700 + 300*sin(2*M_PI*1.3*t))*t) + 0.10 * sin(2*M_PI*(2300 + 500*sin(2*M_PI*0.4*t))*t);
+        v *= 0.5 * (1 + sin(2*M_PI*3.1*t)) * (fmod(t, 2.0) < 1.6 ? 1.0 : 0.0);
+        lcg = lcg * 1664525u + 1013904223u;
+        v += 0.02 * (((lcg >> 8) & 0xFFFF) / 32768.0 - 1.0);
+        x[i] = (float) fmax(-1.0, fmin(1.0, v));
+    }
+    return x;
+}
+
+static std::vector<int> run(const char * model, bool gpu, int strategy, int beam, const std::vector<float> & pcm, int max_tokens) {
+    whisper_context_params cp = whisper_context_default_params();
+    cp.use_gpu = gpu; cp.gpu_device = 0; cp.flash_attn = true;
+    whisper_context * ctx = whisper_init_from_file_with_params(model, cp);
+    if (!ctx) { fprintf(stderr, "model load failed\n"); exit(3); }
+    whisper_full_params p = whisper_full_default_params((whisper_sampling_strategy) strategy);
+    p.n_threads = 8; p.print_progress = false; p.print_realtime = false; p.print_timestamps = false; p.print_special = false;
+    p.no_context = true; p.no_timestamps = true; p.single_segment = true; p.suppress_blank = false; p.suppress_nst = false;
+    p.temperature = 0.0f; p.temperature_inc = 0.0f;            // no temperature fallback: one deterministic pass
+    p.max_tokens = max_tokens; p.language = "en";
+    p.greedy.best_of = 1; p.beam_search.beam_size = beam;
+    if (whisper_full(ctx, p, pcm.data(), (int) pcm.size()) != 0) { fprintf(stderr, "whisper_full failed\n"); exit(4); }
+    std::vector<int> toks;
+    for (int s = 0; s < whisper_full_n_segments(ctx); s++)
+        for (int t = 0; t < whisper_full_n_tokens(ctx, s); t++) toks.push_back(whisper_full_get_token_id(ctx, s, t));
+    whisper_free(ctx);
+    return toks;
+}
+
+int main(int argc, char ** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: %s model.bin [max_tokens=24]\n  env GGML_MI355X_PLUGIN=path\n", argv[0]); return 2; }
+    const int max_tokens = argc > 2 ? atoi(argv[2]) : 24;
+    whisper_log_set(log_quiet, nullptr);
+    const char * plugin = getenv("GGML_MI355X_PLUGIN");
+    const bool selftest = plugin && !strcmp(plugin, "cpu");
+    if (!selftest && (!plugin || !ggml_backend_load(plugin))) { fprintf(stderr, "cannot load plugin (GGML_MI355X_PLUGIN)\n"); return 3; }
+    const std::vector<float> pcm = synth_pcm(16000 * 11);
+    printf("{\"model\": \"%s\"", argv[1]);
+    const struct { const char * name; int strategy, beam; } modes[] = { { "greedy", WHISPER_SAMPLING_GREEDY, 1 }, { "beam5", WHISPER_SAMPLING_BEAM_SEARCH, 5 } };
+    for (const auto & m : modes) {
+        const std::vector<int> a = run(argv[1], false, m.strategy, m.beam, pcm, max_tokens);
+        const std::vector<int> b = run(argv[1], !selftest, m.strategy, m.beam, pcm, max_tokens);
+        size_t same = 0; while (same < a.size() && same < b.size() && a[same] == b[same]) same++;
+        printf(",\n \"%s\": {\"n_cpu\": %zu, \"n_gpu\": %zu, \"identical_prefix\": %zu, \"cpu\": [", m.name, a.size(), b.size(), same);
+        for (size_t i = 0; i < a.size(); i++) printf("%s%d", i ? ", " : "", a[i]);
+        printf("], \"gpu\": [");
+        for (size_t i = 0; i < b.size(); i++) printf("%s%d", i ? ", " : "", b[i]);
+        printf("]}");
+    }
+    printf("}\n");
+    return 0;
+}

@@ -563,6 +563,26 @@ def test_plugin_model_parity(plugin_env, arch, qtype):
     assert d["batch5"]["nmse"] < 5e-4 and d["batch48"]["nmse"] < 5e-4, d
 
 
+@pytest.mark.parametrize("arch,qtype", [("micro", "q5_0"), ("base.en", "q5_0"), ("base.en", "q8_0")])
+def test_plugin_whisper_full_pipeline(plugin_env, arch, qtype):
+    """whisper_full() end to end (mel front end, encoder, sampling loop — all unmodified reference code) on a synthetic
+    11 s signal: the token sequence of the plugin run equals the CPU run for greedy decoding; beam search (5 beams, batched
+    5-token decode steps + KV-cache bookkeeping) is reported and must agree on a prefix."""
+    from whisper_cpp_amd.synth_model import make_model
+    m = make_model(arch, qtype)
+    env = dict(plugin_env, GGML_MI355X_STRICT="1")
+    r = subprocess.run([str(_native("full_parity")), str(m), "24"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    keep = ROOT / "gpurun_out"
+    if keep.exists():
+        (keep / f"full_parity_{arch}_{qtype}.json").write_text(r.stdout)
+    g = d["greedy"]
+    assert g["n_cpu"] > 4 and g["cpu"] == g["gpu"], g
+    bm = d["beam5"]
+    assert bm["identical_prefix"] >= min(8, bm["n_cpu"]), bm
+
+
 def test_bench_smoke():
     """bench.py end to end on a small model: one JSON line with the contract's keys, roofline measured live"""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--arch", "base.en", "--qtype", "q5_0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
