@@ -218,7 +218,7 @@ def main():
         chunk()
     w.whisper_reset_timings(ctx)
     p.ggml_backend_mi355x_host_times.argtypes = [C.POINTER(C.c_double)]
-    host0 = (C.c_double * 12)()
+    host0 = (C.c_double * 13)()
     p.ggml_backend_mi355x_host_times(host0)
     # barrier + synchronize on both sides, exactly K steps, MAX over ranks.  Every whisper_encode / whisper_decode
     # returns only after the backend's stream is drained (ggml_backend_sched_synchronize), torch.cuda.synchronize()
@@ -226,9 +226,9 @@ def main():
     elapsed_s = timed_region(chunk, a.steps, dist, torch.cuda.synchronize, "cuda")
     tm = w.whisper_get_timings(ctx).contents
     encode_ms, decode_ms = float(tm.encode_ms), float(tm.decode_ms)
-    host1 = (C.c_double * 12)()
+    host1 = (C.c_double * 13)()
     p.ggml_backend_mi355x_host_times(host1)
-    host_ms = [host1[i] - host0[i] for i in range(12)]          # host-side time inside the backend during the timed region only
+    host_ms = [host1[i] - host0[i] for i in range(13)]          # host-side time inside the backend during the timed region only
 
     # reported beside the headline (bench.cpp:138-152): 5-token batches and 256-token prompts
     w.whisper_reset_timings(ctx)
@@ -259,7 +259,7 @@ def main():
             "hip_graph": {"graph_computes": int(stats[0]), "replays": int(stats[1]), "patched_nodes": int(stats[2]), "builds": int(stats[3]),
                           "host_ms_in_timed_region": {"plan": round(host_ms[0], 2), "patch": round(host_ms[1], 2), "launch": round(host_ms[2], 2), "eager": round(host_ms[3], 2),
                                             "set_tensor": round(host_ms[4], 2), "get_tensor": round(host_ms[5], 2), "cpy_tensor": round(host_ms[6], 2), "synchronize": round(host_ms[7], 2),
-                                            "calls": [int(host_ms[8 + i]) for i in range(4)]}},
+                                            "calls": [int(host_ms[8 + i]) for i in range(4)], "gpu_span": round(host_ms[12], 2)}},
         }
         if prof:
             dom = max(prof, key=lambda r: r["total_ms"])

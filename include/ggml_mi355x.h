@@ -60,7 +60,7 @@ GGML_MI355X_API void ggml_backend_mi355x_prof_enable_all(int on);
 GGML_MI355X_API void ggml_backend_mi355x_prof_reset_all(void);
 GGML_MI355X_API int  ggml_backend_mi355x_prof_report_all(struct ggml_mi355x_prof_row * rows, int cap);
 GGML_MI355X_API void ggml_backend_mi355x_stats(uint64_t * out);
-/* out[12]: [0..3] host milliseconds inside graph_compute {planning + launch recording, hipGraph node patching, hipGraphLaunch,
+/* out[13]: [12] GPU-side span of all completed graph_computes (ms, hipEvent pairs on the compute stream); [0..3] host milliseconds inside graph_compute {planning + launch recording, hipGraph node patching, hipGraphLaunch,
  * eager launches}; [4..7] milliseconds inside {set_tensor, get_tensor, cpy_tensor, synchronize}; [8..11] their call counts */
 GGML_MI355X_API void ggml_backend_mi355x_host_times(double * out);
 

@@ -315,7 +315,21 @@ struct mi_backend_ctx {
     uint64_t n_graph_compute = 0, n_replay = 0, n_update = 0, n_rebuild = 0;
     bool     recording = false, record_abort = false;
     double   t_plan_ms = 0, t_patch_ms = 0, t_launch_ms = 0, t_eager_ms = 0;    // host time inside graph_compute
+    // GPU-side span of every graph_compute (first launch .. last kernel done), from a ring of hipEvent pairs on the stream
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> span_ev;
+    int      span_next = 0, span_pending = 0;
+    double   t_gpu_span_ms = 0;
 };
+static double g_total_gpu_span_ms = 0;
+
+static void mi_span_drain(mi_backend_ctx * b) {          // all pending pairs must have completed (caller synchronized the stream)
+    for (int i = 0; i < b->span_pending; i++) {
+        const int idx = (b->span_next - 1 - i + 2 * (int) b->span_ev.size()) % (int) b->span_ev.size();
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->span_ev[idx].first, b->span_ev[idx].second) == hipSuccess) b->t_gpu_span_ms += ms;
+    }
+    b->span_pending = 0;
+}
 
 static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -899,6 +913,8 @@ static void mi_backend_free(ggml_backend_t backend) {
     mi355x_ctx_synchronize(b->k);
     if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 " replays=%" PRIu64 " node-updates=%" PRIu64 " rebuilds=%" PRIu64 "\n",
                            b->name.c_str(), b->n_graph_compute, b->n_replay, b->n_update, b->n_rebuild);
+    if (b->span_pending) mi_span_drain(b);
+    for (auto & e : b->span_ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     for (auto & c : b->gcache) { if (c.exec) (void) hipGraphExecDestroy(c.exec); if (c.graph) (void) hipGraphDestroy(c.graph); }
     if (b->act) (void) hipFree(b->act);
     {
@@ -906,6 +922,7 @@ static void mi_backend_free(ggml_backend_t backend) {
         for (size_t i = 0; i < g_backends.size(); i++) if (g_backends[i] == b) { g_backends.erase(g_backends.begin() + i); break; }
         g_total_stats[0] += b->n_graph_compute; g_total_stats[1] += b->n_replay; g_total_stats[2] += b->n_update; g_total_stats[3] += b->n_rebuild;
         g_total_host_ms[0] += b->t_plan_ms; g_total_host_ms[1] += b->t_patch_ms; g_total_host_ms[2] += b->t_launch_ms; g_total_host_ms[3] += b->t_eager_ms;
+        g_total_gpu_span_ms += b->t_gpu_span_ms;
     }
     mi355x_ctx_destroy(b->k);
     delete b;
@@ -917,6 +934,7 @@ static void mi_backend_synchronize(ggml_backend_t backend) {
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     (void) hipSetDevice(b->device);
     mi355x_ctx_synchronize(b->k);
+    if (b->span_pending) mi_span_drain(b);
 }
 
 static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
@@ -932,6 +950,19 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
             b->io_seen = io.seq.load();
         }
     }
+    // GPU span bookkeeping (two event records per call)
+    static const bool span_on = env_flag("GGML_MI355X_SPAN", true);
+    int span_idx = -1;
+    if (span_on && !b->prof) {
+        if (b->span_ev.empty()) {
+            b->span_ev.resize(64);
+            for (auto & e : b->span_ev) { (void) hipEventCreate(&e.first); (void) hipEventCreate(&e.second); }
+        }
+        if (b->span_pending >= (int) b->span_ev.size()) { mi355x_ctx_synchronize(b->k); mi_span_drain(b); }
+        span_idx = b->span_next; b->span_next = (b->span_next + 1) % (int) b->span_ev.size(); b->span_pending++;
+        (void) hipEventRecord(b->span_ev[span_idx].first, (hipStream_t) mi355x_ctx_stream(b->k));
+    }
+    struct span_end { mi_backend_ctx * b; int idx; ~span_end() { if (idx >= 0) (void) hipEventRecord(b->span_ev[idx].second, (hipStream_t) mi355x_ctx_stream(b->k)); } } span_guard{ b, span_idx };
     // graphs pay off when the launch sequence is long and launch-bound (decoder step); profiling needs eager launches
     const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32;
     if (use_graph) {
@@ -1153,12 +1184,15 @@ void ggml_backend_mi355x_stats(uint64_t * out) {
 
 // out[0..3] = host milliseconds spent inside graph_compute: planning (graph walk + launch recording), hipGraph node
 // patching, hipGraphLaunch, eager launches — over all backends so far; out[4..7] = milliseconds inside set_tensor,
-// get_tensor, cpy_tensor, synchronize; out[8..11] = their call counts
+// get_tensor, cpy_tensor, synchronize; out[8..11] = their call counts; out[12] = GPU-side span (first launch .. last kernel
+// done) summed over all completed graph_computes, from hipEvent pairs on the compute stream
 void ggml_backend_mi355x_host_times(double * out) {
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     for (int i = 0; i < 4; i++) out[i] = g_total_host_ms[i];
     for (auto * b : g_backends) { out[0] += b->t_plan_ms; out[1] += b->t_patch_ms; out[2] += b->t_launch_ms; out[3] += b->t_eager_ms; }
     for (int i = 0; i < 4; i++) { out[4 + i] = g_io_ns[i].load() * 1e-6; out[8 + i] = (double) g_io_calls[i].load(); }
+    out[12] = g_total_gpu_span_ms;
+    for (auto * b : g_backends) out[12] += b->t_gpu_span_ms;       // completed (drained) graph_computes only
 }
 
 int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {

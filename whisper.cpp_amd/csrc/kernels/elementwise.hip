@@ -125,10 +125,50 @@ __global__ void __launch_bounds__(256) k_norm(const NormArgs a) {
         y[i] = r;
     }
 }
+// rows of up to 2048 elements (every Whisper width): the row lives in registers (clamped 16-byte loads, all in flight at
+// once), one pass over memory instead of three
+__global__ void __launch_bounds__(256) k_norm_v4(const NormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.nrows) return;
+    const int64_t i1 = row % a.x.ne[1], i2 = (row / a.x.ne[1]) % a.x.ne[2], i3 = row / (a.x.ne[1]*a.x.ne[2]);
+    const float * x = (const float *) (a.x.data + i1*a.x.nb[1] + i2*a.x.nb[2] + i3*a.x.nb[3]);
+    float * y = (float *) (a.y.data + i1*a.y.nb[1] + i2*a.y.nb[2] + i3*a.y.nb[3]);
+    const int n = (int) a.x.ne[0], n4 = n >> 2;
+    float4 xr[8];
+    #pragma unroll
+    for (int i = 0; i < 8; i++) { const int e4 = lane + 64*i; xr[i] = *(const float4 *) (x + (size_t) (e4 < n4 ? e4 : n4 - 1)*4); }
+    float s = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) if (lane + 64*i < n4) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
+    const float mean = wave_sum(s) / n;
+    float v = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (lane + 64*i < n4) {
+            const float d0 = xr[i].x - mean, d1 = xr[i].y - mean, d2 = xr[i].z - mean, d3 = xr[i].w - mean;
+            v += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+        }
+    }
+    const float sc = 1.0f / sqrtf(wave_sum(v) / n + a.eps);
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int e4 = lane + 64*i;
+        if (e4 < n4) {
+            float r[4] = { (xr[i].x - mean) * sc, (xr[i].y - mean) * sc, (xr[i].z - mean) * sc, (xr[i].w - mean) * sc };
+            if (a.w) { const float4 w = *(const float4 *) (a.w + e4*4); r[0] = r[0]*w.x; r[1] = r[1]*w.y; r[2] = r[2]*w.z; r[3] = r[3]*w.w; }
+            if (a.b) { const float4 b = *(const float4 *) (a.b + e4*4); r[0] = r[0]+b.x; r[1] = r[1]+b.y; r[2] = r[2]+b.z; r[3] = r[3]+b.w; }
+            *(float4 *) (y + (size_t) e4*4) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
 extern "C" int mi355x_norm(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y, float eps, const float * w, const float * b) {
     if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
     NormArgs k = { to_d(x), to_d(y), eps, w, b, t_nrows(x) };
     if (k.nrows == 0 || x->ne[0] == 0) return 0;
+    const bool v4 = x->ne[0] % 4 == 0 && x->ne[0] <= 2048 && ((uintptr_t) x->data | (uintptr_t) y->data | (uintptr_t) w | (uintptr_t) b) % 16 == 0 &&
+                    (x->nb[1] | x->nb[2] | x->nb[3] | y->nb[1] | y->nb[2] | y->nb[3]) % 16 == 0;
+    if (v4) return emit(ctx, "norm", k_norm_v4, dim3((uint32_t) ((k.nrows + 3) / 4)), dim3(256), 0, k, (double) t_nelements(x) * 8, 0);
     return emit(ctx, "norm", k_norm, dim3((uint32_t) ((k.nrows + 3) / 4)), dim3(256), 0, k, (double) t_nelements(x) * 8, 0);
 }
 
