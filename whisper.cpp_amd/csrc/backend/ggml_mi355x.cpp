@@ -970,6 +970,8 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
         // host is still planning / patching / launching the following ones, so only 1/n-th of the per-step host work sits in
         // front of the GPU (a decode step of large-v3 is 264 launches and ~145 us of host work in here).
         static const int seg = getenv("GGML_MI355X_GRAPH_SEG") ? atoi(getenv("GGML_MI355X_GRAPH_SEG")) : 64;
+        // the first segment is short: it is the only one whose planning / patching / hipGraphLaunch the GPU has to wait for
+        static const int seg0 = getenv("GGML_MI355X_GRAPH_SEG0") ? atoi(getenv("GGML_MI355X_GRAPH_SEG0")) : 12;
         b->act_src = nullptr;
         int i = 0, iseg = 0;
         bool ok = true;
@@ -978,7 +980,7 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
             mi355x_record_begin(b->k);
             b->recording = true; b->record_abort = false;
             int i_next = cgraph->n_nodes;
-            int rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, seg, &i_next);
+            int rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, (iseg == 0 && seg > 0 && seg0 > 0) ? seg0 : seg, &i_next);
             b->recording = false;
             b->t_plan_ms += now_ms() - t0;
             const mi355x_launch * L; const uint8_t * blob; size_t bsz;
