@@ -258,6 +258,9 @@ MI355X_API void mi355x_gelu_table_host(uint16_t * out65536);
  * copies the 16 stamps of the last launch to the host.  MI355X_E_UNSUPPORTED when the mode is off. */
 MI355X_API int mi355x_debug_read_stamps(mi355x_ctx * ctx, unsigned long long * out16);
 
+/* wide empty launch on `stream` (hipStream_t): wakes the whole chip ahead of the first real dispatch of a decode step */
+MI355X_API int mi355x_wake(void * stream, int nblocks);
+
 /* memset / memcpy helpers on the context stream */
 MI355X_API int mi355x_memset(mi355x_ctx * ctx, void * dptr, int value, size_t n);
 

@@ -88,6 +88,7 @@ struct mi_io_ctx {
     size_t      cap = 0, off = 0;
     std::atomic<uint64_t> seq{0};          // number of uploads enqueued so far
     std::atomic<uint64_t> drained{0};      // uploads known to be complete
+    uint64_t    wake_seq = 0;              // value of seq when the last graph_compute picked the uploads up
     bool        ok = false, tried = false;
 };
 static mi_io_ctx g_io[MI_MAX_DEVICES];
@@ -123,6 +124,9 @@ static bool mi_io_upload(int device, void * dst, const void * src, size_t size) 
     if (io->off + need > io->cap) { (void) hipStreamSynchronize(io->stream); io->drained.store(io->seq.load()); io->off = 0; }
     memcpy(io->pinned + io->off, src, size);
     if (hipMemcpyAsync(dst, io->pinned + io->off, size, hipMemcpyHostToDevice, io->stream) != hipSuccess) return false;
+    // first upload since the last compute: wake the chip now, while the host still has its per-step work ahead
+    static const int wake = getenv("GGML_MI355X_WAKE") ? atoi(getenv("GGML_MI355X_WAKE")) : 1024;
+    if (wake > 0 && io->seq.load() == io->wake_seq) (void) mi355x_wake((void *) io->stream, wake);
     io->off += need;
     (void) hipEventRecord(io->ev, io->stream);
     io->seq++;
@@ -948,6 +952,7 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
             std::lock_guard<std::mutex> lk(io.mtx);
             (void) hipStreamWaitEvent((hipStream_t) mi355x_ctx_stream(b->k), io.ev, 0);
             b->io_seen = io.seq.load();
+            io.wake_seq = b->io_seen;
         }
     }
     // GPU span bookkeeping (two event records per call)

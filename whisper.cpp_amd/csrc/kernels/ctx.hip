@@ -82,6 +82,16 @@ extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
 
 extern "C" void * mi355x_ctx_stream(mi355x_ctx * ctx) { return (void *) ctx->stream; }
 
+// A wide do-nothing launch.  The first chip-wide dispatch after the GPU has sat idle for a few hundred microseconds (the
+// host-side part of a decode step) stalls ~30 us (profiles: gap before the first mat-vec of every step, while the
+// 1-workgroup kernels in front of it start immediately).  The backend issues this on its upload stream when the first input
+// of a step arrives, i.e. while the host is still busy, so the stall is taken off the critical path.
+__global__ void __launch_bounds__(64) k_wake(int * sink) { if (sink && threadIdx.x == 1024) *sink = 0; }
+extern "C" int mi355x_wake(void * stream, int nblocks) {
+    k_wake<<<dim3(nblocks > 0 ? nblocks : 1024), dim3(64), 0, (hipStream_t) stream>>>(nullptr);
+    return (int) hipGetLastError();
+}
+
 // kernel-anatomy stamps (debug): allocated on first use when GGML_MI355X_KTIME=1, else kernels get a null pointer
 void * mi355x_debug_stamps(mi355x_ctx * ctx) {
     static const bool on = getenv("GGML_MI355X_KTIME") && atoi(getenv("GGML_MI355X_KTIME"));

@@ -587,6 +587,34 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     };
 
     // ---- activations -> registers ---------------------------------------------------------------------------------
+    float4 * xstage = (float4 *) (smem + ((((char *) sx - smem) + (Q4K ? (size_t) T*(K >> 5)*4 : (size_t) T*nb*4) + 15) & ~(size_t) 15));   // MODE 2, T > 2 only
+    if constexpr (MODE == 2 && !PBURST) {
+        // one record burst per column in a ROLLED loop (unrolled, the compiler hoists all columns' loads: 72 registers
+        // each); the combined column goes through LDS because a rolled loop cannot index the register array
+        #pragma unroll 1
+        for (int t = 0; t < T; t++) {
+            float2 ml[MAXP]; float4 ov[MAXP];
+            const int64_t base = ((int64_t) ph*T + t) * a.nparts;
+            #pragma unroll
+            for (int p = 0; p < MAXP; p++) {
+                const int pc = p < a.nparts ? p : a.nparts - 1;
+                ml[p] = *(const float2 *) (a.part_ml + (base + pc)*2);
+                ov[p] = *(const float4 *) (a.part_o + (base + pc)*64 + pd);
+            }
+            float M = -1e30f, L = 0.0f;
+            float4 o = make_float4(0, 0, 0, 0);
+            #pragma unroll
+            for (int p = 0; p < MAXP; p++) M = fmaxf(M, ml[p].x);
+            #pragma unroll
+            for (int p = 0; p < MAXP; p++) {
+                const float w = p < a.nparts ? __expf(ml[p].x - M) : 0.0f;
+                L = fmaf(w, ml[p].y, L);
+                o.x = fmaf(w, ov[p].x, o.x); o.y = fmaf(w, ov[p].y, o.y); o.z = fmaf(w, ov[p].z, o.z); o.w = fmaf(w, ov[p].w, o.w);
+            }
+            const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+            xstage[t*nthreads + tid] = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
+        }
+    }
     if constexpr (MODE == 2) {
         // x[t][h*64 + d] = sum_p w_p o_p[d] / sum_p w_p l_p,  w_p = exp(m_p - max_p m_p)   (k_fattn_dec records)
         #pragma unroll
@@ -612,15 +640,10 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
                     o.x = fmaf(w, pov[p].x, o.x); o.y = fmaf(w, pov[p].y, o.y); o.z = fmaf(w, pov[p].z, o.z); o.w = fmaf(w, pov[p].w, o.w);
                 }
             } else {
-                const int64_t base = ((int64_t) ph*T + t) * a.nparts;
-                for (int p = 0; p < a.nparts; p++) M = fmaxf(M, a.part_ml[(base + p)*2]);
-                for (int p = 0; p < a.nparts; p++) {
-                    const float2 ml = *(const float2 *) (a.part_ml + (base + p)*2);
-                    const float w = __expf(ml.x - M);
-                    const float4 v = *(const float4 *) (a.part_o + (base + p)*64 + pd);
-                    L = fmaf(w, ml.y, L);
-                    o.x = fmaf(w, v.x, o.x); o.y = fmaf(w, v.y, o.y); o.z = fmaf(w, v.z, o.z); o.w = fmaf(w, v.w, o.w);
-                }
+                // T > 2: the column's combined value was staged in LDS by the rolled loop above
+                const float4 sv = xstage[t*nthreads + tid];
+                xr[t][0] = sv;
+                continue;
             }
             const float inv = L == 0.0f ? 0.0f : 1.0f / L;
             xr[t][0] = make_float4(o.x*inv, o.y*inv, o.z*inv, o.w*inv);
@@ -893,7 +916,10 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const double flops0 = 2.0 * ntot * K * T;
     static const int env_lean = getenv("GGML_MI355X_GEMV_LEAN") ? atoi(getenv("GGML_MI355X_GEMV_LEAN")) : 1;
     if (env_lean && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
-        const size_t lds_row = 512 + dg_act_bytes(wt, K, T);          // 512-byte reduction header + activation planes
+        const int rpw = gemv_row_waves(K);
+        // 512-byte reduction header + activation planes (+ one float4 per thread and column when the attention combine
+        // of T > 2 columns is staged through LDS)
+        const size_t lds_row = 512 + dg_act_bytes(wt, K, T) + ((from_part && T > 2) ? (size_t) T * 64 * rpw * 16 + 16 : 0);
         const int rpb = gemv_row_waves(K);
         const dim3 grid((ntot + rpb - 1) / rpb);
         int rc = MI355X_E_UNSUPPORTED;
@@ -1082,7 +1108,12 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int K = a.K, nb = K >> 5, K4 = K >> 2;
     const int kg = lane >> 3, dc = lane & 7;
-    const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2, p = blockIdx.x;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed, used for speed only), so the 8 lowest bits of b pick the head
+    // residue: all key chunks of one head share an XCD and its L2 fetches the head's 56 KB of W_q from HBM once instead of
+    // once per XCD that happens to host one of its chunks (PMC: 17 -> 9 MB per launch)
+    const int bx = blockIdx.x, hq = (bx & 7) + 8 * ((bx >> 3) / a.nparts), p = (bx >> 3) % a.nparts;
+    if (hq >= a.H) return;
+    const int hk = hq / a.rk2, hv = hq / a.rv2;
     const int kbeg = p*128 + wave*16;
 
     // ---- load burst: activations, LN vectors, bias, K/V rows, mask, then the weights --------------------------------
@@ -1267,7 +1298,7 @@ extern "C" int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc
     a.part_o  = (float *) mi355x_scratch_alloc(ctx, nrec * 64 * 4);
     a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
     if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
-    const dim3 grid(a.nparts, H), block(512);
+    const dim3 grid(8 * a.nparts * ((H + 7) / 8)), block(512);
     const uint32_t lds = 4096 + (uint32_t) (K/32) * 40;
     const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) mi355x_type_row_bytes(wt, K) * N + (double) K*4 + (double) nrec*66*4;
     const double flops = 4.0 * (double) n_kv * 64 * H + 2.0 * (double) N * K;
