@@ -140,6 +140,13 @@ MI355X_API int mi355x_prep_act(mi355x_ctx * ctx, const void * x, int64_t x_nb1, 
 MI355X_API int mi355x_gemm_f16act(mi355x_ctx * ctx, const mi355x_tensor * w, const void * act_f16, int64_t ld, int64_t T,
                                   void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep /* nullable */);
 
+/* One-time preparation of a quantized weight for the MFMA path: writes dst_f16[M][K] = f16(dequantized w), the
+ * exact values mi355x_gemm_f16act feeds the matrix cores when given the quantized tensor.  A caller that keeps
+ * this copy (HBM is plentiful) passes it to mi355x_gemm_f16act as an F16 tensor and still prepares the
+ * activation with the ORIGINAL weight type's mode: results are bit-identical to the quantized call, the GEMM
+ * inner loop just carries no dequantization.  Launched immediately even while a plan is being recorded. */
+MI355X_API int mi355x_dequant_f16(mi355x_ctx * ctx, const mi355x_tensor * w, void * dst_f16);
+
 /* Decoder-step fusion (T <= 8 columns): [optional LayerNorm(x)*ln_w+ln_b] -> quantize -> up to 3
  * mat-vec products sharing x (Q,K,V) each with its own epilogue/destination.  Same arithmetic as the
  * unfused node sequence norm,mul,add,mul_mat,add,scale,cpy (src/whisper.cpp:2529-2598). */

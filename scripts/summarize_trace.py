@@ -56,14 +56,19 @@ def per_step(files, marker="k_get_rows<6>"):
     span = sum(s[-1][1] - s[0][0] for s in sel) / len(sel) / 1e3
     busy = sum(sum(k[1] - k[0] for k in s) for s in sel) / len(sel) / 1e3
     print(f"mean span first-start..last-end = {span:.1f} us, kernel-busy = {busy:.1f} us, gaps = {span - busy:.1f} us")
-    print(f"{'pos':>4s} {'kernel':40s} {'grid':>8s} {'dur_us':>8s} {'gap_us':>8s}")
+    print(f"{'pos':>4s} {'kernel':40s} {'grid':>8s} {'dur_us':>8s} {'gap_us':>8s} {'gap_med':>8s}")
+    big = []
     for i in range(L):
         dur = sum(s[i][1] - s[i][0] for s in sel) / len(sel) / 1e3
-        gap = sum((s[i][0] - s[i - 1][1]) for s in sel) / len(sel) / 1e3 if i else 0.0
+        gaps = sorted((s[i][0] - s[i - 1][1]) / 1e3 for s in sel) if i else [0.0]
+        gap, med = sum(gaps) / len(gaps), gaps[len(gaps) // 2]
+        if gap > 2.0:
+            big.append((i, gap, med))
         if i < 30 or i >= L - 6:
-            print(f"{i:4d} {sel[0][i][2][:40]:40s} {sel[0][i][3]:>8s} {dur:8.2f} {gap:8.2f}")
+            print(f"{i:4d} {sel[0][i][2][:40]:40s} {sel[0][i][3]:>8s} {dur:8.2f} {gap:8.2f} {med:8.2f}")
         elif i == 30:
             print("   ... (layers repeat)")
+    print("positions with mean gap > 2 us (pos, mean, median): " + ", ".join(f"{i}: {g:.1f}/{m:.1f}" for i, g, m in big))
 
 
 if __name__ == "__main__":

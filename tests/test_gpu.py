@@ -108,6 +108,41 @@ def test_mul_mat_vs_oracle(gpu, oracle, t, K, N, T):
     assert e < tol, f"{t} K={K} N={N} T={T}: NMSE {e:.3e} >= {tol}"
 
 
+@pytest.mark.parametrize("t", list(QT))
+def test_f16_weight_copy_is_bit_identical_to_fused_dequant(gpu, oracle, t):
+    """mi355x_dequant_f16 + the F16-operand GEMM (what the backend runs for weights that meet wide activations)
+    must give the bits of the GEMM that dequantizes in its loop, and the copy itself must be f16(dequantized weight)
+    of the oracle's dequantizer (ggml-quants.c dequantize_row_*)."""
+    ctx, ka, torch = gpu
+    tid = QT[t]
+    K, N, T = 1280, 384, 300
+    rng = np.random.default_rng(17 + tid)
+    wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    blocks, planar = quantize(oracle, ka, tid, wf)
+    w_d, x_d = dev(torch, planar), dev(torch, x)
+    sh_d = torch.zeros((N, K), dtype=torch.float16, device="cuda:0")
+    act_d = torch.zeros((T, K), dtype=torch.float16, device="cuda:0")
+    y1, y2 = (torch.zeros((T, N), dtype=torch.float32, device="cuda:0") for _ in range(2))
+    torch.cuda.synchronize()
+    tw = ka.tensor(w_d.data_ptr(), tid, [K, N])
+    ctx.check(ka.lib().mi355x_dequant_f16(ctx.h, C.byref(tw), sh_d.data_ptr()), "dequant_f16")
+    mode = 2 if tid == 12 else 1
+    ctx.check(ka.lib().mi355x_prep_act(ctx.h, x_d.data_ptr(), K * 4, 0, act_d.data_ptr(), K, T, mode), "prep_act")
+    ts = ka.tensor(sh_d.data_ptr(), ka.F16, [K, N])
+    ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(tw), act_d.data_ptr(), K, T, y1.data_ptr(), N * 4, ka.F32, None), "gemm quantized A")
+    ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(ts), act_d.data_ptr(), K, T, y2.data_ptr(), N * 4, ka.F32, None), "gemm f16 A")
+    ctx.sync()
+    assert np.array_equal(y1.cpu().numpy().view(np.uint32), y2.cpu().numpy().view(np.uint32))
+    deq = np.empty((N, K), dtype=np.float32)
+    oracle.oracle_dequantize_row(tid, ptr(blocks), ptr(deq), N * K)
+    got = sh_d.cpu().numpy()
+    if tid == 12:     # d*sc*q - dmin*m: the kernel contracts to one fma, the CPU rounds twice -> at most 1 f16 ulp apart
+        assert np.allclose(got.astype(np.float32), deq, rtol=2e-3, atol=1e-7)
+    else:
+        assert np.array_equal(got, deq.astype(np.float16))
+
+
 def test_mul_mat_f16_weights(gpu, oracle):
     _, ka, _ = gpu
     rng = np.random.default_rng(5)

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #define MI_MAX_DEVICES 16
@@ -62,6 +63,31 @@ static mi_device_ctx              g_device_ctx[MI_MAX_DEVICES];
 static int                        g_n_devices = -1;
 
 static bool is_quant_type(ggml_type t) { return mi355x_type_is_quantized((int) t) != 0; }
+
+// f16 copies of quantized WEIGHTS tensors that meet wide activations (encoder, cross-attention K/V, prompt): made once by
+// mi355x_dequant_f16 the first time such a tensor reaches the MFMA path, kept until its buffer is written or freed.
+// 2 bytes/weight of HBM buys a GEMM inner loop without dequantization (GGML_MI355X_F16_SHADOW_MB caps the total, 0 = off).
+struct mi_shadow { void * f16; size_t bytes; const void * buf_base; int device; int type; int64_t ne0, ne1; };
+static std::mutex                                   g_shadow_mtx;
+static std::unordered_map<const void *, mi_shadow>  g_shadows;
+static std::atomic<size_t>                          g_shadow_count{0};
+static size_t                                       g_shadow_bytes = 0;
+
+// forget (and free) the copies that belong to one buffer (buf_base) or one device (buf_base == nullptr)
+static void mi_shadows_drop(int device, const void * buf_base) {
+    if (g_shadow_count.load() == 0) return;
+    std::lock_guard<std::mutex> lk(g_shadow_mtx);
+    bool synced = false;
+    for (auto it = g_shadows.begin(); it != g_shadows.end(); ) {
+        if (it->second.device == device && (!buf_base || it->second.buf_base == buf_base)) {
+            if (!synced) { (void) hipSetDevice(device); (void) hipDeviceSynchronize(); synced = true; }
+            (void) hipFree(it->second.f16);
+            g_shadow_bytes -= it->second.bytes;
+            it = g_shadows.erase(it);
+        } else ++it;
+    }
+    g_shadow_count.store(g_shadows.size());
+}
 
 // host-side time spent in the buffer callbacks (set/get/cpy: the per-step H2D of ids / positions / mask and the D2H of
 // the logits row) and in synchronize — reported by ggml_backend_mi355x_host_times
@@ -156,6 +182,7 @@ static void mi_buffer_free(ggml_backend_buffer_t buffer) {
         std::lock_guard<std::mutex> lk(g_weights_mtx);
         for (size_t i = 0; i < g_buffers.size(); i++) if (g_buffers[i].base == ctx->base) { g_buffers.erase(g_buffers.begin() + i); break; }
     }
+    mi_shadows_drop(ctx->device, ctx->base);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     (void) hipDeviceSynchronize();
@@ -172,6 +199,7 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
+        mi_shadows_drop(ctx->device, ctx->base);
         mi_io_drain(ctx->device);
         const size_t nbytes = ggml_nbytes(tensor);
         std::vector<uint8_t> planar(nbytes);
@@ -214,6 +242,7 @@ static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
 
 static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    if (is_quant_type(tensor->type)) mi_shadows_drop(ctx->device, ctx->base);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     (void) hipMemset((char *) tensor->data + offset, value, size);
@@ -222,6 +251,7 @@ static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * 
 
 static void mi_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    mi_shadows_drop(ctx->device, ctx->base);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     (void) hipMemset(ctx->base, value, ctx->size);
@@ -235,6 +265,7 @@ static bool mi_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
     if (!mi_buffer_is_ours(sbuf)) return false;
     io_timer tm(2);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    if (is_quant_type(dst->type)) mi_shadows_drop(ctx->device, ctx->base);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     // same layout on both sides (ggml_are_same_layout is asserted by the caller) => raw bytes, planar included
@@ -443,6 +474,31 @@ static bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c
 
 static int mode_for(ggml_type t) { return t == GGML_TYPE_Q4_K ? 2 : (is_quant_type(t) ? 1 : 0); }
 
+// f16 copy of a quantized weight for the MFMA path (nullptr: not eligible / over budget -> the GEMM dequantizes in its loop)
+static const void * mi_shadow_get(mi_backend_ctx * b, const ggml_tensor * w, const mi355x_tensor & mw) {
+    static const size_t cap_mb = getenv("GGML_MI355X_F16_SHADOW_MB") ? (size_t) atoll(getenv("GGML_MI355X_F16_SHADOW_MB")) : 16384;
+    if (cap_mb == 0) return nullptr;
+    ggml_backend_buffer_t buf = w->view_src ? w->view_src->buffer : w->buffer;
+    if (!buf || !mi_buffer_is_ours(buf) || buf->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) return nullptr;
+    std::lock_guard<std::mutex> lk(g_shadow_mtx);
+    auto it = g_shadows.find(w->data);
+    if (it != g_shadows.end()) {
+        const mi_shadow & sh = it->second;
+        return (sh.type == (int) w->type && sh.ne0 == w->ne[0] && sh.ne1 == w->ne[1]) ? sh.f16 : nullptr;
+    }
+    const size_t bytes = (size_t) w->ne[0] * (size_t) w->ne[1] * 2;
+    if (g_shadow_bytes + bytes > cap_mb * 1024 * 1024) return nullptr;
+    const mi_buffer_ctx * bc = (const mi_buffer_ctx *) buf->context;
+    void * p = nullptr;
+    if (hipMalloc(&p, bytes + 256) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    // the copy is published only once it is complete, so another backend (another whisper_state on its own stream) never reads it early
+    if (mi355x_dequant_f16(b->k, &mw, p) != 0 || mi355x_ctx_synchronize(b->k) != 0) { (void) hipFree(p); return nullptr; }
+    g_shadows[w->data] = { p, bytes, bc->base, bc->device, (int) w->type, w->ne[0], w->ne[1] };
+    g_shadow_bytes += bytes;
+    g_shadow_count.store(g_shadows.size());
+    return p;
+}
+
 static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
     const ggml_tensor * mm = c.mm, * w = mm->src[0], * x = mm->src[1];
     mi355x_tensor mw = to_mt(w), mx = to_mt(x);
@@ -480,6 +536,17 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
                     b->act_src = x->data; b->act_K = K; b->act_T = T; b->act_mode = mode; b->act_nb1 = (int64_t) x->nb[1];
                 }
                 act = b->act; ld = K;
+            }
+            // wide activations: run the GEMM on the weight's f16 copy (same values, no dequantization in the loop)
+            static const int shadow_min_t = getenv("GGML_MI355X_F16_SHADOW_MIN_T") ? atoi(getenv("GGML_MI355X_F16_SHADOW_MIN_T")) : 128;
+            if (mode != 0 && T >= shadow_min_t) {
+                if (const void * f16 = mi_shadow_get(b, w, mw)) {
+                    mi355x_tensor ms = mw;
+                    ms.data = (void *) f16; ms.type = MI355X_TYPE_F16;
+                    ms.nb[0] = 2; ms.nb[1] = K*2; ms.nb[2] = ms.nb[1]*w->ne[1]; ms.nb[3] = ms.nb[2];
+                    const int rc = mi355x_gemm_f16act(b->k, &ms, act, ld, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
+                    if (rc != MI355X_E_UNSUPPORTED) return rc;
+                }
             }
             const int rc = mi355x_gemm_f16act(b->k, &mw, act, ld, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
             if (rc != MI355X_E_UNSUPPORTED) return rc;
@@ -986,7 +1053,14 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
             mi355x_record_begin(b->k);
             b->recording = true; b->record_abort = false;
             int i_next = cgraph->n_nodes;
-            int rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, (iseg == 0 && seg > 0 && seg0 > 0) ? seg0 : seg, &i_next);
+            // GGML_MI355X_GRAPH_SEGS=a,b,c overrides the schedule: segment i holds the i-th entry's launches (last entry repeats)
+            static const std::vector<int> segs = [] {
+                std::vector<int> v;
+                if (const char * e = getenv("GGML_MI355X_GRAPH_SEGS")) for (const char * p = e; *p; ) { v.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p) p++; }
+                return v;
+            }();
+            const int seg_len = !segs.empty() ? segs[std::min((size_t) iseg, segs.size() - 1)] : (iseg == 0 && seg > 0 && seg0 > 0) ? seg0 : seg;
+            int rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, seg_len, &i_next);
             b->recording = false;
             b->t_plan_ms += now_ms() - t0;
             const mi355x_launch * L; const uint8_t * blob; size_t bsz;
@@ -1204,6 +1278,7 @@ void ggml_backend_mi355x_host_times(double * out) {
 }
 
 int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {
+    mi_shadows_drop(device, nullptr);          // the caller is about to overwrite the weights behind our back
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     int n = 0;
     for (auto & r : g_buffers) {

@@ -153,10 +153,9 @@ __device__ __forceinline__ void a_load(a_regs<AT> & r, const GemmArgs & a, int m
     }
 }
 
-// dequantize to f16 and store the 4 slots (8 halves each) of this thread's 32 k-values
+// dequantize this thread's 32 k-values to f16: 4 slots of 8 halves
 template <int AT>
-__device__ __forceinline__ void a_store(const a_regs<AT> & r, char * lds, int row, int half, int k /* global k of first element */) {
-    uint4 out[4];
+__device__ __forceinline__ void a_unpack(const a_regs<AT> & r, int k /* global k of first element */, uint4 (&out)[4]) {
     if constexpr (AT == MI355X_TYPE_F16) {
         #pragma unroll
         for (int i = 0; i < 4; i++) out[i] = r.v[i];
@@ -220,8 +219,58 @@ __device__ __forceinline__ void a_store(const a_regs<AT> & r, char * lds, int ro
         #pragma unroll
         for (int i = 0; i < 4; i++) out[i] = make_uint4(o[4*i], o[4*i+1], o[4*i+2], o[4*i+3]);
     }
+}
+
+template <int AT>
+__device__ __forceinline__ void a_store(const a_regs<AT> & r, char * lds, int row, int half, int k) {
+    uint4 out[4];
+    a_unpack<AT>(r, k, out);
     #pragma unroll
     for (int i = 0; i < 4; i++) *(uint4 *) (lds + lds_off(row, half*4 + i)) = out[i];
+}
+
+// -------------------------------------------------------------------------------------------------
+// one-time weight preparation for the MFMA path: planar quantized A -> f16 [M][K] (the values k_gemm_mfma would
+// put into LDS, bit for bit).  With 288 GB of HBM the backend keeps this copy next to the quantized one for
+// weights that meet wide activations (encoder, cross-attention K/V, prompt), so the GEMM inner loop carries
+// no dequantization VALU work; the mat-vec path keeps streaming the quantized planes.
+// -------------------------------------------------------------------------------------------------
+template <int AT>
+__global__ void __launch_bounds__(256) k_dequant_f16(const GemmArgs a) {
+    const int64_t g = (int64_t) blockIdx.x * 256 + threadIdx.x;          // one 32-element group per thread
+    const int kg = a.K >> 5;
+    if (g >= (int64_t) a.M * kg) return;
+    const int m = (int) (g / kg), k = (int) (g % kg) * 32;
+    a_regs<AT> r;
+    a_load<AT>(r, a, m, k, true);
+    uint4 out[4];
+    a_unpack<AT>(r, k, out);
+    uint4 * d = (uint4 *) (a.dst + ((int64_t) m * a.K + k) * 2);
+    #pragma unroll
+    for (int i = 0; i < 4; i++) d[i] = out[i];
+}
+
+extern "C" int mi355x_dequant_f16(mi355x_ctx * ctx, const mi355x_tensor * A, void * dst) {
+    const int K = (int) A->ne[0], M = (int) A->ne[1];
+    if (!mi355x_type_is_quantized(A->type) || !t_is_contiguous(A) || A->ne[2] != 1 || A->ne[3] != 1 || K % type_block(A->type) ||
+        ((uintptr_t) A->data % 16) || ((uintptr_t) dst % 16) || M <= 0 || K <= 0) return MI355X_E_UNSUPPORTED;
+    GemmArgs k; memset(&k, 0, sizeof(k));
+    k.A = (const char *) A->data; k.M = M; k.K = K; k.nbt = (int64_t) M * (K / type_block(A->type)); k.dst = (char *) dst;
+    const int64_t ngroups = (int64_t) M * (K / 32);
+    const dim3 g((uint32_t) ((ngroups + 255) / 256)), b(256);
+    const double bytes = (double) mi355x_type_row_bytes(A->type, K) * M + (double) M * K * 2;
+    // preparation, not part of a step: always launched now, never appended to a plan that is being recorded
+    const bool rec = ctx->recording; ctx->recording = false;
+    int rc;
+    switch (A->type) {
+        case MI355X_TYPE_Q4_0: rc = emit(ctx, "dequant_f16", k_dequant_f16<MI355X_TYPE_Q4_0>, g, b, 0, k, bytes, 0); break;
+        case MI355X_TYPE_Q5_0: rc = emit(ctx, "dequant_f16", k_dequant_f16<MI355X_TYPE_Q5_0>, g, b, 0, k, bytes, 0); break;
+        case MI355X_TYPE_Q8_0: rc = emit(ctx, "dequant_f16", k_dequant_f16<MI355X_TYPE_Q8_0>, g, b, 0, k, bytes, 0); break;
+        case MI355X_TYPE_Q4_K: rc = emit(ctx, "dequant_f16", k_dequant_f16<MI355X_TYPE_Q4_K>, g, b, 0, k, bytes, 0); break;
+        default: rc = MI355X_E_UNSUPPORTED;
+    }
+    ctx->recording = rec;
+    return rc;
 }
 
 template <int AT, int BN>
