@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--arch", default="large-v3")
     ap.add_argument("--qtype", default="q5_0")
     ap.add_argument("--n-decode", type=int, default=256)
+    ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU in the timed region (headline config: 1)")
+    ap.add_argument("--multi-stream", type=int, default=4, help="also measure S concurrent streams on one GPU after the headline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="print the per-kernel hipEvent profile of one chunk and exit")
     ap.add_argument("--no-profile", action="store_true", help="skip the hipEvent per-kernel pass (no roofline object; used under rocprofv3 --pmc)")
@@ -190,7 +192,18 @@ def main():
     tokens = (C.c_int32 * 512)()
     n_threads = 4
 
+    from whisper_cpp_amd.streams import Streams
+
+    def make_streams(n):
+        mels = [(np.random.default_rng(1000 * rank + 42 + i).random((n_mels, 3000), dtype=np.float32) * 2 - 1) for i in range(n)]
+        return Streams(w, ctx, n, mels)
+
+    multi = make_streams(a.streams) if a.streams > 1 else None
+
     def chunk():
+        if multi is not None:                 # --streams S: S states on this GPU, one host thread each, all process one chunk
+            multi.chunk_all(a.n_decode)
+            return
         if w.whisper_encode(ctx, 0, n_threads) != 0:
             raise RuntimeError("whisper_encode failed")
         for i in range(a.n_decode):
@@ -239,23 +252,42 @@ def main():
     tm = w.whisper_get_timings(ctx).contents
     batchd_ms, prompt_ms = float(tm.batchd_ms), float(tm.prompt_ms)
 
+    # SURVEY.md §8f rank 2, reported beside the headline: S concurrent streams sharing this GPU and one copy of the weights
+    multi_stream = None
+    if a.multi_stream > 1 and multi is None and world == 1:
+        try:
+            ms = make_streams(a.multi_stream)
+            ms.chunk_all(a.n_decode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                ms.chunk_all(a.n_decode)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            ms.close()
+            multi_stream = {"streams": a.multi_stream, "chunks_per_s": round(2 * a.multi_stream / el, 4),
+                            "ms_per_chunk_aggregate": round(el * 1e3 / (2 * a.multi_stream), 3), "ms_per_chunk_per_stream": round(el * 1e3 / 2, 3),
+                            "note": "one whisper_state (own HIP stream, KV caches, compute buffers) per stream on one whisper_context; weights shared"}
+        except Exception as e:  # noqa: BLE001
+            multi_stream = {"streams": a.multi_stream, "error": str(e)}
+
     stats = (C.c_uint64 * 4)()
     p.ggml_backend_mi355x_stats(stats)
     prof = profile_chunk() if (rank == 0 and not a.no_profile) else []
 
     if rank == 0:
         figs = algorithmic_figures(a.arch, a.qtype)
-        ms_per_step, agg_ms, chunks_per_s = aggregate(elapsed_s, a.steps, world)
+        ms_per_step, agg_ms, chunks_per_s = aggregate(elapsed_s, a.steps, world * a.streams)
         out = {
             "metric": "whisper-bench encoder+decoder ms per 30s chunk", "value": round(agg_ms, 4), "unit": "ms/chunk",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": False,
             "scaling": "weak", "vs_baseline": None, "dtype": "int8 dot (decode) / f16 MFMA (encode), f32 accumulate", "data": "synthetic",
-            "config": {"workload": f"{a.arch} {a.qtype.upper()}: 1 x whisper_encode + {a.n_decode} x whisper_decode(1 token), one stream per GPU",
-                       "streams": world, "flash_attn": True, "weights": "seeded random, reference quantizer", "mel": "seeded uniform(-1,1)"},
+            "config": {"workload": f"{a.arch} {a.qtype.upper()}: 1 x whisper_encode + {a.n_decode} x whisper_decode(1 token), {a.streams} stream{'s' if a.streams > 1 else ''} per GPU",
+                       "streams": world * a.streams, "flash_attn": True, "weights": "seeded random, reference quantizer", "mel": "seeded uniform(-1,1)"},
             "chunks_per_s": round(chunks_per_s, 4),
             "encode_ms": round(encode_ms, 3), "decode_ms_per_token": round(decode_ms, 4),
             "batchd_ms_per_token": round(batchd_ms, 4), "prompt_ms_per_token": round(prompt_ms, 4),
-            "weight_broadcast": bcast,
+            "weight_broadcast": bcast, "multi_stream": multi_stream,
             "hip_graph": {"graph_computes": int(stats[0]), "replays": int(stats[1]), "patched_nodes": int(stats[2]), "builds": int(stats[3]),
                           "host_ms_in_timed_region": {"plan": round(host_ms[0], 2), "patch": round(host_ms[1], 2), "launch": round(host_ms[2], 2), "eager": round(host_ms[3], 2),
                                             "set_tensor": round(host_ms[4], 2), "get_tensor": round(host_ms[5], 2), "cpy_tensor": round(host_ms[6], 2), "synchronize": round(host_ms[7], 2),

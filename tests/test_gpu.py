@@ -626,6 +626,19 @@ def test_plugin_whisper_full_pipeline(plugin_env, arch, qtype):
     assert d["greedy"]["identical_prefix"] >= 6, d["greedy"]
 
 
+@pytest.mark.parametrize("arch,qtype,streams", [("base.en", "q5_0", 4), ("large-v3-2l", "q8_0", 3)])
+def test_concurrent_streams_on_one_gpu_match_serial(arch, qtype, streams):
+    """several whisper_states on one context, one host thread each (the whisper_full_parallel arrangement, W:7848-7869):
+    each stream's logits must be bit-identical to the same stream running alone"""
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_check.py"), arch, qtype, str(streams), "12"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["errors"] == [] and d["finite"], d
+    assert d["rows_compared"] == streams * 12 and d["mismatching_rows"] == 0, d
+    assert d["streams_differ_from_each_other"] == 1, d
+
+
 def test_bench_smoke():
     """bench.py end to end on a small model: one JSON line with the contract's keys, roofline measured live"""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--arch", "base.en", "--qtype", "q5_0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
@@ -635,3 +648,4 @@ def test_bench_smoke():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+    assert d["multi_stream"]["streams"] == 4 and d["multi_stream"]["chunks_per_s"] > 0, d["multi_stream"]
