@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--multi-stream", type=int, default=4, help="also measure S concurrent streams on one GPU after the headline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-only", action="store_true", help="print the per-kernel hipEvent profile of one chunk and exit")
+    ap.add_argument("--profile-what", default="chunk", choices=["chunk", "batchd", "prompt"], help="what --profile-only measures")
     ap.add_argument("--no-profile", action="store_true", help="skip the hipEvent per-kernel pass (no roofline object; used under rocprofv3 --pmc)")
     a = ap.parse_args()
 
@@ -213,7 +214,14 @@ def main():
     def profile_chunk():
         p.ggml_backend_mi355x_prof_enable_all(1)
         p.ggml_backend_mi355x_prof_reset_all()
-        chunk()
+        if a.profile_what == "batchd":        # the beam-search shape: 5 tokens per step
+            for _ in range(16):
+                w.whisper_decode(ctx, tokens, 5, 0, n_threads)
+        elif a.profile_what == "prompt":
+            for _ in range(4):
+                w.whisper_decode(ctx, tokens, 256, 0, n_threads)
+        else:
+            chunk()
         rows = (ProfRow * 64)()
         n = p.ggml_backend_mi355x_prof_report_all(rows, 64)
         p.ggml_backend_mi355x_prof_enable_all(0)

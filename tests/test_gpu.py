@@ -90,7 +90,7 @@ def run_mul_mat(gpu, tid, planar_or_f16, x, K, N, T, ep=None):
 # quantized mat-mul against the oracle (seeded inputs) — decoder (T <= 8, int8 dot) and encoder (T > 8, MFMA) kernels
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("t", list(QT))
-@pytest.mark.parametrize("K,N,T", [(1280, 640, 1), (1280, 333, 5), (512, 1027, 8), (5120, 256, 2),
+@pytest.mark.parametrize("K,N,T", [(1280, 640, 1), (1280, 333, 5), (512, 1027, 8), (5120, 256, 2), (1280, 8452, 3),
                                    (1280, 640, 9), (512, 515, 100), (1280, 384, 257), (5120, 130, 64)])
 def test_mul_mat_vs_oracle(gpu, oracle, t, K, N, T):
     _, ka, _ = gpu
@@ -458,7 +458,7 @@ def test_attention_partials_feed_the_projection(gpu, oracle, T, n_kv, H):
     assert nmse(want, y_d.cpu().numpy()) < 1e-9
 
 
-@pytest.mark.parametrize("t", ["q5_0", "q8_0", "q4_0"])
+@pytest.mark.parametrize("t", ["q5_0", "q8_0", "q4_0", "q4_K"])
 @pytest.mark.parametrize("n_kv", [1536, 130])
 def test_fused_ln_q_attention_matches_unfused_sequence(gpu, oracle, t, n_kv):
     """k_qattn (LayerNorm + Q projection + decode attention in one launch, T = 1) against the oracle's

@@ -227,6 +227,17 @@ __device__ __forceinline__ void q4k_scale_min(int j, const uint8_t * q, int & sc
     else       { sc = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); m = (q[j + 4] >> 4) | ((q[j] >> 6) << 4); }
 }
 
+// the same from the 12 scale bytes held as three little-endian words (registers): shifts and selects only — indexing a
+// register-resident byte array with a lane-dependent j would put it in scratch memory
+__device__ __forceinline__ void q4k_scale_min_w(int j, uint32_t s0, uint32_t s1, uint32_t s2, int & sc, int & m) {
+    const int sh = (j & 3) * 8;
+    const int a_sc = (int) ((s0 >> sh) & 63), a_m = (int) ((s1 >> sh) & 63);
+    const int b_sc = (int) (((s2 >> sh) & 0xF) | (((s0 >> (sh + 6)) & 3) << 4));
+    const int b_m  = (int) (((s2 >> (sh + 4)) & 0xF) | (((s1 >> (sh + 6)) & 3) << 4));
+    sc = j < 4 ? a_sc : b_sc;
+    m  = j < 4 ? a_m  : b_m;
+}
+
 // dequantize element-block helpers: write 32 floats of block `ib` (32-element granularity for all types;
 // for Q4_K `ib` indexes 32-element sub-blocks: super-block ib/8, sub-block ib%8)
 template <int TYPE>

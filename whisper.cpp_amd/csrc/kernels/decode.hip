@@ -50,9 +50,11 @@ struct DGArgs {
 #define DG_U(LPR) ((LPR) == 8 ? 5 : 3)
 #define DG_XR 5           // float4 activation registers per thread in the "activations first" order
 
-static inline size_t dg_lds_bytes(int K, int T, bool staged) {
+static inline size_t dg_lds_bytes(int wt, int K, int T, bool staged) {
     // red[64 floats] | lo[T][nb] uint4 | hi[T][nb] uint4 | dx[T][nb] f32 | sx[T][nb] i32 | stage[T][K] f32 (optional)
-    return 256 + (size_t) T * (K/32) * 40 + (staged ? (size_t) T * K * 4 : 0);
+    // Q4_K: red | four Q8_K planes [4][T][K/64] uint4 | dx[T][K/256] f32 | sums[T][K/32] i32 | (16-byte aligned) stage
+    const size_t act = wt == MI355X_TYPE_Q4_K ? (((size_t) T * ((size_t) K + (K/256)*4 + (K/32)*4) + 15) & ~(size_t) 15) : (size_t) T * (K/32) * 40;
+    return 256 + act + (staged ? (size_t) T * K * 4 : 0);
 }
 
 template <int WT> struct wblk;
@@ -180,8 +182,8 @@ __device__ __forceinline__ void wblk_dot_q4k(const wblk<MI355X_TYPE_Q4_K> & r, i
     const int sb = ch >> 2, c = ch & 3;
     const float dw = h2f((uint16_t) (r.dm & 0xFFFF)) * live, dminw = h2f((uint16_t) (r.dm >> 16)) * live;
     int sc_lo, m_lo, sc_hi, m_hi;
-    q4k_scale_min(2*c,     (const uint8_t *) r.sc, sc_lo, m_lo);
-    q4k_scale_min(2*c + 1, (const uint8_t *) r.sc, sc_hi, m_hi);
+    q4k_scale_min_w(2*c,     r.sc[0], r.sc[1], r.sc[2], sc_lo, m_lo);
+    q4k_scale_min_w(2*c + 1, r.sc[0], r.sc[1], r.sc[2], sc_hi, m_hi);
     const uint32_t w[8] = { r.q[0], r.q[1], r.q[2], r.q[3], r.q1[0], r.q1[1], r.q1[2], r.q1[3] };
     #pragma unroll
     for (int t = 0; t < T; t++) {
@@ -210,11 +212,12 @@ static inline size_t dg_act_bytes(int wt, int K, int T) {
 
 template <int WT, int T, int LPR>
 __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
-    constexpr int U = DG_U(LPR), RPW = 64 / LPR;                      // blocks per lane per chunk, rows per wave pass
+    constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;                       // lane-units: 64-element chunks instead of 32-element blocks
+    constexpr int U = Q4K ? (LPR == 8 ? 3 : (LPR == 16 ? 2 : 1)) : DG_U(LPR), RPW = 64 / LPR;      // units per lane per chunk, rows per wave pass
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int wave = tid >> 6, lane = tid & 63;
-    const int K = a.K, nb = K >> 5;
+    const int K = a.K, nb = Q4K ? K >> 6 : K >> 5, nsb = K >> 8;
     const int r8 = lane / LPR, j8 = lane % LPR;
     const int ntot = a.row_start[a.nseg];
     const int nchunks = (nb + LPR*U - 1) / (LPR*U);
@@ -238,7 +241,8 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
         #pragma unroll
         for (int u = 0; u < U; u++) {
             const int g = j8 + LPR*(c*U + u);
-            wblk_load<WT>(r[u], base, nbt, (int64_t) (rok ? row : 0) * nb + (g < nb ? g : nb - 1));      // clamped, never predicated
+            if constexpr (Q4K) wblk_load_q4k(r[u], base, nbt, rok ? row : 0, nsb, g < nb ? g : nb - 1);
+            else               wblk_load<WT>(r[u], base, nbt, (int64_t) (rok ? row : 0) * nb + (g < nb ? g : nb - 1));      // clamped, never predicated
         }
     };
 
@@ -246,11 +250,17 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
     float * red = (float *) smem;
     uint32_t * lo = (uint32_t *) (smem + 256);
     uint32_t * hi = lo + (size_t) T*nb*4;
-    float * dx = (float *) (hi + (size_t) T*nb*4);
-    int *   sx = (int *) (dx + T*nb);
-    float * stage = (float *) (sx + T*nb);
+    float * dx = Q4K ? (float *) (smem + 256 + (size_t) T*K) : (float *) (hi + (size_t) T*nb*4);
+    int *   sx = Q4K ? (int *) (dx + T*nsb) : (int *) (dx + T*nb);
+    float * stage = Q4K ? (float *) (smem + 256 + ((((size_t) T * ((size_t) K + nsb*4 + (K >> 5)*4)) + 15) & ~(size_t) 15)) : (float *) (sx + T*nb);
     const bool staged = a.x == nullptr || a.has_norm;
     const int K4 = K >> 2;
+    // 4 consecutive values of column t starting at element e -> quantized activation planes (Q8_K: whole waves call this
+    // together, one wave = one 256-element super-block: K % 256 == 0 and the loops below advance by whole waves)
+    auto act_store = [&](const float v[4], int e, int t) {
+        if constexpr (Q4K) dg_q8_K_store(v, e, t, K, T, lo, dx, sx);
+        else               dg_q8_0_store(v, e, t, nb, lo, hi, dx, sx);
+    };
 
     // Loads return in issue order (vmcnt), so the short-latency activation loads (L2 hits) go first and the first chunk
     // of weights (HBM misses) right behind them: the prologue then runs while the weights are still in flight.
@@ -283,7 +293,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
                 if (idx < T*K4) {
                     const int t = idx / K4, e4 = idx - t*K4;
                     const float v[4] = { xr[i].x, xr[i].y, xr[i].z, xr[i].w };
-                    dg_q8_0_store(v, e4*4, t, nb, lo, hi, dx, sx);
+                    act_store(v, e4*4, t);
                 }
             }
         }
@@ -353,7 +363,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
             float o[4] = { (v.x - mt) * sc, (v.y - mt) * sc, (v.z - mt) * sc, (v.w - mt) * sc };
             o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
             o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
-            dg_q8_0_store(o, e4*4, t, nb, lo, hi, dx, sx);
+            act_store(o, e4*4, t);
         }
     } else if (!a.xfirst) {
         for (int idx = tid; idx < T*K4; idx += nthreads) {
@@ -361,7 +371,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
             const float4 x4 = staged ? *(const float4 *) (stage + (size_t) t*K + e4*4)
                                      : *(const float4 *) ((const char *) a.x + (int64_t) t*a.x_nb1 + (int64_t) e4*16);
             const float v[4] = { x4.x, x4.y, x4.z, x4.w };
-            dg_q8_0_store(v, e4*4, t, nb, lo, hi, dx, sx);
+            act_store(v, e4*4, t);
         }
     }
     __syncthreads();
@@ -369,9 +379,11 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
     // ---- main loop: chunk `it` in registers, chunk it+1 in flight ----
     const uint4 * alo = (const uint4 *) lo;
     const uint4 * ahi = (const uint4 *) hi;
-    float acc[T];
+    float acc[T], accm[Q4K ? T : 1];
     #pragma unroll
     for (int t = 0; t < T; t++) acc[t] = 0.0f;
+    #pragma unroll
+    for (int t = 0; t < (Q4K ? T : 1); t++) accm[t] = 0.0f;
 
     for (int it = 0; it < total; it++) {
         if (it + 1 < total) load_chunk(nxt, it + 1);
@@ -379,7 +391,9 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
         #pragma unroll
         for (int u = 0; u < U; u++) {
             const int g = j8 + LPR*(c*U + u);
-            if (g < nb) {
+            if constexpr (Q4K) {
+                if (g < nb) wblk_dot_q4k<T>(cur[u], g, 1.0f, nb, nsb, alo, dx, sx, acc, accm);
+            } else if (g < nb) {
                 uint32_t vlo[4], vhi[4];
                 wblk_unpack<WT>(cur[u], vlo, vhi);
                 const float dw = h2f(cur[u].d);
@@ -405,6 +419,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
             // reduce over the LPR lanes of the row, lane j8 == t finishes column t
             #pragma unroll
             for (int t = 0; t < T; t++) {
+                if constexpr (Q4K) { acc[t] += accm[t]; accm[t] = 0.0f; }
                 acc[t] = group_sum<LPR>(acc[t]);
             }
             float v = acc[0];
@@ -889,7 +904,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     } else if (!d->x || ((uintptr_t) d->x % 16) || (d->x_nb1 % 16)) return MI355X_E_UNSUPPORTED;
     if (d->has_norm && (!d->ln_w || !d->ln_b || ((uintptr_t) d->ln_w % 16) || ((uintptr_t) d->ln_b % 16))) return MI355X_E_UNSUPPORTED;
     const bool staged = from_part || d->has_norm;
-    const size_t lds = dg_lds_bytes(K, T, staged);
+    const size_t lds = dg_lds_bytes(wt, K, T, staged);
 
     DGArgs k; memset(&k, 0, sizeof(k));
     k.x = from_part ? nullptr : d->x; k.x_nb1 = d->x_nb1; k.K = K; k.has_norm = d->has_norm; k.eps = d->eps; k.nseg = d->nseg;
@@ -931,9 +946,8 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         }
         if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
-    if (wt == MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;            // k_gemv8 has no Q4_K path: first-generation kernel
     if (lds > 64*1024) return MI355X_E_UNSUPPORTED;
-    if (staged && ((size_t) T * (K/32) * 40) % 16) return MI355X_E_UNSUPPORTED;      // float4 alignment of the staging area
+    if (wt != MI355X_TYPE_Q4_K && staged && ((size_t) T * (K/32) * 40) % 16) return MI355X_E_UNSUPPORTED;      // float4 alignment of the staging area
     // geometry: latency-bound regime => as many waves as the matrix allows, up to ~16 per CU: lanes per row LPR such that
     // N * LPR / 64 waves >= 8 per CU (but no more lanes than the row has blocks), 4 waves per workgroup (each workgroup
     // repeats the activation prologue; 256 threads keep it short), several passes per wave only for huge N
@@ -943,7 +957,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     static const int env_wpc = getenv("GGML_MI355X_GEMV_WAVES_PER_CU") ? atoi(getenv("GGML_MI355X_GEMV_WAVES_PER_CU")) : 8;
     int lpr = 8;
     while (lpr < 64 && (int64_t) ntot * lpr / 64 < (int64_t) ctx->n_cu * env_wpc) lpr *= 2;
-    while (lpr > 8 && lpr / 2 >= K / 32) lpr /= 2;
+    while (lpr > 8 && lpr / 2 >= K / (wt == MI355X_TYPE_Q4_K ? 64 : 32)) lpr /= 2;
     if (env_lpr == 8 || env_lpr == 16 || env_lpr == 32 || env_lpr == 64) lpr = env_lpr;
     const int rpw = 64 / lpr;
     const int ngroups = (ntot + rpw - 1) / rpw;
@@ -962,6 +976,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         case MI355X_TYPE_Q4_0: return launch_gemv8<MI355X_TYPE_Q4_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
         case MI355X_TYPE_Q5_0: return launch_gemv8<MI355X_TYPE_Q5_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
         case MI355X_TYPE_Q8_0: return launch_gemv8<MI355X_TYPE_Q8_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q4_K: return launch_gemv8<MI355X_TYPE_Q4_K>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
     }
     return MI355X_E_UNSUPPORTED;
 }
@@ -1105,8 +1120,9 @@ struct QAArgs {
 template <int WT>
 __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int K = a.K, nb = K >> 5, K4 = K >> 2;
+    const int K = a.K, nb = Q4K ? K >> 6 : K >> 5, K4 = K >> 2, nsb = K >> 8;     // nb = lane-units per row (Q4_K: 64-element chunks)
     const int kg = lane >> 3, dc = lane & 7;
     // (an XCD-aware order — all key chunks of a head on one XCD, so that W_q of the head is fetched from HBM once instead of
     // once per XCD — halves the PMC traffic but measured 8.4 -> 10.6 us: the head's 393 KB of K/V then also funnel through one
@@ -1138,7 +1154,10 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     {
         const int gc = lane < nb ? lane : nb - 1;
         #pragma unroll
-        for (int r = 0; r < 8; r++) wblk_load<WT>(wr[r], (const char *) a.w, a.nbt, (int64_t) (qrow0 + r) * nb + gc);
+        for (int r = 0; r < 8; r++) {
+            if constexpr (Q4K) wblk_load_q4k(wr[r], (const char *) a.w, a.nbt, qrow0 + r, nsb, gc);
+            else               wblk_load<WT>(wr[r], (const char *) a.w, a.nbt, (int64_t) (qrow0 + r) * nb + gc);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -1146,10 +1165,10 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     float * qs  = red + 16;                                             // [64] projected, f16-rounded q of this head
     float * wo  = qs + 64;                                              // [8 waves][64] + [8][2] wave partials
     float * wml = wo + 8*64;
-    uint32_t * lo = (uint32_t *) (smem + 4096);
+    uint32_t * lo = (uint32_t *) (smem + 4096);                          // Q4_K: the four Q8_K planes [4][K/64] uint4
     uint32_t * hi = lo + (size_t) nb*4;
-    float * dx = (float *) (hi + (size_t) nb*4);
-    int *   sx = (int *) (dx + nb);
+    float * dx = Q4K ? (float *) (smem + 4096 + (size_t) K) : (float *) (hi + (size_t) nb*4);
+    int *   sx = Q4K ? (int *) (dx + nsb) : (int *) (dx + nb);          // Q4_K: per-32-element sums
 
     // ---- LayerNorm + Q8_0 quantization of the activation (ggml-cpu/ops.cpp:3698-3765, arch/x86/quants.c:302-398) ----
     {
@@ -1174,7 +1193,8 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
             float o[4] = { d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd };
             o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
             o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
-            dg_q8_0_store(o, tid*4, 0, nb, lo, hi, dx, sx);
+            if constexpr (Q4K) dg_q8_K_store(o, tid*4, 0, K, 1, lo, dx, sx);       // K % 256 == 0: whole waves take this branch
+            else               dg_q8_0_store(o, tid*4, 0, nb, lo, hi, dx, sx);
         }
     }
     __syncthreads();
@@ -1182,27 +1202,37 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     // ---- q_h: 8 rows per wave ----------------------------------------------------------------------------------------
     {
         const int gc = lane < nb ? lane : nb - 1;
-        const uint4 al = ((const uint4 *) lo)[gc], ah = ((const uint4 *) hi)[gc];
-        const float dxa = dx[gc]; const int sxa = sx[gc];
         float qv = 0.0f;
-        #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint32_t vlo[4], vhi[4];
-            wblk_unpack<WT>(wr[r], vlo, vhi);
-            const float dw = lane < nb ? h2f(wr[r].d) : 0.0f;
-            constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
-            int sum = 0;
-            sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
-            sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
-            if (off) sum -= off * sxa;
-            const float acc = wave_sum(fmaf(dw * dxa, (float) sum, 0.0f));
-            qv = (lane & 7) == r ? acc : qv;                            // lane r (mod 8) keeps row r
+        if constexpr (Q4K) {
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                float a1[1] = { 0.0f }, am1[1] = { 0.0f };
+                wblk_dot_q4k<1>(wr[r], gc, lane < nb ? 1.0f : 0.0f, nb, nsb, (const uint4 *) lo, dx, sx, a1, am1);
+                const float acc = wave_sum(a1[0] + am1[0]);
+                qv = (lane & 7) == r ? acc : qv;
+            }
+        } else {
+            const uint4 al = ((const uint4 *) lo)[gc], ah = ((const uint4 *) hi)[gc];
+            const float dxa = dx[gc]; const int sxa = sx[gc];
+            #pragma unroll
+            for (int r = 0; r < 8; r++) {
+                uint32_t vlo[4], vhi[4];
+                wblk_unpack<WT>(wr[r], vlo, vhi);
+                const float dw = lane < nb ? h2f(wr[r].d) : 0.0f;
+                constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+                int sum = 0;
+                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
+                if (off) sum -= off * sxa;
+                const float acc = wave_sum(fmaf(dw * dxa, (float) sum, 0.0f));
+                qv = (lane & 7) == r ? acc : qv;                        // lane r (mod 8) keeps row r
+            }
         }
         if (lane < 8) {
             float v = qv;
@@ -1276,7 +1306,8 @@ extern "C" int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc
     static const bool enabled = !(getenv("GGML_MI355X_QATTN") && !atoi(getenv("GGML_MI355X_QATTN")));
     if (!enabled || d->T != 1 || d->nseg != 1 || !d->has_norm || !d->x || d->attn_part_o) return MI355X_E_UNSUPPORTED;
     const int wt = d->seg[0].wtype, K = d->K, N = d->seg[0].N;
-    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0) return MI355X_E_UNSUPPORTED;
+    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;
+    if (wt == MI355X_TYPE_Q4_K && K % 256) return MI355X_E_UNSUPPORTED;
     if (K % 32 || K > 2048 || N % 64 || d->seg[0].ep.gelu || d->seg[0].ep.residual) return MI355X_E_UNSUPPORTED;
     if (((uintptr_t) d->x | (uintptr_t) d->ln_w | (uintptr_t) d->ln_b | (uintptr_t) d->seg[0].w) % 16) return MI355X_E_UNSUPPORTED;
     const int H = N / 64, n_kv = (int) k->ne[1];
@@ -1286,7 +1317,7 @@ extern "C" int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc
     if (mask && (mask->type != MI355X_TYPE_F16 || mask->ne[0] < n_kv || mask->nb[0] != 2 || mask->ne[2] != 1 || mask->ne[3] != 1)) return MI355X_E_UNSUPPORTED;
     QAArgs a; memset(&a, 0, sizeof(a));
     a.x = d->x; a.ln_w = d->ln_w; a.ln_b = d->ln_b; a.eps = d->eps; a.K = K;
-    a.w = d->seg[0].w; a.nbt = (int64_t) N * (K/32); a.bias = d->seg[0].ep.bias; a.qscale = d->seg[0].ep.scale; a.has_qscale = d->seg[0].ep.has_scale;
+    a.w = d->seg[0].w; a.nbt = (int64_t) N * (K / (wt == MI355X_TYPE_Q4_K ? 256 : 32)); a.bias = d->seg[0].ep.bias; a.qscale = d->seg[0].ep.scale; a.has_qscale = d->seg[0].ep.has_scale;
     a.k = to_d(k); a.v = to_d(v); if (mask) a.m = to_d(mask);
     a.has_mask = mask != nullptr; a.scale = scale; a.n_kv = n_kv; a.H = H;
     a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
@@ -1297,13 +1328,14 @@ extern "C" int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc
     a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
     if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
     const dim3 grid(a.nparts, H), block(512);
-    const uint32_t lds = 4096 + (uint32_t) (K/32) * 40;
+    const uint32_t lds = 4096 + (uint32_t) dg_act_bytes(wt, K, 1) + 64;
     const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) mi355x_type_row_bytes(wt, K) * N + (double) K*4 + (double) nrec*66*4;
     const double flops = 4.0 * (double) n_kv * 64 * H + 2.0 * (double) N * K;
     int rc;
     switch (wt) {
         case MI355X_TYPE_Q4_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_0>, grid, block, lds, a, bytes, flops); break;
         case MI355X_TYPE_Q5_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q5_0>, grid, block, lds, a, bytes, flops); break;
+        case MI355X_TYPE_Q4_K: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_K>, grid, block, lds, a, bytes, flops); break;
         default:               rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q8_0>, grid, block, lds, a, bytes, flops); break;
     }
     if (rc) return rc;

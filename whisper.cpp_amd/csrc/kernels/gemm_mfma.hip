@@ -177,7 +177,7 @@ __device__ __forceinline__ void a_unpack(const a_regs<AT> & r, int k /* global k
     } else if constexpr (AT == MI355X_TYPE_Q4_K) {
         const float d = h2f((uint16_t) (r.dm & 0xFFFF)), dmin = h2f((uint16_t) (r.dm >> 16));
         const int j = (k & 255) >> 5;
-        int sc, m; q4k_scale_min(j, (const uint8_t *) r.sc, sc, m);
+        int sc, m; q4k_scale_min_w(j, r.sc[0], r.sc[1], r.sc[2], sc, m);
         const float d1 = d * sc, m1 = dmin * m;
         const int sh = (j & 1) * 4;
         const uint32_t w[8] = { r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w };
