@@ -483,7 +483,10 @@ static int launch_gemv8(mi355x_ctx * ctx, const DGArgs & k, int T, int lpr, dim3
 // weights cannot be consumed before they arrive.  MODE selects the activation source at compile time for the same
 // reason (no phi between the sources): 0 plain x, 1 LayerNorm(x)*w+b, 2 combine of attention partial records.
 // ---------------------------------------------------------------------------------------------------
-template <int WT, int T, int XS, int MODE, bool NSEG1>                              // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads)
+// R = weight rows per wave.  1 for T <= 2.  With more columns every workgroup re-reads T*K*4 bytes of activations from L2
+// (26 MB per launch for 1024 workgroups at T = 5, six times the weight bytes): R = 4 rows per wave cuts the workgroup count
+// and that traffic by 4 while the same number of weight loads stays in flight.
+template <int WT, int T, int XS, int MODE, bool NSEG1, int R = 1>                   // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads)
 __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
     constexpr int NU = Q4K ? (XS == 1 ? 1 : 2) : (XS == 1 ? 1 : 3);      // units per lane: 32-element blocks (64-element chunks for Q4_K)
@@ -496,7 +499,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     const int K = a.K, nb = Q4K ? K >> 6 : K >> 5, K4 = K >> 2;           // nb = lane-units per row
     const int nsb = K >> 8;
     const int ntot = a.ntot;
-    const int grow = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + wave);
+    const int grow = __builtin_amdgcn_readfirstlane((blockIdx.x * nwaves + wave) * R);      // first of this wave's R rows (same segment, all valid or none: launcher)
     int s = 0;
     if constexpr (!NSEG1) {
         if (a.nseg > 1 && grow >= a.row_start[1]) s = 1;
@@ -571,21 +574,26 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         }
     }
     // bias / residual of (row, column lane): clamped column, dummy (valid) address when absent
-    const int tcol = lane < T ? lane : T - 1;
-    const float * bptr = sg.bias ? sg.bias + row : (const float *) a.gelu_tab;
-    const float * rptr = sg.residual ? (const float *) ((const char *) sg.residual + (int64_t) tcol*sg.res_nb1) + row : (const float *) a.gelu_tab;
+    // lane r*T + t finishes (row r, column t)
+    const int tcol = R == 1 ? (lane < T ? lane : T - 1) : lane % T;
+    const int rlane = R == 1 ? 0 : (lane / T < R ? lane / T : R - 1);
+    const float * bptr = sg.bias ? sg.bias + row + rlane : (const float *) a.gelu_tab;
+    const float * rptr = sg.residual ? (const float *) ((const char *) sg.residual + (int64_t) tcol*sg.res_nb1) + row + rlane : (const float *) a.gelu_tab;
     const float bias_v = *bptr, res_v = *rptr;
     __builtin_amdgcn_sched_barrier(0);
-    wblk<WT> wr[NU];
+    wblk<WT> wr[R][NU];
     {
         const char * base = (const char *) sg.w;
         const int64_t nbt = sg.nbt;
-        const int ib0 = row * nb;
         #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
-            if constexpr (Q4K) wblk_load_q4k(wr[u], base, nbt, row, nsb, gc);
-            else               wblk_load<WT>(wr[u], base, nbt, (int64_t) (ib0 + gc));
+        for (int r = 0; r < R; r++) {
+            const int ib0 = (row + r) * nb;
+            #pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+                if constexpr (Q4K) wblk_load_q4k(wr[r][u], base, nbt, row + r, nsb, gc);
+                else               wblk_load<WT>(wr[r][u], base, nbt, (int64_t) (ib0 + gc));
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -785,58 +793,76 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     // ---- dot products: lane handles blocks lane (+64, +128) of the wave's row; clamped duplicates carry weight 0 ----
     const uint4 * alo = (const uint4 *) lo;
     const uint4 * ahi = (const uint4 *) hi;
-    float acc[T];
+    float acc[R][T];
     #pragma unroll
-    for (int t = 0; t < T; t++) acc[t] = 0.0f;
+    for (int r = 0; r < R; r++)
+        #pragma unroll
+        for (int t = 0; t < T; t++) acc[r][t] = 0.0f;
     if constexpr (Q4K) {
-        float accm[T];
         #pragma unroll
-        for (int t = 0; t < T; t++) accm[t] = 0.0f;
-        #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
-            wblk_dot_q4k<T>(wr[u], gc, g < nb ? 1.0f : 0.0f, nb, nsb, alo, dx, sx, acc, accm);
+        for (int r = 0; r < R; r++) {
+            float accm[T];
+            #pragma unroll
+            for (int t = 0; t < T; t++) accm[t] = 0.0f;
+            #pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+                wblk_dot_q4k<T>(wr[r][u], gc, g < nb ? 1.0f : 0.0f, nb, nsb, alo, dx, sx, acc[r], accm);
+            }
+            #pragma unroll
+            for (int t = 0; t < T; t++) acc[r][t] += accm[t];
         }
-        #pragma unroll
-        for (int t = 0; t < T; t++) acc[t] += accm[t];
     } else {
         #pragma unroll
         for (int u = 0; u < NU; u++) {
             const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
-            uint32_t vlo[4], vhi[4];
-            wblk_unpack<WT>(wr[u], vlo, vhi);
-            const float dw = g < nb ? h2f(wr[u].d) : 0.0f;
+            uint32_t vlo[R][4], vhi[R][4];
+            float dw[R];
+            #pragma unroll
+            for (int r = 0; r < R; r++) {
+                wblk_unpack<WT>(wr[r][u], vlo[r], vhi[r]);
+                dw[r] = g < nb ? h2f(wr[r][u].d) : 0.0f;
+            }
             constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
             #pragma unroll
             for (int t = 0; t < T; t++) {
-                const uint4 al = alo[(size_t) t*nb + gc], ah = ahi[(size_t) t*nb + gc];
-                int sum = 0;
-                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
-                if (off) sum -= off * sx[t*nb + gc];
-                acc[t] = fmaf(dw * dx[t*nb + gc], (float) sum, acc[t]);
+                const uint4 al = alo[(size_t) t*nb + gc], ah = ahi[(size_t) t*nb + gc];       // one LDS read serves all R rows
+                const int sxv = off ? sx[t*nb + gc] : 0;
+                const float dxv = dx[t*nb + gc];
+                #pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int sum = 0;
+                    sum = __builtin_amdgcn_sdot4((int) vlo[r][0], (int) al.x, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[r][1], (int) al.y, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[r][2], (int) al.z, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[r][3], (int) al.w, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[r][0], (int) ah.x, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[r][1], (int) ah.y, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[r][2], (int) ah.z, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[r][3], (int) ah.w, sum, false);
+                    if (off) sum -= off * sxv;
+                    acc[r][t] = fmaf(dw[r] * dxv, (float) sum, acc[r][t]);
+                }
             }
         }
     }
     DG_STAMP(5);                                                        // weights arrived, dots done
     #pragma unroll
-    for (int t = 0; t < T; t++) acc[t] = wave_sum(acc[t]);
-    float v = acc[0];
+    for (int r = 0; r < R; r++)
+        #pragma unroll
+        for (int t = 0; t < T; t++) acc[r][t] = wave_sum(acc[r][t]);
+    float v = acc[0][0];
     #pragma unroll
-    for (int t = 1; t < T; t++) v = (lane == t) ? acc[t] : v;
-    if (rok && lane < T) {
+    for (int r = 0; r < R; r++)
+        #pragma unroll
+        for (int t = 0; t < T; t++) if (r + t > 0) v = (lane == r*T + t) ? acc[r][t] : v;
+    if (rok && lane < R*T) {
         if (sg.bias)      v = v + bias_v;
         if (sg.has_scale) v = v * sg.scale;
         if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
         if (sg.residual)  v = v + res_v;
-        char * dp = (char *) sg.dst + (int64_t) lane*sg.dst_nb1;
-        if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
+        char * dp = (char *) sg.dst + (int64_t) tcol*sg.dst_nb1;
+        if (sg.dst_f16) ((uint16_t *) dp)[row + rlane] = f2h(v); else ((float *) dp)[row + rlane] = v;
     }
     DG_STAMP(6);
 }
@@ -849,8 +875,22 @@ static inline int gemv_row_waves(int K) {
 }
 
 template <int WT, int MODE, bool NSEG1>
-static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
+static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops, int R = 1) {
     const char * name = "gemv";
+    if constexpr (MODE == 0 || MODE == 1) {
+        if (R == 4 && k.K <= 2048) {            // T >= 3: four rows per wave (grid already sized for it by the caller)
+            const dim3 block4(64 * gemv_row_waves(k.K));
+            switch (T) {
+                case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
+                case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
+                case 5: return emit(ctx, name, k_gemv_row<WT, 5, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
+                case 6: return emit(ctx, name, k_gemv_row<WT, 6, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
+                case 7: return emit(ctx, name, k_gemv_row<WT, 7, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
+                case 8: return emit(ctx, name, k_gemv_row<WT, 8, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
+                default: return MI355X_E_UNSUPPORTED;
+            }
+        }
+    }
     if (k.K > 2048) {
         if constexpr (MODE == 0 || MODE == 1) { if (T == 1) return emit(ctx, name, k_gemv_row<WT, 1, 5, MODE, NSEG1>, grid, dim3(256), lds, k, bytes, flops); }
         return MI355X_E_UNSUPPORTED;
@@ -875,21 +915,21 @@ static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 gri
     }
 }
 template <int WT>
-static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops) {
+static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops, int R = 1) {
     // wave-local LayerNorm (MODE 3) measured no faster than the workgroup version and slower for N >= 3840 (every one of
     // ~15 waves per CU repeats the statistics): off unless GGML_MI355X_GEMV_WAVE_LN=1
     static const bool wave_ln = getenv("GGML_MI355X_GEMV_WAVE_LN") && atoi(getenv("GGML_MI355X_GEMV_WAVE_LN"));
     if (k.x == nullptr) {
         if (k.nparts > 12 || k.nseg != 1) return MI355X_E_UNSUPPORTED;   // records of one column are held in registers, 12 at most
-        return launch_gemv_row_m<WT, 2, true>(ctx, k, T, grid, lds, bytes, flops);
+        return launch_gemv_row_m<WT, 2, true>(ctx, k, T, grid, lds, bytes, flops, R);
     }
     if (k.has_norm) {
         if (wave_ln && k.K <= 2048 && T <= 2)
             return k.nseg == 1 ? launch_gemv_row_m<WT, 3, true>(ctx, k, T, grid, lds, bytes, flops) : launch_gemv_row_m<WT, 3, false>(ctx, k, T, grid, lds, bytes, flops);
-        return k.nseg == 1 ? launch_gemv_row_m<WT, 1, true>(ctx, k, T, grid, lds, bytes, flops) : launch_gemv_row_m<WT, 1, false>(ctx, k, T, grid, lds, bytes, flops);
+        return k.nseg == 1 ? launch_gemv_row_m<WT, 1, true>(ctx, k, T, grid, lds, bytes, flops, R) : launch_gemv_row_m<WT, 1, false>(ctx, k, T, grid, lds, bytes, flops, R);
     }
     if (k.nseg != 1) return MI355X_E_UNSUPPORTED;                        // several segments without LayerNorm: generic kernel
-    return launch_gemv_row_m<WT, 0, true>(ctx, k, T, grid, lds, bytes, flops);
+    return launch_gemv_row_m<WT, 0, true>(ctx, k, T, grid, lds, bytes, flops, R);
 }
 
 // second-generation entry: returns MI355X_E_UNSUPPORTED for anything it does not cover (caller falls back to k_gemv)
@@ -935,14 +975,22 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         // 512-byte reduction header + activation planes (+ one float4 per thread and column when the attention combine
         // of T > 2 columns is staged through LDS)
         const size_t lds_row = 512 + dg_act_bytes(wt, K, T) + ((from_part && T > 2) ? (size_t) T * 64 * rpw * 16 + 16 : 0);
-        const int rpb = gemv_row_waves(K);
+        // rows per wave: 4 once the activation re-reads outweigh the weights (T >= 3), if every segment is a multiple of 4 rows
+        static const int env_r = getenv("GGML_MI355X_GEMV_ROWS") ? atoi(getenv("GGML_MI355X_GEMV_ROWS")) : 4;
+        // (measured at T = 5, large-v3: LN+FC1 11.3 -> 10.0 us, LN+QKV 12.5 -> 10.5 us; the 1280-row O-projection with its
+        // attention-combine prologue gets SLOWER on 64 workgroups, 12.1 -> 16.4 us, so it keeps one row per wave)
+        int R = (T >= 3 && K <= 2048 && env_r == 4 && !from_part && ntot / (gemv_row_waves(K) * 4) >= 128) ? 4 : 1;
+        for (int s = 0; s < d->nseg; s++) if (d->seg[s].N % 4) R = 1;
+        static const bool env_wave_ln = getenv("GGML_MI355X_GEMV_WAVE_LN") && atoi(getenv("GGML_MI355X_GEMV_WAVE_LN"));
+        if (d->has_norm && env_wave_ln) R = 1;
+        const int rpb = gemv_row_waves(K) * R;
         const dim3 grid((ntot + rpb - 1) / rpb);
         int rc = MI355X_E_UNSUPPORTED;
         switch (wt) {
-            case MI355X_TYPE_Q4_0: rc = launch_gemv_row<MI355X_TYPE_Q4_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
-            case MI355X_TYPE_Q5_0: rc = launch_gemv_row<MI355X_TYPE_Q5_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
-            case MI355X_TYPE_Q8_0: rc = launch_gemv_row<MI355X_TYPE_Q8_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
-            case MI355X_TYPE_Q4_K: rc = launch_gemv_row<MI355X_TYPE_Q4_K>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0); break;
+            case MI355X_TYPE_Q4_0: rc = launch_gemv_row<MI355X_TYPE_Q4_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0, R); break;
+            case MI355X_TYPE_Q5_0: rc = launch_gemv_row<MI355X_TYPE_Q5_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0, R); break;
+            case MI355X_TYPE_Q8_0: rc = launch_gemv_row<MI355X_TYPE_Q8_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0, R); break;
+            case MI355X_TYPE_Q4_K: rc = launch_gemv_row<MI355X_TYPE_Q4_K>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0, R); break;
         }
         if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
