@@ -273,6 +273,47 @@ extern "C" int mi355x_dequant_f16(mi355x_ctx * ctx, const mi355x_tensor * A, voi
     return rc;
 }
 
+// epilogue shared by the GEMM kernels: bias / scale / GELU / residual / f16 store on the 2 x NT accumulator tiles of a wave
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc)[2][NT], int m0, int64_t n0, int wm, int wn, int WN, int lane) {
+    // epilogue: C[i = A row][j = B row]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) && !a.dst_f16 &&
+                        (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || ((uintptr_t) a.bias % 16 == 0));
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        #pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int64_t t = n0 + wn*WN + j*32 + (lane & 31);
+            if (t >= a.T) continue;
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int m = m0 + wm*64 + i*32 + 8*g + 4*(lane >> 5);
+                if (m >= a.M) continue;
+                float v[4] = { acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3] };
+                if (vec_ok) {                                   // m % 4 == 0 and M % 4 == 0  =>  m+3 < M
+                    if (a.bias) { const float4 b = *(const float4 *) (a.bias + m); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (a.has_scale) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
+                    if (a.gelu) { v[0] = gelu_lut(v[0], a.gelu_tab); v[1] = gelu_lut(v[1], a.gelu_tab); v[2] = gelu_lut(v[2], a.gelu_tab); v[3] = gelu_lut(v[3], a.gelu_tab); }
+                    if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
+                    *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (m + e >= a.M) break;
+                        float x = v[e];
+                        if (a.bias) x += a.bias[m + e];
+                        if (a.has_scale) x *= a.scale;
+                        if (a.gelu) x = gelu_lut(x, a.gelu_tab);
+                        if (a.residual) x += *(const float *) (a.residual + t*a.res_nb1 + (int64_t) (m + e)*4);
+                        if (a.dst_f16) *(uint16_t *) (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*2) = f2h(x);
+                        else           *(float *)    (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*4) = x;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int AT, int BN>
 __global__ void __launch_bounds__(256) k_gemm_mfma(const GemmArgs a) {
     constexpr int WN = BN / 2;            // wave tile width (tokens)
@@ -345,42 +386,116 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const GemmArgs a) {
         if (kt + 1 < nk) { store_tile((kt + 1) * BK); __syncthreads(); }
     }
 
-    // epilogue: C[i = A row][j = B row]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) && !a.dst_f16 &&
-                        (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || ((uintptr_t) a.bias % 16 == 0));
+    gemm_epilogue<NT>(a, acc, m0, n0, wm, wn, WN, lane);
+}
+
+// -------------------------------------------------------------------------------------------------
+// k_gemm_f16_ring: the GEMM for two plain f16 operands, A [M][K] (a weight's f16 copy, or an f16 weight) and B [T][K]
+// (prepared activations), both K-contiguous.  Nothing passes through VGPRs on the way in: every wave fills its share of a
+// ring of NST LDS stages with `global_load_lds` (16 bytes per lane, 1 KB = 8 rows x 128 B per instruction; the XOR swizzle
+// that keeps the ds_read_b128 fragment reads conflict-free is applied to the per-lane GLOBAL address because the LDS side
+// of an LDS-DMA is lane-linear), NST-1 K-steps ahead of the MFMAs.  One raw s_barrier per K-step; the wait for a stage is a
+// counted s_waitcnt vmcnt(G * stages_still_in_flight), never 0 inside the loop.  All LDS is ONE array and no ordinary
+// global load is issued inside the loop (either would make hipcc drain the DMA queue every step).  Same fragment
+// layout, MFMA and K order as k_gemm_mfma => bit-identical results.
+// -------------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+template <int BN, int NST>
+__global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
+    constexpr int WN = BN / 2, NT = WN / 32;
+    constexpr int STAGE = (BM + BN) * 128;            // bytes per stage: A tile [128][64] f16, B tile [BN][64] f16
+    constexpr int GA = BM / 32, GB = BN / 32;         // LDS-DMA instructions per wave and stage: 8 rows each
+    constexpr int G = GA + GB;
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int64_t n0 = (int64_t) blockIdx.y * BN;
+    const int nk = a.K / BK;
+
+    // this lane's share of a stage: row (lane >> 3) of each 8-row group, physical 16-byte slot (lane & 7), which holds the
+    // logical k-slot (lane & 7) ^ ((row >> 1) & 7)  (lds_off).  Rows past the matrix edge are clamped (their columns /
+    // rows are never stored).
+    const char * ga[GA]; const char * gb[GB];
     #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < GA; i++) {
+        const int r = wave * (BM / 4) + i * 8 + (lane >> 3);
+        const int mr = m0 + r < a.M ? m0 + r : a.M - 1;
+        ga[i] = a.A + (int64_t) mr * a.a_nb1 + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+    }
+    #pragma unroll
+    for (int i = 0; i < GB; i++) {
+        const int r = wave * (BN / 4) + i * 8 + (lane >> 3);
+        const int64_t tr = n0 + r < a.T ? n0 + r : a.T - 1;
+        gb[i] = (const char *) (a.B + tr * a.ldb) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+    }
+    auto issue = [&](int kt) {
+        char * st = ring + (kt % NST) * STAGE;
+        const int koff = kt * BK * 2;
         #pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int64_t t = n0 + wn*WN + j*32 + (lane & 31);
-            if (t >= a.T) continue;
+        for (int i = 0; i < GA; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (ga[i] + koff),
+                                             (__attribute__((address_space(3))) void *) (st + (wave * (BM / 4) + i * 8) * 128), 16, 0, 0);
+        #pragma unroll
+        for (int i = 0; i < GB; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (gb[i] + koff),
+                                             (__attribute__((address_space(3))) void *) (st + BM*128 + (wave * (BN / 4) + i * 8) * 128), 16, 0, 0);
+    };
+
+    floatx16 acc[2][NT];
+    #pragma unroll
+    for (int i = 0; i < 2; i++)
+        #pragma unroll
+        for (int j = 0; j < NT; j++)
             #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int m = m0 + wm*64 + i*32 + 8*g + 4*(lane >> 5);
-                if (m >= a.M) continue;
-                float v[4] = { acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3] };
-                if (vec_ok) {                                   // m % 4 == 0 and M % 4 == 0  =>  m+3 < M
-                    if (a.bias) { const float4 b = *(const float4 *) (a.bias + m); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                    if (a.has_scale) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
-                    if (a.gelu) { v[0] = gelu_lut(v[0], a.gelu_tab); v[1] = gelu_lut(v[1], a.gelu_tab); v[2] = gelu_lut(v[2], a.gelu_tab); v[3] = gelu_lut(v[3], a.gelu_tab); }
-                    if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                    *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        if (m + e >= a.M) break;
-                        float x = v[e];
-                        if (a.bias) x += a.bias[m + e];
-                        if (a.has_scale) x *= a.scale;
-                        if (a.gelu) x = gelu_lut(x, a.gelu_tab);
-                        if (a.residual) x += *(const float *) (a.residual + t*a.res_nb1 + (int64_t) (m + e)*4);
-                        if (a.dst_f16) *(uint16_t *) (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*2) = f2h(x);
-                        else           *(float *)    (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*4) = x;
-                    }
-                }
-            }
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    #pragma unroll
+    for (int p = 0; p < NST - 1; p++) if (p < nk) issue(p);
+
+    for (int kt = 0; kt < nk; kt++) {
+        // stages issued after stage kt and still allowed in flight: min(NST - 2, nk - 1 - kt)
+        const int ahead = nk - 1 - kt;
+        if (ahead >= NST - 2)      wait_vmcnt<G * (NST - 2)>();
+        else if (ahead == 1)       wait_vmcnt<G>();
+        else                       wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                 // stage kt complete in LDS for every wave; everyone is done reading stage kt-1
+        if (kt + NST - 1 < nk) issue(kt + NST - 1);    // refill the slot of stage kt-1
+
+        const char * ldsA = ring + (kt % NST) * STAGE;
+        const char * ldsB = ldsA + BM*128;
+        #pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            half8_t af[2], bf[NT];
+            const int slot = kk*2 + (lane >> 5);
+            #pragma unroll
+            for (int i = 0; i < 2; i++) af[i] = *(const half8_t *) (ldsA + lds_off(wm*64 + i*32 + (lane & 31), slot));
+            #pragma unroll
+            for (int j = 0; j < NT; j++) bf[j] = *(const half8_t *) (ldsB + lds_off(wn*WN + j*32 + (lane & 31), slot));
+            #pragma unroll
+            for (int i = 0; i < 2; i++)
+                #pragma unroll
+                for (int j = 0; j < NT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
+    gemm_epilogue<NT>(a, acc, m0, n0, wm, wn, WN, lane);
+}
+
+template <int BN, int NST>
+static int launch_ring(mi355x_ctx * ctx, const GemmArgs & k, dim3 grid, double bytes, double flops) {
+    constexpr uint32_t lds = (uint32_t) NST * (BM + BN) * 128;
+    static bool attr_set = false;                      // > 64 KB of dynamic LDS needs the attribute once per function
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *) k_gemm_f16_ring<BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) {
+            (void) hipGetLastError();
+            return MI355X_E_UNSUPPORTED;
+        }
+        attr_set = true;
+    }
+    return emit(ctx, "gemm_f16_ring", k_gemm_f16_ring<BN, NST>, grid, dim3(256), lds, k, bytes, flops);
 }
 
 template <int AT>
@@ -388,6 +503,25 @@ static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, doubl
     // pick BN so the grid covers the chip: 128-wide token tiles unless that leaves CUs idle
     const int64_t mt = (k.M + BM - 1) / BM;
     const int64_t nt128 = (k.T + 127) / 128, nt64 = (k.T + 63) / 64;
+    if constexpr (AT == MI355X_TYPE_F16) {
+        // both operands plain f16: the LDS-DMA ring (GGML_MI355X_GEMM_RING=0 keeps the register-staged kernel)
+        static const bool ring_on = !(getenv("GGML_MI355X_GEMM_RING") && !atoi(getenv("GGML_MI355X_GEMM_RING")));
+        if (ring_on && k.K % BK == 0 && k.K >= 2*BK && (k.a_nb1 % 16) == 0 && ((uintptr_t) k.A % 16) == 0 && (k.ldb % 8) == 0 && nt64 <= 65535) {
+            int rc;
+            static const int nst128 = getenv("GGML_MI355X_GEMM_RING_NST128") ? atoi(getenv("GGML_MI355X_GEMM_RING_NST128")) : 3;
+            static const int nst64  = getenv("GGML_MI355X_GEMM_RING_NST64")  ? atoi(getenv("GGML_MI355X_GEMM_RING_NST64"))  : 4;
+            const dim3 g128((uint32_t) mt, (uint32_t) nt128), g64((uint32_t) mt, (uint32_t) nt64);
+            if (mt * nt128 >= ctx->n_cu) rc = nst128 == 2 ? launch_ring<128, 2>(ctx, k, g128, bytes, flops)
+                                            : nst128 == 4 ? launch_ring<128, 4>(ctx, k, g128, bytes, flops)
+                                                          : launch_ring<128, 3>(ctx, k, g128, bytes, flops);
+            else                         rc = nst64 == 2 ? launch_ring<64, 2>(ctx, k, g64, bytes, flops)
+                                            : nst64 == 3 ? launch_ring<64, 3>(ctx, k, g64, bytes, flops)
+                                            : nst64 == 5 ? launch_ring<64, 5>(ctx, k, g64, bytes, flops)
+                                            : nst64 == 6 ? launch_ring<64, 6>(ctx, k, g64, bytes, flops)
+                                                         : launch_ring<64, 4>(ctx, k, g64, bytes, flops);
+            if (rc != MI355X_E_UNSUPPORTED) return rc;
+        }
+    }
     if (mt * nt128 >= ctx->n_cu || k.T > 64*65535LL) {
         if (nt128 > 65535) return MI355X_E_UNSUPPORTED;
         return emit(ctx, "gemm_mfma", k_gemm_mfma<AT, 128>, dim3((uint32_t) mt, (uint32_t) nt128), dim3(256), 0, k, bytes, flops);
