@@ -255,6 +255,10 @@ def main():
     host_ms = [host1[i] - host0[i] for i in range(13)]          # host-side time inside the backend during the timed region only
 
     # reported beside the headline (bench.cpp:138-152): 5-token batches and 256-token prompts
+    # (one untimed pass of each shape first, as whisper-bench's own heat-up does, bench.cpp:94-121: the first 256-column pass
+    # makes the one-time f16 copies of the decoder weights and instantiates its hipGraphs)
+    w.whisper_decode(ctx, tokens, 5, 0, n_threads)
+    w.whisper_decode(ctx, tokens, 256, 0, n_threads)
     w.whisper_reset_timings(ctx)
     for _ in range(16):
         w.whisper_decode(ctx, tokens, 5, 0, n_threads)

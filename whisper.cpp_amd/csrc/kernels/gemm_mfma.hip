@@ -92,6 +92,7 @@ struct GemmArgs {
     const float * bias; float scale; int has_scale; int gelu;
     const char * residual; int64_t res_nb1;
     const uint16_t * gelu_tab;
+    int mt, nt, per, m_major;                           // k_gemm_f16_ring: tile counts and the XCD-aware tile order (launch_ring)
 };
 
 #define BM 128
@@ -411,8 +412,18 @@ __global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM;
-    const int64_t n0 = (int64_t) blockIdx.y * BN;
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2, so
+    // with the natural order each XCD ends up reading (nearly) all of A and all of B: PMC showed 55 MB of fabric reads for
+    // the 7 MB of operands of a 1280 x 1500 x 1280 product.  Here XCD x = id % 8 works through the contiguous tile range
+    // [x*per, (x+1)*per) of an order in which neighbours share an operand (whole columns of tiles, or whole rows —
+    // whichever moves fewer bytes, chosen on the host).
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = xcd * a.per + idx;
+    if (tile >= a.mt * a.nt) return;                  // padding blocks of the last XCD range (uniform exit, before any barrier)
+    const int mi = a.m_major ? tile / a.nt : tile % a.mt;
+    const int ni = a.m_major ? tile % a.nt : tile / a.mt;
+    const int m0 = mi * BM;
+    const int64_t n0 = (int64_t) ni * BN;
     const int nk = a.K / BK;
 
     // this lane's share of a stage: row (lane >> 3) of each 8-row group, physical 16-byte slot (lane & 7), which holds the
@@ -485,8 +496,20 @@ __global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
 }
 
 template <int BN, int NST>
-static int launch_ring(mi355x_ctx * ctx, const GemmArgs & k, dim3 grid, double bytes, double flops) {
+static int launch_ring(mi355x_ctx * ctx, const GemmArgs & k0, dim3 tiles, double bytes, double flops) {
     constexpr uint32_t lds = (uint32_t) NST * (BM + BN) * 128;
+    GemmArgs k = k0;
+    k.mt = (int) tiles.x; k.nt = (int) tiles.y;
+    const int64_t ntiles = (int64_t) k.mt * k.nt;
+    k.per = (int) ((ntiles + 7) / 8);
+    {   // bytes each XCD pulls through its L2 for its `per` consecutive tiles, column-major vs row-major tile order
+        const double a_tile = (double) BM * k.K * 2, b_tile = (double) BN * k.K * 2;
+        const double col_major = a_tile * (k.per < k.mt ? k.per : k.mt) + b_tile * ((k.per + k.mt - 1) / k.mt + (k.per % k.mt ? 1 : 0));
+        const double row_major = b_tile * (k.per < k.nt ? k.per : k.nt) + a_tile * ((k.per + k.nt - 1) / k.nt + (k.per % k.nt ? 1 : 0));
+        static const int force = getenv("GGML_MI355X_GEMM_XCD_ORDER") ? atoi(getenv("GGML_MI355X_GEMM_XCD_ORDER")) : -1;
+        k.m_major = force >= 0 ? force : (row_major < col_major ? 1 : 0);
+    }
+    const dim3 grid((uint32_t) (8 * k.per));
     static bool attr_set = false;                      // > 64 KB of dynamic LDS needs the attribute once per function
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *) k_gemm_f16_ring<BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) {
@@ -508,7 +531,9 @@ static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, doubl
         static const bool ring_on = !(getenv("GGML_MI355X_GEMM_RING") && !atoi(getenv("GGML_MI355X_GEMM_RING")));
         if (ring_on && k.K % BK == 0 && k.K >= 2*BK && (k.a_nb1 % 16) == 0 && ((uintptr_t) k.A % 16) == 0 && (k.ldb % 8) == 0 && nt64 <= 65535) {
             int rc;
-            static const int nst128 = getenv("GGML_MI355X_GEMM_RING_NST128") ? atoi(getenv("GGML_MI355X_GEMM_RING_NST128")) : 3;
+            // stages: measured on large-v3 encode — 64-wide tiles (one block per CU): 2 -> 13.0 ms, 3 -> 11.3, 4 -> 10.9, 5/6 no better;
+            // 128-wide tiles (FC1, ~2 blocks per CU): 2 stages (64 KB, two blocks co-resident) 10.6-10.8 vs 3 -> 10.9, 4 -> 11.0
+            static const int nst128 = getenv("GGML_MI355X_GEMM_RING_NST128") ? atoi(getenv("GGML_MI355X_GEMM_RING_NST128")) : 2;
             static const int nst64  = getenv("GGML_MI355X_GEMM_RING_NST64")  ? atoi(getenv("GGML_MI355X_GEMM_RING_NST64"))  : 4;
             const dim3 g128((uint32_t) mt, (uint32_t) nt128), g64((uint32_t) mt, (uint32_t) nt64);
             if (mt * nt128 >= ctx->n_cu) rc = nst128 == 2 ? launch_ring<128, 2>(ctx, k, g128, bytes, flops)
