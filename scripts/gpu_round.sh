@@ -29,7 +29,7 @@ bench)
 prof)
     stage "rocprofv3 --kernel-trace --stats (bench.py $ARCH $QT, 1 step)"
     rm -rf "$OUT/prof"
-    ( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline \
+    ( cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline --multi-stream 0 \
         > "$OUT/prof_bench.json" 2> "$OUT/prof_bench.err" )
     echo "exit=$?"
     f=$(find "$OUT/prof" -name "*kernel_stats.csv" | head -1)
@@ -43,7 +43,7 @@ pmc)
     for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
         tag=$(echo "$ctr" | tr ' ' '+')
         rm -rf "$OUT/pmc_$tag"
-        ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace -f csv -d "$OUT/pmc_$tag" -o pmc -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 0 --n-decode 8 --no-cpu-baseline --no-profile \
+        ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace -f csv -d "$OUT/pmc_$tag" -o pmc -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 0 --n-decode 8 --no-cpu-baseline --no-profile --multi-stream 0 \
             > "$OUT/pmc_$tag.json" 2> "$OUT/pmc_$tag.err" )
         echo "$tag exit=$?"
         python3 scripts/summarize_pmc.py "$OUT/pmc_$tag" > "$OUT/pmc_$tag.summary.txt" 2>&1; head -30 "$OUT/pmc_$tag.summary.txt"
@@ -53,7 +53,7 @@ pmc)
 eager)
     stage "bench.py with GGML_MI355X_GRAPHS=0 (eager launches) under rocprofv3"
     rm -rf "$OUT/prof_eager"
-    ( cd /tmp && GGML_MI355X_GRAPHS=0 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_eager" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline --no-profile \
+    ( cd /tmp && GGML_MI355X_GRAPHS=0 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_eager" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline --no-profile --multi-stream 0 \
         > "$OUT/prof_eager.json" 2> "$OUT/prof_eager.err" )
     echo "exit=$?"; cat "$OUT/prof_eager.json" | cut -c1-900
     python3 scripts/summarize_trace.py "$OUT/prof_eager" > "$OUT/kernel_trace_summary_eager.txt" 2>&1; grep -v "at::\|rocclr" "$OUT/kernel_trace_summary_eager.txt" | head -12; sed -n '/decode-step anatomy/,$p' "$OUT/kernel_trace_summary_eager.txt" | head -50
