@@ -16,6 +16,7 @@
 //  * Global loads for K-step k+1 are issued before the MFMAs of step k (register-staged prefetch), LDS tiles
 //    are conflict-free for ds_read_b128 via slot ^= (row>>1)&7.
 #include "common.h"
+#include <atomic>
 
 // -------------------------------------------------------------------------------------------------
 // activation preparation: f32 [K, T] (ggml src1) -> f16 [T][K]
@@ -510,13 +511,14 @@ static int launch_ring(mi355x_ctx * ctx, const GemmArgs & k0, dim3 tiles, double
         k.m_major = force >= 0 ? force : (row_major < col_major ? 1 : 0);
     }
     const dim3 grid((uint32_t) (8 * k.per));
-    static bool attr_set = false;                      // > 64 KB of dynamic LDS needs the attribute once per function
-    if (!attr_set) {
+    static std::atomic<bool> attr_set[64];             // > 64 KB of dynamic LDS needs the attribute once per function AND device
+    const int dev = ctx->device & 63;
+    if (!attr_set[dev].load()) {
         if (hipFuncSetAttribute((const void *) k_gemm_f16_ring<BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) {
             (void) hipGetLastError();
             return MI355X_E_UNSUPPORTED;
         }
-        attr_set = true;
+        attr_set[dev].store(true);
     }
     return emit(ctx, "gemm_f16_ring", k_gemm_f16_ring<BN, NST>, grid, dim3(256), lds, k, bytes, flops);
 }
