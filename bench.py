@@ -360,6 +360,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "ms/chunk", "cores": cores, "kind": "reference", "sample": f"failed: {e}"}
         print(json.dumps(out))
+    barrier()                   # rank 0 may still be profiling / printing: nobody tears the process group down under it
     w.whisper_free(ctx)
     if dist is not None:
         dist.destroy_process_group()
