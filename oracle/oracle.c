@@ -128,6 +128,109 @@ void oracle_dequantize_row(int type, const void * blocks, float * y, int64_t n) 
 
 #define OR_MIN(a, b) ((a) < (b) ? (a) : (b))
 
+
+/* ---- Q4_K weight quantizer (quantize_row_q4_K_ref, ggml-quants.c:1457-1527, with make_qkx2_quants :799-878) ----------
+ * Per 32 values: fit x ~ scale*q + min (q in 0..15, min <= 0) by weighted least squares, weights = rms(x) + |x|, trying the
+ * 21 candidate grids iscale = (15 - 1 + 0.1*k)/(max - min); keep the one with the smallest weighted squared error.
+ * Per 256 values: the 8 scales and 8 (negated) mins are themselves quantized to 6 bits against their maxima, the values are
+ * re-rounded against the quantized scale/min.  Written for bit-equality with the reference built without FMA contraction
+ * (upstream compiles ggml-base without -mfma; every product and sum below is a separate f32 operation in that order). */
+static int q4k_rint(float v) { return (int) rintf(v); }                 /* nearest_int :621-626 (ties to even) */
+
+static float q4k_fit32(const float * x, const float * wt, uint8_t * q, float * neg_min) {
+    float lo = x[0], hi = x[0], sw = wt[0], swx = wt[0] * x[0];
+    for (int i = 1; i < 32; i++) {
+        if (x[i] < lo) lo = x[i];
+        if (x[i] > hi) hi = x[i];
+        sw += wt[i];
+        swx += wt[i] * x[i];
+    }
+    if (lo > 0) lo = 0;
+    if (hi == lo) { memset(q, 0, 32); *neg_min = -lo; return 0.0f; }
+    float inv = 15 / (hi - lo), scale = 1 / inv, best = 0;
+    for (int i = 0; i < 32; i++) {
+        int l = q4k_rint(inv * (x[i] - lo));
+        l = l < 0 ? 0 : (l > 15 ? 15 : l);
+        q[i] = (uint8_t) l;
+        float e = scale * q[i] + lo - x[i];
+        e = e * e;
+        best += wt[i] * e;
+    }
+    uint8_t trial[32];
+    for (int step = 0; step <= 20; step++) {
+        inv = (-1.f + 0.1f * step + 15) / (hi - lo);
+        float sl = 0, sl2 = 0, sxl = 0;
+        for (int i = 0; i < 32; i++) {
+            int l = q4k_rint(inv * (x[i] - lo));
+            l = l < 0 ? 0 : (l > 15 ? 15 : l);
+            trial[i] = (uint8_t) l;
+            const float w = wt[i];
+            sl  += w * l;
+            sl2 += w * l * l;
+            sxl += w * l * x[i];
+        }
+        const float det = sw * sl2 - sl * sl;
+        if (det > 0) {
+            float sc = (sw * sxl - swx * sl) / det;
+            float mn = (sl2 * swx - sl * sxl) / det;
+            if (mn > 0) { mn = 0; sc = sxl / sl2; }
+            float err = 0;
+            for (int i = 0; i < 32; i++) {
+                float e = sc * trial[i] + mn - x[i];
+                e = e * e;
+                err += wt[i] * e;
+            }
+            if (err < best) { memcpy(q, trial, 32); best = err; scale = sc; lo = mn; }
+        }
+    }
+    *neg_min = -lo;
+    return scale;
+}
+
+static void q4k_quantize_superblock(const float * x, blk_q4_K * y) {
+    uint8_t q[256];
+    float scales[8], mins[8], wt[32];
+    float top_scale = 0, top_min = 0;
+    for (int j = 0; j < 8; j++) {
+        float ss = 0;
+        for (int l = 0; l < 32; l++) ss += x[32*j + l] * x[32*j + l];
+        const float rms = sqrtf(ss / 32);
+        for (int l = 0; l < 32; l++) wt[l] = rms + fabsf(x[32*j + l]);
+        scales[j] = q4k_fit32(x + 32*j, wt, q + 32*j, &mins[j]);
+        if (scales[j] > top_scale) top_scale = scales[j];
+        if (mins[j] > top_min) top_min = mins[j];
+    }
+    const float is = top_scale > 0 ? 63.f / top_scale : 0.f, im = top_min > 0 ? 63.f / top_min : 0.f;
+    memset(y->scales, 0, 12);
+    for (int j = 0; j < 8; j++) {                                       /* 6-bit packing, get_scale_min_k4's inverse (:880-887) */
+        uint8_t ls = (uint8_t) q4k_rint(is * scales[j]), lm = (uint8_t) q4k_rint(im * mins[j]);
+        if (ls > 63) ls = 63;
+        if (lm > 63) lm = 63;
+        if (j < 4) { y->scales[j] |= ls; y->scales[j + 4] |= lm; }
+        else {
+            y->scales[j + 4] |= (uint8_t) ((ls & 0xF) | ((lm & 0xF) << 4));
+            y->scales[j - 4] |= (uint8_t) ((ls >> 4) << 6);
+            y->scales[j]     |= (uint8_t) ((lm >> 4) << 6);
+        }
+    }
+    y->d    = oracle_f32_to_f16(top_scale / 63.f);
+    y->dmin = oracle_f32_to_f16(top_min / 63.f);
+    for (int j = 0; j < 8; j++) {                                       /* re-round against the quantized scale / min */
+        int sc, m;
+        if (j < 4) { sc = y->scales[j] & 63; m = y->scales[j + 4] & 63; }
+        else { sc = (y->scales[j + 4] & 0xF) | ((y->scales[j - 4] >> 6) << 4); m = (y->scales[j + 4] >> 4) | ((y->scales[j] >> 6) << 4); }
+        const float d = oracle_f16_to_f32(y->d) * sc;
+        if (!d) continue;
+        const float dm = oracle_f16_to_f32(y->dmin) * m;
+        for (int l = 0; l < 32; l++) {
+            int v = q4k_rint((x[32*j + l] + dm) / d);
+            q[32*j + l] = (uint8_t) (v < 0 ? 0 : (v > 15 ? 15 : v));
+        }
+    }
+    for (int c = 0; c < 4; c++)
+        for (int l = 0; l < 32; l++) y->qs[32*c + l] = (uint8_t) (q[64*c + l] | (q[64*c + 32 + l] << 4));
+}
+
 void oracle_quantize_row_ref(int type, const float * x, void * blocks, int64_t n) {
     if (type == ORACLE_Q4_0 || type == ORACLE_Q5_0) {                     /* ggml-quants.c:113-148, :187-230 */
         const int lv = type == ORACLE_Q4_0 ? 8 : 16;
@@ -167,6 +270,8 @@ void oracle_quantize_row_ref(int type, const float * x, void * blocks, int64_t n
             b->d = oracle_f32_to_f16(d);
             for (int j = 0; j < 32; j++) b->qs[j] = (int8_t) roundf(x[i*32 + j] * id);
         }
+    } else if (type == ORACLE_Q4_K) {
+        for (int64_t i = 0; i < n / 256; i++) q4k_quantize_superblock(x + i*256, (blk_q4_K *) blocks + i);
     } else if (type == ORACLE_F16) {
         uint16_t * h = (uint16_t *) blocks;
         for (int64_t i = 0; i < n; i++) h[i] = oracle_f32_to_f16(x[i]);

@@ -58,6 +58,17 @@ def blocks_npz():
         getattr(base, f"dequantize_row_{t}")(blk.ctypes.data_as(C.c_void_p), deq.ctypes.data_as(C.c_void_p), C.c_int64(n))
         out[f"wblk_{t}"] = blk
         out[f"wdeq_{t}"] = deq
+    # a wider Q4_K weight-quantizer case (make_qkx2_quants search): varied magnitudes per 32-block, an all-zero super-block,
+    # an all-positive 32-block (min clamps to 0), a constant block, a block with one outlier
+    xk = (rng.standard_normal(16 * 256) * np.repeat(rng.uniform(0.001, 3.0, 16 * 8), 32)).astype(np.float32)
+    xk[256:512] = 0.0
+    xk[512:544] = np.abs(xk[512:544]) + 0.25
+    xk[544:576] = 0.731
+    xk[576:608] *= 0.01; xk[590] = 4.0
+    kb = np.zeros(144 * 16, dtype=np.uint8)
+    base.quantize_row_q4_K_ref(xk.ctypes.data_as(C.c_void_p), kb.ctypes.data_as(C.c_void_p), C.c_int64(len(xk)))
+    out["q4k_x"] = xk
+    out["q4k_blk"] = kb
     a8 = np.zeros(34 * n // 32, dtype=np.uint8)
     cpu.quantize_row_q8_0(x.ctypes.data_as(C.c_void_p), a8.ctypes.data_as(C.c_void_p), C.c_int64(n))      # AVX2 path
     out["act_q8_0"] = a8

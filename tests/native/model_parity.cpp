@@ -40,7 +40,7 @@ int main(int argc, char ** argv) {
     const char * model = argv[1];
     const int n_steps = argc > 2 ? atoi(argv[2]) : 24;
     const bool fa = argc > 3 ? atoi(argv[3]) != 0 : true;
-    const int n_threads = 8;
+    const int n_threads = getenv("MODEL_PARITY_THREADS") ? atoi(getenv("MODEL_PARITY_THREADS")) : 8;
     whisper_log_set(log_quiet, nullptr);
     const char * plugin = getenv("GGML_MI355X_PLUGIN");
     const bool selftest = plugin && !strcmp(plugin, "cpu");     // harness self-test: CPU against CPU

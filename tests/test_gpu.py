@@ -52,9 +52,9 @@ def dev(torch, a: np.ndarray):
 
 def quantize(oracle, ka, tid, wf):
     """reference weight quantizer (restated in the oracle, pinned bit-exact by tests/test_oracle.py) -> ggml blocks + planar.
-    Q4_K: the oracle restates the dequantizer and the dot product but not make_qkx2_quants (the weight quantizer is not
-    on the hot path: whisper-quantize produces the file), so valid super-blocks are drawn directly: any bit pattern with
-    finite d / dmin is a legal block_q4_K (ggml-common.h:327-338)."""
+    Q4_K: super-blocks are drawn directly — any bit pattern with finite d / dmin is a legal block_q4_K
+    (ggml-common.h:327-338) and arbitrary 6-bit scale / min combinations are a harder input for the kernels than the
+    quantizer's output (the oracle's restated quantize_row_q4_K_ref is pinned separately in tests/test_oracle.py)."""
     N, K = wf.shape
     if tid == 12:
         rng = np.random.default_rng(N * 31 + K)
@@ -575,7 +575,7 @@ def test_plugin_op_parity_against_reference_cpu_backend(plugin_env, tmp_path):
     assert n > 250, n
 
 
-@pytest.mark.parametrize("arch,qtype", [("micro", "q5_0"), ("base.en", "q5_0"), ("base.en", "q4_k"), ("large-v3-2l", "q8_0")])
+@pytest.mark.parametrize("arch,qtype", [("micro", "q5_0"), ("base.en", "q5_0"), ("base.en", "q4_k"), ("large-v3-2l", "q8_0"), ("large-v3", "q5_0")])
 def test_plugin_model_parity(plugin_env, arch, qtype):
     """same model file through the unmodified libwhisper on the reference CPU backend and on the plugin: logits within
     tolerance at every teacher-forced step; greedy tokens identical wherever the CPU's own top-2 margin exceeds the
@@ -583,7 +583,11 @@ def test_plugin_model_parity(plugin_env, arch, qtype):
     from whisper_cpp_amd.synth_model import make_model
     m = make_model(arch, qtype)
     env = dict(plugin_env, GGML_MI355X_STRICT="1")
-    r = subprocess.run([str(_native("model_parity")), str(m), "16"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    steps = "16"
+    if arch == "large-v3":          # the headline configuration at full size: 32 + 32 layers; the CPU side gets more threads, fewer steps
+        env["MODEL_PARITY_THREADS"] = str(max(8, min(32, (os.cpu_count() or 16) // 2)))
+        steps = "8"
+    r = subprocess.run([str(_native("model_parity")), str(m), steps], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout)
     keep = ROOT / "gpurun_out"
@@ -595,7 +599,12 @@ def test_plugin_model_parity(plugin_env, arch, qtype):
     for st in d["steps"]:
         if st["tok_cpu"] != st["tok_gpu"]:
             assert st["margin"] <= 4 * st["max_diff"], st
-    assert d["batch5"]["nmse"] < 5e-4 and d["batch48"]["nmse"] < 5e-4, d
+    # multi-token rows: 5e-4 on the 2-6 layer models; at the full 32 + 32 layers the difference grows to 1.0e-3 (unchanged by
+    # any choice of our decode kernels: it is the encoder's f16-product / f32-softmax difference propagated through cross
+    # attention) while the reference's OWN two attention paths (CPU flash-attn on vs off, same model, same rows) differ by
+    # 6.9e-3 / 7.3e-3: profiles/r01_reference_self_spread_large-v3_q5_0.json (model_parity self-test, MODEL_PARITY_SPREAD=1)
+    tol_batch = 2e-3 if arch == "large-v3" else 5e-4
+    assert d["batch5"]["nmse"] < tol_batch and d["batch48"]["nmse"] < tol_batch, d
 
 
 @pytest.mark.parametrize("arch,qtype", [("micro", "q5_0"), ("base.en", "q5_0"), ("base.en", "q8_0")])

@@ -62,12 +62,33 @@ def test_dequantize_bit_exact(oracle, blocks, t):
         assert np.array_equal(y, ref)
 
 
-@pytest.mark.parametrize("t", ["q4_0", "q5_0", "q8_0"])
+@pytest.mark.parametrize("t", ["q4_0", "q5_0", "q8_0", "q4_K"])
 def test_weight_quantizer_bit_exact(oracle, blocks, t):
     w = blocks["w"]
     blk = np.zeros_like(blocks[f"wblk_{t}"])
     oracle.oracle_quantize_row_ref(TYPES[t], ptr(w), ptr(blk), w.size)
     assert np.array_equal(blk, blocks[f"wblk_{t}"])
+
+
+def test_q4_K_weight_quantizer_search_bit_exact(oracle, blocks):
+    """quantize_row_q4_K_ref incl. the make_qkx2_quants grid search (ggml-quants.c:799-878, :1457-1527) on 16 super-blocks
+    with per-block magnitudes over 3 decades, an all-zero super-block, an all-positive block (min clamps to 0), a constant
+    block and an outlier block — against the bytes the reference itself produced (tests/golden/make_golden.py)"""
+    x = blocks["q4k_x"]
+    blk = np.zeros_like(blocks["q4k_blk"])
+    oracle.oracle_quantize_row_ref(TYPES["q4_K"], ptr(x), ptr(blk), x.size)
+    assert np.array_equal(blk, blocks["q4k_blk"])
+    # and the round trip stays within the format's resolution per super-block: half a 4-bit step of the widest 32-block,
+    # plus the 6-bit rounding of the scale (x15 levels) and of the min, with 50 % slack for the fitted (not min/max) grids
+    y = np.zeros_like(x)
+    oracle.oracle_dequantize_row(TYPES["q4_K"], ptr(blk), ptr(y), x.size)
+    err = np.abs(x - y).reshape(-1, 256).max(axis=1)
+    xb = x.reshape(-1, 8, 32)
+    lo = np.minimum(xb.min(axis=2), 0)
+    span = (xb.max(axis=2) - lo).max(axis=1)
+    negmin = (-lo).max(axis=1)
+    bound = 1.5 * (span / 30 + span / 126 + negmin / 126) + 1e-6
+    assert np.all(err <= bound), float((err / bound).max())
 
 
 def test_activation_quantizers_bit_exact(oracle, blocks):

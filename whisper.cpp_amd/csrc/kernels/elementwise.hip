@@ -298,21 +298,12 @@ static int get_rows_impl(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x
 extern "C" int mi355x_get_rows(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx, const mi355x_tensor * d) {
     return get_rows_impl(ctx, s, idx, d, nullptr, nullptr);
 }
-struct DbgWideArgs { int * sink; };
-__global__ void __launch_bounds__(320) k_dbg_wide(DbgWideArgs a) { if (a.sink && threadIdx.x == 4096) *a.sink = 0; }
-static int get_rows_impl(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx, const mi355x_tensor * d,
-                         const mi355x_tensor * add, const mi355x_tensor * add_idx);
 extern "C" int mi355x_get_rows_add(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx,
                                    const mi355x_tensor * add, const mi355x_tensor * add_idx, const mi355x_tensor * d) {
     if (!add || !add_idx || add->type != MI355X_TYPE_F32 || add->nb[0] != 4 || add->ne[0] != s->ne[0] || add->ne[2] != 1 || add->ne[3] != 1 ||
         add_idx->type != MI355X_TYPE_I32 || add_idx->nb[0] != 4 || add_idx->ne[1] != 1 || add_idx->ne[2] != 1 || idx->ne[1] != 1 || idx->ne[2] != 1 ||
         add_idx->ne[0] != idx->ne[0] || ((uintptr_t) add->data % 16) || (add->nb[1] % 16)) return MI355X_E_UNSUPPORTED;
-    const int rc = get_rows_impl(ctx, s, idx, d, add, add_idx);
-    // debug probe (GGML_MI355X_DBG_WIDE_AFTER_EMBED=n): a do-nothing n-workgroup launch right behind the embedding gather,
-    // to see whether the step-start stall follows the first chip-wide dispatch or the first mat-vec
-    static const int wide = getenv("GGML_MI355X_DBG_WIDE_AFTER_EMBED") ? atoi(getenv("GGML_MI355X_DBG_WIDE_AFTER_EMBED")) : 0;
-    if (rc == 0 && wide > 0) { DbgWideArgs a = { nullptr }; return emit(ctx, "dbg_wide", k_dbg_wide, dim3(wide), dim3(320), 0, a, 0, 0); }
-    return rc;
+    return get_rows_impl(ctx, s, idx, d, add, add_idx);
 }
 static int get_rows_impl(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x_tensor * idx, const mi355x_tensor * d,
                          const mi355x_tensor * add, const mi355x_tensor * add_idx) {
