@@ -191,3 +191,20 @@ def test_committed_pmc_traffic_covers_the_benchmarked_kernels():
     for name in ("void k_qattn<6>", "void k_gemv_row<6, 1, 1, 2, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 1>", "void k_gemv8<6, 1, 8>",
                  "void k_gemm_f16_ring<64, 4>"):
         assert name in k and k[name]["hbm_bytes_per_launch"] > 0, name
+
+
+def test_no_kernel_spills_to_scratch():
+    """resource metadata of every gfx950 kernel in the built library (scripts/kernel_resources.py, no GPU needed):
+    none may use scratch memory — a register array indexed by a lane-dependent value (the Q4_K scale bytes once were) or a
+    spilled accumulator silently costs microseconds in a latency-bound decode kernel — and the hot decode kernels must keep
+    the register budget that lets a 512-thread workgroup co-reside with a second one on a CU."""
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "kernel_resources.py"), "--json"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ks = json.loads(r.stdout)
+    assert len(ks) > 300
+    spilled = [k["demangled"] for k in ks if k.get("private_segment_fixed_size", 0) > 0]
+    assert not spilled, spilled[:10]
+    by = {k["demangled"]: k for k in ks}
+    for name in ("k_gemv_row<6, 1, 1, 0, true, 1>", "k_gemv_row<6, 1, 1, 1, true, 1>", "k_gemv_row<6, 1, 1, 1, false, 1>", "k_gemv_row<6, 1, 1, 2, true, 1>", "k_qattn<6>"):
+        assert by[name]["vgpr_count"] <= 128, (name, by[name])
+    assert by["k_gemm_f16_ring<64, 4>"]["agpr_count"] == 32 and by["k_gemm_f16_ring<128, 2>"]["agpr_count"] == 64      # accumulators live in AGPRs
