@@ -53,7 +53,28 @@ def kernels(so: Path):
     return out
 
 
+def disassemble(so: Path, mangled: str) -> str:
+    """ISA of one kernel of the built library (llvm-objdump on the code object that defines it)"""
+    with tempfile.TemporaryDirectory() as d:
+        d = Path(d)
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(so), str(d / "fat.bin")], check=True)
+        data = (d / "fat.bin").read_bytes()
+        starts = [m.start() for m in re.finditer(re.escape(MAGIC), data)]
+        for n, (a, b) in enumerate(zip(starts, starts[1:] + [len(data)])):
+            (d / f"b{n}.bin").write_bytes(data[a:b])
+            subprocess.run([str(LLVM / "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            f"--input={d / f'b{n}.bin'}", f"--output={d / f'b{n}.co'}"], check=True, stderr=subprocess.DEVNULL)
+            syms = subprocess.run([str(LLVM / "llvm-readelf"), "-s", "-W", str(d / f"b{n}.co")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+            if re.search(rf"\s{re.escape(mangled)}$", syms, re.M):
+                return subprocess.run([str(LLVM / "llvm-objdump"), "-d", f"--disassemble-symbols={mangled}", str(d / f"b{n}.co")],
+                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout
+    return ""
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--disasm":
+        print(disassemble(ROOT / "whisper.cpp_amd" / "lib" / "libmi355x_kernels.so", sys.argv[2]))
+        sys.exit(0)
     ks = kernels(ROOT / "whisper.cpp_amd" / "lib" / "libmi355x_kernels.so")
     if "--json" in sys.argv:
         print(json.dumps(ks))

@@ -208,3 +208,61 @@ def test_no_kernel_spills_to_scratch():
     for name in ("k_gemv_row<6, 1, 1, 0, true, 1>", "k_gemv_row<6, 1, 1, 1, true, 1>", "k_gemv_row<6, 1, 1, 1, false, 1>", "k_gemv_row<6, 1, 1, 2, true, 1>", "k_qattn<6>"):
         assert by[name]["vgpr_count"] <= 128, (name, by[name])
     assert by["k_gemm_f16_ring<64, 4>"]["agpr_count"] == 32 and by["k_gemm_f16_ring<128, 2>"]["agpr_count"] == 64      # accumulators live in AGPRs
+
+
+def test_ring_gemm_loop_never_drains_the_dma_queue(tmp_path):
+    """ISA check of k_gemm_f16_ring (hipcc cross-compiles without a GPU): the basic blocks that issue MFMAs must not wait
+    `vmcnt(0)` — hipcc inserts exactly that in front of the first ds_read of a K-step as soon as a second __shared__ object
+    or an ordinary global load shares the loop with the LDS-DMA (cdna_hip_programming.md, glds pipeline traps), which turns
+    the 4-stage ring into a synchronous copy — and the counted waits of the pipeline must be there."""
+    src = ROOT / "whisper.cpp_amd" / "csrc" / "kernels" / "gemm_mfma.hip"
+    out = tmp_path / "gemm.s"
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", f"-I{ROOT / 'include'}",
+                        f"-I{src.parent}", str(src), "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    for fn, counted in (("_Z15k_gemm_f16_ringILi64ELi4EEv8GemmArgs", "vmcnt(12)"), ("_Z15k_gemm_f16_ringILi128ELi2EEv8GemmArgs", None)):
+        body = text[text.index(fn + ":"):]
+        body = body[:body.index("s_endpgm")]
+        assert body.count("global_load_lds_dwordx4") >= 12, fn
+        blocks, cur = [], []
+        for line in body.splitlines():
+            if line.startswith(".LBB"):
+                blocks.append(cur)
+                cur = []
+            cur.append(line)
+        blocks.append(cur)
+        mfma_blocks = [b for b in blocks if any("v_mfma_f32_32x32x16_f16" in ln for ln in b)]
+        assert mfma_blocks, fn
+        for b in mfma_blocks:
+            assert not any("vmcnt(0)" in ln for ln in b), (fn, "\n".join(b[:40]))
+        if counted:
+            assert counted in body and "s_barrier" in body, fn
+
+
+@pytest.mark.parametrize("mangled,min_loads", [("_Z10k_gemv_rowILi6ELi1ELi1ELi1ELb1ELi1EEv6DGArgs", 8),      # LN + mat-vec
+                                               ("_Z10k_gemv_rowILi6ELi1ELi1ELi2ELb1ELi1EEv6DGArgs", 27),     # attention combine + mat-vec
+                                               ("_Z10k_gemv_rowILi6ELi1ELi1ELi1ELb0ELi1EEv6DGArgs", 8)])     # LN + Q/K/V
+def test_decode_matvec_issues_all_loads_in_one_burst(mangled, min_loads):
+    """ISA of the built decode kernels: every global load of the kernel body is issued before the FIRST vmcnt wait, and that
+    wait is a counted one that leaves the weight stream in flight.  This is the property that took the projection inside
+    the real graph from 7.9 to 4.5 us (hipcc serializes predicated loads behind `s_waitcnt vmcnt(0)` and
+    sinks loads to their first use unless the order is pinned)."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import kernel_resources as kr
+    isa = kr.disassemble(ROOT / "whisper.cpp_amd" / "lib" / "libmi355x_kernels.so", mangled).splitlines()
+    ops = [(i, ln.split()[0], ln) for i, ln in enumerate(isa) if ln.startswith("\t") and ln.split()]
+    loads = [i for i, op, _ in ops if op.startswith("global_load")]
+    waits = [(i, ln) for i, op, ln in ops if op == "s_waitcnt" and "vmcnt(" in ln]
+    barriers = [i for i, op, _ in ops if op == "s_barrier"]
+    assert loads and waits and barriers, (len(loads), len(waits), len(barriers))
+    first_wait = waits[0][0]
+    burst = [i for i in loads if i < first_wait]
+    assert len(burst) >= min_loads, (len(burst), min_loads)
+    # nothing but the epilogue's GELU-table lookup may load after the burst
+    late = [isa[i] for i in loads if i > first_wait]
+    assert len(late) <= 1 and all("global_load_ushort" in ln for ln in late), late
+    import re
+    n_first = int(re.search(r"vmcnt\((\d+)\)", waits[0][1]).group(1))
+    assert n_first >= 3, waits[0][1]                      # the weight loads (issued last) stay in flight behind the first wait
+    assert not any("vmcnt(0)" in ln for i, ln in waits if i < barriers[0]), "a full drain before the first barrier"
