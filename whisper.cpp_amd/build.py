@@ -27,6 +27,8 @@ BACKEND_SRCS = ["ggml_mi355x.cpp"]
 
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
             "-Wall", "-Wno-unused-function", "-Wno-unused-variable", f"-I{ROOT / 'include'}", f"-I{CSRC / 'kernels'}"]
+if os.environ.get("MI355X_KTIME_BUILD") == "1":      # kernel-anatomy stamps (GGML_MI355X_KTIME=1 at run time, scripts/kbench.py)
+    HIPFLAGS.append("-DMI355X_KTIME")
 
 
 def _run(cmd):

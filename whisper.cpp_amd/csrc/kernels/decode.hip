@@ -41,7 +41,14 @@ struct DGArgs {
     const uint16_t * gelu_tab;
     unsigned long long * dbg;          // GGML_MI355X_KTIME=1: s_memtime stamps of workgroup 0 / wave 0 (kernel anatomy, scripts/kbench.py)
 };
+// Kernel-anatomy stamps are compiled in only with -DMI355X_KTIME (MI355X_KTIME_BUILD=1 python whisper.cpp_amd/build.py): even
+// with a null pointer each of the seven stamp sites costs a saveexec / branch / restore triple and a basic-block boundary in
+// kernels whose whole body is ~2 us.
+#ifdef MI355X_KTIME
 #define DG_STAMP(i) do { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DG_STAMP(i) do { } while (0)
+#endif
 
 // LPR = lanes per weight row (8/16/32/64 => 8/4/2/1 rows per wave pass).  Decode mat-vecs are latency-bound: what counts
 // is how many waves have loads in flight right after launch, so small matrices use more lanes (= more waves) per row and
@@ -741,8 +748,14 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         __syncthreads();
         #pragma unroll
         for (int t = 0; t < T; t++) {
+            // the (up to 8) wave partials: eight independent LDS reads and a value mask instead of a rolled loop of dependent
+            // read-add steps (nwaves is a launch parameter); same summation order, slots >= nwaves hold stale data
+            float pw[8];
+            #pragma unroll
+            for (int w = 0; w < 8; w++) pw[w] = red[t*8 + w];
             float rs = 0.0f;
-            for (int w = 0; w < nwaves; w++) rs += red[t*8 + w];
+            #pragma unroll
+            for (int w = 0; w < 8; w++) rs += w < nwaves ? pw[w] : 0.0f;
             mean[t] = rs / K;
             float p = 0.0f;
             #pragma unroll
@@ -758,8 +771,12 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         __syncthreads();
         #pragma unroll
         for (int t = 0; t < T; t++) {
+            float pw[8];
+            #pragma unroll
+            for (int w = 0; w < 8; w++) pw[w] = red[T*8 + t*8 + w];
             float rs = 0.0f;
-            for (int w = 0; w < nwaves; w++) rs += red[T*8 + t*8 + w];
+            #pragma unroll
+            for (int w = 0; w < 8; w++) rs += w < nwaves ? pw[w] : 0.0f;
             rstd[t] = 1.0f / sqrtf(rs / K + a.eps);
             #pragma unroll
             for (int i = 0; i < XS; i++) {
