@@ -96,19 +96,13 @@ def broadcast_weights(p, dist, torch, device: int, rank: int):
     bases, sizes = (C.c_void_p * cap)(), (C.c_size_t * cap)()
     p.ggml_backend_mi355x_weight_buffers.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
     n = p.ggml_backend_mi355x_weight_buffers(device, bases, sizes, cap)
-    total, t0 = 0, time.perf_counter()
+    t0 = time.perf_counter()
     try:
-        meta = torch.tensor([n] + [int(sizes[i]) for i in range(min(n, cap))] + [0] * (cap - min(n, cap)), dtype=torch.int64, device="cuda")
-        ref = meta.clone()
-        dist.broadcast(ref, src=0)
-        ok = torch.tensor([1 if torch.equal(ref, meta) and 0 < n <= cap else 0], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same branch: no rank is left waiting in a collective
-        if int(ok.item()) == 0:
+        from whisper_cpp_amd.dist_timing import broadcast_buffers
+        views = [torch.as_tensor(_DevMem(int(bases[i]), int(sizes[i])), device="cuda") for i in range(min(n, cap))]
+        total = broadcast_buffers(dist, torch, views, device="cuda", cap=cap, n=n)     # n > cap: every rank skips together
+        if total is None:
             raise RuntimeError("weight buffer layout differs between ranks")
-        for i in range(n):
-            t = torch.as_tensor(_DevMem(int(bases[i]), int(sizes[i])), device="cuda")
-            dist.broadcast(t, src=0)
-            total += int(sizes[i])
         torch.cuda.synchronize()
         return {"bytes": total, "buffers": n, "seconds": round(time.perf_counter() - t0, 4)}
     except Exception as e:  # noqa: BLE001  (every rank already holds the weights from the model file: safe to continue)

@@ -266,3 +266,46 @@ def test_decode_matvec_issues_all_loads_in_one_burst(mangled, min_loads):
     n_first = int(re.search(r"vmcnt\((\d+)\)", waits[0][1]).group(1))
     assert n_first >= 3, waits[0][1]                      # the weight loads (issued last) stay in flight behind the first wait
     assert not any("vmcnt(0)" in ln for i, ln in waits if i < barriers[0]), "a full drain before the first barrier"
+
+
+_BCAST_WORKER = """
+import os, sys
+sys.path.insert(0, {root!r})
+import torch
+import torch.distributed as dist
+import __graft_entry__ as g
+g.load_package()
+from whisper_cpp_amd.dist_timing import broadcast_buffers
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+gen = torch.Generator().manual_seed(100 + rank)
+# case 1: identical layout -> every rank ends up with rank 0's bytes
+bufs = [torch.randint(0, 256, (n,), dtype=torch.uint8, generator=gen) for n in (4096, 1000, 77)]
+g0 = torch.Generator().manual_seed(100)
+want = [torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g0) for n in (4096, 1000, 77)]
+total = broadcast_buffers(dist, torch, bufs)
+ok1 = total == 5173 and all(torch.equal(a, b) for a, b in zip(bufs, want))
+# case 2: rank 1 has a different layout -> BOTH ranks skip, nobody hangs, buffers untouched
+mine = [torch.full((64 + 8 * rank,), rank + 1, dtype=torch.uint8)]
+r2 = broadcast_buffers(dist, torch, mine)
+ok2 = r2 is None and bool((mine[0] == rank + 1).all())
+# case 3: more buffers than the cap on one rank -> skip together
+r3 = broadcast_buffers(dist, torch, [torch.zeros(8, dtype=torch.uint8)], cap=4, n=(9 if rank == 0 else 1))
+ok3 = r3 is None
+open(os.path.join({out!r}, "b%d.txt" % rank), "w").write("%d %d %d" % (ok1, ok2, ok3))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_weight_broadcast_logic(tmp_path):
+    """the one collective of the system (weights, once, at load — SURVEY.md 8e) on gloo with world size 2: data lands, and a
+    layout mismatch on ANY rank makes ALL ranks skip instead of deadlocking inside a broadcast"""
+    script = tmp_path / "b.py"
+    script.write_text(_BCAST_WORKER.format(root=str(ROOT), out=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    files = sorted(tmp_path.glob("b*.txt"))
+    assert len(files) == 2, r.stdout[-1500:]
+    for f in files:
+        assert f.read_text() == "1 1 1", (f.name, f.read_text(), r.stdout[-800:])
