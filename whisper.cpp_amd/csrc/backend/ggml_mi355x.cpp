@@ -664,7 +664,7 @@ static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const
 static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int & end_out, int & rc_out) {
     const ggml_tensor * fa = g->nodes[i];
     const ggml_tensor * q = fa->src[0], * k = fa->src[1], * v = fa->src[2], * m = fa->src[3];
-    const int64_t T = q->ne[1], H = q->ne[2];
+    const int64_t T = q->ne[1];
     if (T > 8 || q->ne[3] != 1 || fa->type != GGML_TYPE_F32 || !ggml_is_contiguous(fa)) return false;
     mi355x_tensor mq = to_mt(q), mk = to_mt(k), mv = to_mt(v), mm_;
     if (m) mm_ = to_mt(m);
@@ -934,7 +934,7 @@ static int mi_run_recorded(mi_backend_ctx * b, uint64_t key, const mi355x_launch
         gc->nodes.resize(n);
         if (hipGraphCreate(&gc->graph, 0) != hipSuccess) return -2;
         for (int i = 0; i < n; i++) {
-            hipKernelNodeParams p; memset(&p, 0, sizeof(p));
+            hipKernelNodeParams p = {};
             void * args[1] = { (void *) (gc->blob.data() + L[i].arg_offset) };
             p.func = (void *) L[i].func;
             p.gridDim = dim3(L[i].grid[0], L[i].grid[1], L[i].grid[2]);
@@ -956,7 +956,7 @@ static int mi_run_recorded(mi_backend_ctx * b, uint64_t key, const mi355x_launch
             if (same) continue;
             memcpy(gc->blob.data() + o.arg_offset, blob + L[i].arg_offset, L[i].arg_size);
             memcpy(gc->launches[i].grid, L[i].grid, sizeof(o.grid));
-            hipKernelNodeParams p; memset(&p, 0, sizeof(p));
+            hipKernelNodeParams p = {};
             void * args[1] = { (void *) (gc->blob.data() + o.arg_offset) };
             p.func = (void *) o.func;
             p.gridDim = dim3(L[i].grid[0], L[i].grid[1], L[i].grid[2]);
