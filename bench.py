@@ -113,7 +113,7 @@ def broadcast_weights(p, dist, torch, device: int, rank: int):
 
 def algorithmic_figures(arch: str, qtype: str):
     """algorithmic HBM bytes per decoded token and FLOPs per encode, from the hyper-parameters."""
-    from whisper_cpp_amd.synth_model import ARCHS
+    from whisper_cpp_amd.archs import ARCHS
     (n_vocab, n_actx, n_as, n_ah, n_al, n_tctx, n_ts, n_th, n_tl, n_mels) = ARCHS[arch]
     bpw = {"q4_0": 18 / 32, "q4_k": 144 / 256, "q5_0": 22 / 32, "q8_0": 34 / 32, "f16": 2.0}[qtype]
     n_ctx_pad = (n_actx + 255) // 256 * 256
@@ -167,7 +167,8 @@ def main():
 
     import __graft_entry__ as graft
     graft.load_package()
-    from whisper_cpp_amd.synth_model import make_model
+    sys.path.insert(0, str(ROOT / "scripts"))
+    from synth_model import make_model          # tooling: writes the synthetic model file with the reference application's own quantizer
 
     # rank 0 writes the synthetic model file once; every rank loads the same file (one replica per GPU).
     # Replicas are independent streams: no data-path collective.

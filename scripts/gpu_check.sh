@@ -33,7 +33,7 @@ model)
     stage "model parity"
     for spec in "micro q5_0" "tiny.en f16" "base.en q5_0" "base.en q4_k" "base.en q8_0" "base.en q4_0" "large-v3-2l q5_0"; do
         set -- $spec
-        m=$(python3 whisper.cpp_amd/synth_model.py --arch "$1" --qtype "$2") || continue
+        m=$(python3 scripts/synth_model.py --arch "$1" --qtype "$2") || continue
         for mode in "1 1" "0 0"; do
             set -- $mode
             echo "--- $spec fuse=$1 graphs=$2"
@@ -49,19 +49,19 @@ bench)
     stage "whisper-bench (reference binary + plugin)"
     for spec in "base.en q5_0" "large-v3 q5_0"; do
         set -- $spec
-        m=$(python3 whisper.cpp_amd/synth_model.py --arch "$1" --qtype "$2") || continue
+        m=$(python3 scripts/synth_model.py --arch "$1" --qtype "$2") || continue
         echo "--- GPU $spec"
         timeout 900 "$REF/whisper-bench" -m "$m" -t 8 > "$OUT/bench_gpu_$1_$2.log" 2>&1
         grep -E "encode time|decode time|batchd time|prompt time|backends|MI355X" "$OUT/bench_gpu_$1_$2.log" | head -12
     done
-    m=$(python3 whisper.cpp_amd/synth_model.py --arch base.en --qtype q5_0)
+    m=$(python3 scripts/synth_model.py --arch base.en --qtype q5_0)
     echo "--- CPU base.en q5_0 (-ng, $NCPU threads)"
     timeout 900 "$REF/whisper-bench" -m "$m" -ng -t "$NCPU" > "$OUT/bench_cpu_base.en_q5_0.log" 2>&1
     grep -E "encode time|decode time|batchd time|prompt time|system_info" "$OUT/bench_cpu_base.en_q5_0.log" | head -8
     ;;
 prof)
     stage "per-kernel profile (hipEvents inside the backend)"
-    m=$(python3 whisper.cpp_amd/synth_model.py --arch large-v3 --qtype q5_0)
+    m=$(python3 scripts/synth_model.py --arch large-v3 --qtype q5_0)
     GGML_MI355X_PROF=1 timeout 900 python3 bench.py --steps 1 --warmup 1 --profile-only > "$OUT/kernel_profile.json" 2> "$OUT/kernel_profile.err"
     tail -3 "$OUT/kernel_profile.err"; head -c 3000 "$OUT/kernel_profile.json"
     ;;

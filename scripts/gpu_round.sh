@@ -77,7 +77,7 @@ wbench)
     stage "reference whisper-bench binary + plugin"
     export GGML_BACKEND_PATH=$ROOT/whisper.cpp_amd/lib/libggml-mi355x.so
     export LD_LIBRARY_PATH=$ROOT/whisper.cpp_amd/host/_whisper:$ROOT/whisper.cpp_amd/lib:${LD_LIBRARY_PATH:-}
-    m=$(python3 whisper.cpp_amd/synth_model.py --arch "$ARCH" --qtype "$QT")
+    m=$(python3 scripts/synth_model.py --arch "$ARCH" --qtype "$QT")
     timeout 900 whisper.cpp_amd/host/_whisper/whisper-bench -m "$m" -t 8 > "$OUT/wbench_gpu_${ARCH}_${QT}.log" 2>&1
     grep -E "encode time|decode time|batchd time|prompt time|backends|MI355X" "$OUT/wbench_gpu_${ARCH}_${QT}.log" | head -12
     ;;

@@ -6,7 +6,7 @@ arch=$1; qt=$2; steps=$3; shift 3
 export GGML_MI355X_PLUGIN=$ROOT/whisper.cpp_amd/lib/libggml-mi355x.so GGML_BACKEND_PATH=$ROOT/whisper.cpp_amd/lib/libggml-mi355x.so
 export LD_LIBRARY_PATH=$ROOT/oracle/_ref:$ROOT/whisper.cpp_amd/lib:${LD_LIBRARY_PATH:-}
 export MODEL_PARITY_THREADS=${MODEL_PARITY_THREADS:-32}
-m=$(python3 whisper.cpp_amd/synth_model.py --arch "$arch" --qtype "$qt")
+m=$(python3 scripts/synth_model.py --arch "$arch" --qtype "$qt")
 for v in "$@"; do
     env $v tests/native/bin/model_parity "$m" "$steps" 2>/dev/null | python3 -c "
 import json,sys

@@ -19,7 +19,8 @@ import bench  # noqa: E402
 
 graft.load_package()
 from whisper_cpp_amd.streams import Streams  # noqa: E402
-from whisper_cpp_amd.synth_model import make_model  # noqa: E402
+sys.path.insert(0, str(ROOT / "scripts"))
+from synth_model import make_model  # noqa: E402
 
 arch, qtype, S, n_dec = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 model = make_model(arch, qtype)

@@ -1,4 +1,4 @@
-"""Synthetic whisper.cpp model files (legacy `ggml` bin format) with seeded random weights.
+"""TOOLING (not part of the shipped package): synthetic whisper.cpp model files (legacy `ggml` bin format) with seeded random weights.
 
 There are no real Whisper checkpoints in the build container or on the GPU box (no network), so every
 parity / benchmark run uses models of the real ARCHITECTURE with random-init weights, written in the
@@ -22,21 +22,15 @@ from pathlib import Path
 
 import numpy as np
 
+import sys
+
 ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as _graft  # noqa: E402
 
-ARCHS = {
-    # name: n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer, n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels
-    "tiny.en":        (51864, 1500, 384, 6, 4, 448, 384, 6, 4, 80),
-    "base.en":        (51864, 1500, 512, 8, 6, 448, 512, 8, 6, 80),
-    "small.en":       (51864, 1500, 768, 12, 12, 448, 768, 12, 12, 80),
-    "large-v3":       (51866, 1500, 1280, 20, 32, 448, 1280, 20, 32, 128),
-    "large-v3-turbo": (51866, 1500, 1280, 20, 32, 448, 1280, 20, 4, 128),
-    # reduced-depth variants for fast tests (same widths => same kernels / tiles)
-    "large-v3-2l":    (51866, 1500, 1280, 20, 2, 448, 1280, 20, 2, 128),
-    "micro":          (51864, 1500, 256, 4, 2, 448, 256, 4, 2, 80),
-}
+_graft.load_package()
+from whisper_cpp_amd.archs import ARCHS, QTYPES  # noqa: E402
 
-QTYPES = ("f16", "q4_0", "q5_0", "q8_0", "q4_k")
 
 
 def _w_tensor(f, name: str, arr: np.ndarray):
@@ -156,7 +150,8 @@ def make_model(arch: str, qtype: str, out_dir: Path | None = None, seed: int = 1
         return f16
     q = out_dir / f"synth-{arch}-{qtype}.bin"
     if not q.exists():
-        qb = Path(quantize_bin or ROOT / "oracle" / "_ref" / "whisper-quantize")
+        # the reference application's own quantizer, installed next to the unmodified libwhisper the plugin drops into
+        qb = Path(quantize_bin or ROOT / "whisper.cpp_amd" / "host" / "_whisper" / "whisper-quantize")
         tmp = q.with_suffix(".tmp")
         r = subprocess.run([str(qb), str(f16), str(tmp), qtype], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0 or not tmp.exists():

@@ -9,6 +9,7 @@ import pytest
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "scripts"))          # tooling used by the tests (synthetic model files)
 
 import __graft_entry__ as graft  # noqa: E402
 

@@ -580,7 +580,7 @@ def test_plugin_model_parity(plugin_env, arch, qtype):
     """same model file through the unmodified libwhisper on the reference CPU backend and on the plugin: logits within
     tolerance at every teacher-forced step; greedy tokens identical wherever the CPU's own top-2 margin exceeds the
     logit error (random-weight models have near-ties a real model does not)."""
-    from whisper_cpp_amd.synth_model import make_model
+    from synth_model import make_model
     m = make_model(arch, qtype)
     env = dict(plugin_env, GGML_MI355X_STRICT="1")
     steps = "16"
@@ -611,7 +611,7 @@ def test_plugin_model_parity(plugin_env, arch, qtype):
 def test_plugin_whisper_full_pipeline(plugin_env, arch, qtype):
     """whisper_full() end to end (mel front end, encoder, sampling loop — all unmodified reference code) on a synthetic
     11 s signal, greedy and 5-beam search (batched 5-token decode steps + KV-cache bookkeeping through the plugin)."""
-    from whisper_cpp_amd.synth_model import make_model
+    from synth_model import make_model
     m = make_model(arch, qtype)
     env = dict(plugin_env, GGML_MI355X_STRICT="1")
     r = subprocess.run([str(_native("full_parity")), str(m), "24"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)

@@ -74,7 +74,7 @@ def test_synthetic_model_loads_in_reference(tmp_path):
     exe = ROOT / "oracle" / "_ref" / "cpu_baseline"
     if not exe.exists():
         pytest.skip("oracle/_ref not built")
-    from whisper_cpp_amd.synth_model import make_model
+    from synth_model import make_model
     m = make_model("micro", "q5_0", out_dir=tmp_path)
     env = dict(os.environ, LD_LIBRARY_PATH=str(ROOT / "oracle" / "_ref"))
     r = subprocess.run([str(exe), str(m), "4", "2", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)

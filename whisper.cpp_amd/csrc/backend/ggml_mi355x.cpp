@@ -194,11 +194,21 @@ static void * mi_buffer_get_base(ggml_backend_buffer_t buffer) { return ((mi_buf
 
 // quantized tensors are stored planar (include/mi355x_kernels.h); whole-tensor transfers re-layout on the host,
 // partial ones go through read-modify-write of the whole tensor (never happens in whisper.cpp: W:1934-1938)
+// The planar layout is defined per WHOLE tensor (the planes of NB blocks follow each other): a row / sub-view of a quantized
+// tensor has no contiguous image in it, and a non-contiguous one cannot be re-laid out block by block.  whisper.cpp only ever
+// transfers whole weight tensors (W:1934-1938); anything else is a programmer error and must not silently corrupt weights.
+static bool whole_quant_tensor(const ggml_tensor * t) {
+    return ggml_is_contiguous(t) && (!t->view_src || (t->view_offs == 0 && ggml_nbytes(t) == ggml_nbytes(t->view_src)));
+}
+#define MI_REQUIRE_WHOLE_QUANT(t, what) do { if (is_quant_type((t)->type) && !whole_quant_tensor(t)) \
+    GGML_ABORT("ggml-mi355x: %s of a partial / non-contiguous view of quantized tensor '%s' (%s): quantized tensors are stored planar and move as whole tensors only", what, (t)->name, ggml_type_name((t)->type)); } while (0)
+
 static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     io_timer tm(0);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
-    if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
+    MI_REQUIRE_WHOLE_QUANT(tensor, "set_tensor");
+    if (is_quant_type(tensor->type)) {
         mi_shadows_drop(ctx->device, ctx->base);
         mi_io_drain(ctx->device);
         const size_t nbytes = ggml_nbytes(tensor);
@@ -227,7 +237,8 @@ static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
-    if (is_quant_type(tensor->type) && ggml_is_contiguous(tensor)) {
+    MI_REQUIRE_WHOLE_QUANT(tensor, "get_tensor");
+    if (is_quant_type(tensor->type)) {
         const size_t nbytes = ggml_nbytes(tensor);
         std::vector<uint8_t> planar(nbytes), blocks(nbytes);
         (void) hipMemcpy(planar.data(), tensor->data, nbytes, hipMemcpyDeviceToHost);
@@ -242,6 +253,9 @@ static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
 
 static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    MI_REQUIRE_WHOLE_QUANT(tensor, "memset_tensor");
+    if (is_quant_type(tensor->type) && !(offset == 0 && size == ggml_nbytes(tensor)))
+        GGML_ABORT("ggml-mi355x: partial memset of quantized tensor '%s': planar layout, whole tensors only", tensor->name);
     if (is_quant_type(tensor->type)) mi_shadows_drop(ctx->device, ctx->base);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
@@ -265,7 +279,12 @@ static bool mi_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
     if (!mi_buffer_is_ours(sbuf)) return false;
     io_timer tm(2);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    MI_REQUIRE_WHOLE_QUANT(src, "cpy_tensor (source)");
+    MI_REQUIRE_WHOLE_QUANT(dst, "cpy_tensor (destination)");
     if (is_quant_type(dst->type)) mi_shadows_drop(ctx->device, ctx->base);
+    // uploads still in flight for the SOURCE (it may live on another of our devices) must land before the raw copy reads it
+    const int sdev = ((mi_buffer_ctx *) sbuf->context)->device;
+    if (sdev != ctx->device) { (void) hipSetDevice(sdev); mi_io_drain(sdev); }
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     // same layout on both sides (ggml_are_same_layout is asserted by the caller) => raw bytes, planar included
@@ -335,6 +354,7 @@ struct mi_graph_cache {
     std::vector<mi355x_launch>  launches;
     std::vector<uint8_t>        blob;
     uint64_t                    hits = 0;
+    uint64_t                    last_call = 0;     // n_graph_compute of the most recent launch (never evicted within that call)
 };
 
 struct mi_backend_ctx {
@@ -914,17 +934,25 @@ static int mi_run_recorded(mi_backend_ctx * b, uint64_t key, const mi355x_launch
     }
     if (rebuild) {
         if (!gc) {
-            if (b->gcache.size() >= 48) {           // bounded cache: drop the least used entry
-                size_t worst = 0;
-                for (size_t i = 1; i < b->gcache.size(); i++) if (b->gcache[i].hits < b->gcache[worst].hits) worst = i;
-                if (b->gcache[worst].exec)  (void) hipGraphExecDestroy(b->gcache[worst].exec);
-                if (b->gcache[worst].graph) (void) hipGraphDestroy(b->gcache[worst].graph);
-                b->gcache.erase(b->gcache.begin() + worst);
+            if (b->gcache.size() >= 48) {           // bounded cache: drop the least used entry that was not launched by this graph_compute
+                size_t worst = b->gcache.size();
+                for (size_t i = 0; i < b->gcache.size(); i++) {
+                    if (b->gcache[i].last_call == b->n_graph_compute) continue;
+                    if (worst == b->gcache.size() || b->gcache[i].hits < b->gcache[worst].hits) worst = i;
+                }
+                if (worst < b->gcache.size()) {
+                    // graph launches are asynchronous: the entry may still be executing (or queued) on the compute stream
+                    (void) hipStreamSynchronize(stream);
+                    if (b->gcache[worst].exec)  (void) hipGraphExecDestroy(b->gcache[worst].exec);
+                    if (b->gcache[worst].graph) (void) hipGraphDestroy(b->gcache[worst].graph);
+                    b->gcache.erase(b->gcache.begin() + worst);
+                }
             }
             b->gcache.emplace_back();
             gc = &b->gcache.back();
             gc->key = key;
         } else {
+            (void) hipStreamSynchronize(stream);        // the previous instance of this entry may still be executing
             if (gc->exec)  (void) hipGraphExecDestroy(gc->exec);
             if (gc->graph) (void) hipGraphDestroy(gc->graph);
             gc->exec = nullptr; gc->graph = nullptr;
@@ -969,7 +997,7 @@ static int mi_run_recorded(mi_backend_ctx * b, uint64_t key, const mi355x_launch
         b->n_replay++;
         b->t_patch_ms += now_ms() - tp0;
     }
-    gc->hits++;
+    gc->hits++; gc->last_call = b->n_graph_compute;
     const double tl0 = now_ms();
     hipError_t e = hipGraphLaunch(gc->exec, stream);
     b->t_launch_ms += now_ms() - tl0;
@@ -1279,6 +1307,7 @@ void ggml_backend_mi355x_host_times(double * out) {
 
 int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {
     mi_shadows_drop(device, nullptr);          // the caller is about to overwrite the weights behind our back
+    if (hipSetDevice(device) == hipSuccess) { mi_io_drain(device); (void) hipDeviceSynchronize(); }     // small weights uploaded through the pinned ring have landed
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     int n = 0;
     for (auto & r : g_buffers) {

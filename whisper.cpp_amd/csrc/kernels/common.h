@@ -34,6 +34,7 @@ struct mi355x_ctx {
     void *      scratch      = nullptr;
     size_t      scratch_size = 0;
     size_t      scratch_used = 0;        // bump pointer, reset per op group
+    std::vector<void *> scratch_retired; // outgrown arenas that may still back pointers of the current op group
     // recording
     bool                        recording = false;
     bool                        record_invalid = false;

@@ -75,6 +75,7 @@ extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
     (void) hipStreamSynchronize(ctx->stream);
     for (auto & e : ctx->ev_pool) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     if (ctx->scratch)  (void) hipFree(ctx->scratch);
+    for (void * r : ctx->scratch_retired) (void) hipFree(r);
     if (ctx->gelu_tab) (void) hipFree(ctx->gelu_tab);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -149,7 +150,11 @@ void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes) {
         (void) hipStreamSynchronize(ctx->stream);
         void * nptr = nullptr;
         if (hipMalloc(&nptr, nsz) != hipSuccess) { mi355x_set_error("scratch alloc of %zu bytes failed", nsz); return nullptr; }
-        if (ctx->scratch) (void) hipFree(ctx->scratch);
+        // arenas retired by EARLIER growths are idle now (the stream was just drained); the current one may hold pointers handed
+        // out earlier in this op group (e.g. part_o before part_ml), so it stays alive until the next growth / context destroy
+        for (void * r : ctx->scratch_retired) (void) hipFree(r);
+        ctx->scratch_retired.clear();
+        if (ctx->scratch) { if (ctx->scratch_used > 0) ctx->scratch_retired.push_back(ctx->scratch); else (void) hipFree(ctx->scratch); }
         ctx->scratch = nptr; ctx->scratch_size = nsz; ctx->scratch_used = 0;
         if (ctx->recording) { mi355x_set_error("scratch grew while recording; plan invalid"); ctx->record_invalid = true; }
     }

@@ -2,16 +2,13 @@
 //     dst[:, h, t] = softmax_k( scale * <f16(q[:, t, h]), k[:, k, h]> + mask[k, t] ) . v[:, k, h]
 // q F32 (rounded to f16 like the CPU's q_to_vec_dot), k/v F16, mask F16 or none, f32 accumulation throughout.
 //
-// Two kernels:
 //   k_fattn_mfma : T > 8 (encoder 1500 x 1536, prompt).  128 queries x 1 head per workgroup, 4 waves x 32 queries,
 //                  64-key tiles staged once per workgroup in LDS (K row-major XOR-swizzled, V transposed with a
 //                  conflict-free 136-byte row pitch).  S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_f16, so a
 //                  lane owns ONE query column: softmax statistics are per-lane scalars (one shuffle with lane^32),
 //                  the P fragment feeds the second MFMA straight from registers (the k-index permutation inside the
 //                  MFMA is applied identically to V^T), and the O rescale is a per-lane scalar multiply.
-//   k_fattn_vec  : T <= 8 (decoder step).  HBM-bound on the F16 K/V read (cross-attention: 1536 x 64 x 2 x 2 B per
-//                  head and layer), so the key range is split over workgroups (32 keys per wave, 128 per workgroup)
-//                  to cover all CUs; partial (max, sum, O) records are merged by k_fattn_combine.
+//   T <= 8 (decoder step) goes to k_fattn_dec in decode.hip (128-key partial records, merged by the consumer).
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -22,7 +19,6 @@ struct FattnArgs {
     dtensor q, k, v, m, d;
     int has_mask; float scale;
     int T, n_kv, H, rk2, rv2;
-    float * part; int nparts;          // vec kernel: partial records [H][T][nparts][66]
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -180,113 +176,6 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// vector kernel (T <= 8): 32 keys per wave, partial softmax records
-// ---------------------------------------------------------------------------------------------------
-template <int T>
-__global__ void __launch_bounds__(256) k_fattn_vec(const FattnArgs a) {
-    __shared__ __attribute__((aligned(16))) float qs[T][FA_D];
-    __shared__ float pl[4][T][32];
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2;
-    const int pidx = blockIdx.x*4 + wave;                      // partial index == 32-key chunk index
-    const int kbeg = pidx*32;
-
-    for (int i = tid; i < T*FA_D; i += 256) {
-        const int t = i / FA_D, d = i % FA_D;
-        qs[t][d] = round_f16(*(const float *) (a.q.data + (int64_t) t*a.q.nb[1] + (int64_t) hq*a.q.nb[2] + d*4));
-    }
-    __syncthreads();
-    if (kbeg >= a.n_kv) {                                      // wave-uniform: padded chunk -> neutral record
-        for (int t = 0; t < T; t++) {
-            float * rec = a.part + (((int64_t) hq*T + t)*a.nparts + pidx)*66;
-            rec[2 + lane] = 0.0f;
-            if (lane == 0) { rec[0] = -1e30f; rec[1] = 0.0f; }
-        }
-        return;
-    }
-
-    const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2];
-    const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2];
-    const int dch = lane & 3;
-
-    float sc[2][T];
-    #pragma unroll
-    for (int ps = 0; ps < 2; ps++) {
-        const int key = kbeg + ps*16 + (lane >> 2);
-        const bool ok = key < a.n_kv;
-        float kf[16];
-        {
-            uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0;
-            if (ok) { const char * kp = kbase + (int64_t) key*a.k.nb[1] + dch*32; k0 = *(const uint4 *) kp; k1 = *(const uint4 *) (kp + 16); }
-            const uint32_t w[8] = { k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w };
-            #pragma unroll
-            for (int i = 0; i < 8; i++) { kf[2*i] = h2f((uint16_t) (w[i] & 0xFFFF)); kf[2*i+1] = h2f((uint16_t) (w[i] >> 16)); }
-        }
-        #pragma unroll
-        for (int t = 0; t < T; t++) {
-            float acc = 0.0f;
-            #pragma unroll
-            for (int i = 0; i < 16; i++) acc = fmaf(kf[i], qs[t][dch*16 + i], acc);
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            float x = acc * a.scale;
-            if (a.has_mask && ok) x += h2f(*(const uint16_t *) (a.m.data + (int64_t) t*a.m.nb[1] + key*2));
-            sc[ps][t] = ok ? x : -INFINITY;
-        }
-    }
-    float mt[T], lt[T];
-    #pragma unroll
-    for (int t = 0; t < T; t++) {
-        float m = fmaxf(sc[0][t], sc[1][t]);
-        #pragma unroll
-        for (int o = 4; o < 64; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        m = fmaxf(m, -1e30f);
-        const float p0 = __expf(sc[0][t] - m), p1 = __expf(sc[1][t] - m);
-        float l = dch == 0 ? p0 + p1 : 0.0f;
-        l = wave_sum(l);
-        mt[t] = m; lt[t] = l;
-        if (dch == 0) { pl[wave][t][lane >> 2] = p0; pl[wave][t][16 + (lane >> 2)] = p1; }
-    }
-    // pl is written and read by the same wave only; LDS ops of one wave complete in order
-    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-
-    float o[T];
-    #pragma unroll
-    for (int t = 0; t < T; t++) o[t] = 0.0f;
-    const int nk = a.n_kv - kbeg < 32 ? a.n_kv - kbeg : 32;
-    #pragma unroll 8
-    for (int kk = 0; kk < nk; kk++) {
-        const float v = h2f(*(const uint16_t *) (vbase + (int64_t) (kbeg + kk)*a.v.nb[1] + lane*2));
-        #pragma unroll
-        for (int t = 0; t < T; t++) o[t] = fmaf(pl[wave][t][kk], v, o[t]);
-    }
-    #pragma unroll
-    for (int t = 0; t < T; t++) {
-        float * rec = a.part + (((int64_t) hq*T + t)*a.nparts + pidx)*66;
-        rec[2 + lane] = o[t];
-        if (lane == 0) { rec[0] = mt[t]; rec[1] = lt[t]; }
-    }
-}
-
-struct CombineArgs { const float * part; int nparts, T, H; dtensor d; };
-__global__ void __launch_bounds__(64) k_fattn_combine(const CombineArgs a) {
-    const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-    const float * rec = a.part + (((int64_t) h*a.T + t)*a.nparts)*66;
-    float M = -1e30f;
-    for (int i = 0; i < a.nparts; i++) M = fmaxf(M, rec[i*66]);
-    float L = 0.0f, O = 0.0f;
-    for (int i = 0; i < a.nparts; i++) {
-        const float w = __expf(rec[i*66] - M);
-        L = fmaf(w, rec[i*66 + 1], L);
-        O = fmaf(w, rec[i*66 + 2 + lane], O);
-    }
-    float * dp = (float *) (a.d.data + (int64_t) h*a.d.nb[1] + (int64_t) t*a.d.nb[2]);
-    dp[lane] = L == 0.0f ? 0.0f : O / L;
-}
-
 extern "C" int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                                      const mi355x_tensor * mask, const mi355x_tensor * dst, float scale) {
     if (q->type != MI355X_TYPE_F32 || k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16 || dst->type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
@@ -311,34 +200,11 @@ extern "C" int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, 
     const double flops = 4.0 * T * (double) n_kv * FA_D * H;
     if (n_kv == 0) return mi355x_memset(ctx, dst->data, 0, (size_t) dst->nb[3]*dst->ne[3]);
 
-    static const bool dec_v2 = !(getenv("GGML_MI355X_FATTN_V1") && atoi(getenv("GGML_MI355X_FATTN_V1")));
-    if (T <= 8 && dec_v2) {
+    if (T <= 8) {               // decoder step: partial records per 128-key chunk (decode.hip), merged here when no projection consumes them
         mi355x_attn_partials parts;
         const int rc = mi355x_flash_attn_partial(ctx, q, k, v, mask, scale, &parts);
         if (rc == 0) return mi355x_flash_attn_combine(ctx, &parts, dst);
         if (rc != MI355X_E_UNSUPPORTED) return rc;
-    }
-    if (T <= 8) {
-        const int nparts = (n_kv + 31) / 32, nblk = (nparts + 3) / 4;
-        mi355x_scratch_reset(ctx);
-        a.nparts = nblk*4;
-        a.part = (float *) mi355x_scratch_alloc(ctx, (size_t) H*T*a.nparts*66*4);
-        if (!a.part) return (int) hipErrorOutOfMemory;
-        const dim3 grid(nblk, H), block(256);
-        int rc;
-        const double bytes = kv_bytes + (double) T*H*FA_D*8;
-        switch (T) {
-            case 1: rc = emit(ctx, "fattn_vec", k_fattn_vec<1>, grid, block, 0, a, bytes, flops); break;
-            case 2: rc = emit(ctx, "fattn_vec", k_fattn_vec<2>, grid, block, 0, a, bytes, flops); break;
-            case 3: rc = emit(ctx, "fattn_vec", k_fattn_vec<3>, grid, block, 0, a, bytes, flops); break;
-            case 4: rc = emit(ctx, "fattn_vec", k_fattn_vec<4>, grid, block, 0, a, bytes, flops); break;
-            case 5: rc = emit(ctx, "fattn_vec", k_fattn_vec<5>, grid, block, 0, a, bytes, flops); break;
-            case 6: rc = emit(ctx, "fattn_vec", k_fattn_vec<6>, grid, block, 0, a, bytes, flops); break;
-            case 7: rc = emit(ctx, "fattn_vec", k_fattn_vec<7>, grid, block, 0, a, bytes, flops); break;
-            default: rc = emit(ctx, "fattn_vec", k_fattn_vec<8>, grid, block, 0, a, bytes, flops); break;
-        }
-        if (rc) return rc;
-        return emit(ctx, "fattn_combine", k_fattn_combine, dim3(T, H), dim3(64), 0, CombineArgs{ a.part, a.nparts, T, H, a.d }, 0, 0);
     }
     const double bytes = kv_bytes * ((T + 127) / 128) + (double) T*H*FA_D*8;
     return emit(ctx, "fattn_mfma", k_fattn_mfma, dim3((T + 127) / 128, H), dim3(256), 0, a, bytes, flops);

@@ -65,6 +65,12 @@ __global__ void __launch_bounds__(256) k_prep_act(const PrepArgs a) {
             for (int i = 0; i < 4; i++) r[i] = d * fminf(127.0f, rintf(iscale * v[i]));
         }
     }
+    if (a.mode != 0) {
+        // d*q is stored as f16: the reference keeps d and q apart and stays finite up to ~8e6 where f16 overflows at 65504.
+        // Saturate instead of producing inf (mode 0 keeps the reference's own f16 conversion of the activation, inf included).
+        #pragma unroll
+        for (int i = 0; i < 4; i++) r[i] = fminf(fmaxf(r[i], -65504.0f), 65504.0f);
+    }
     *(uint2 *) (a.y + t*a.K + e) = make_uint2(f2h(r[0]) | ((uint32_t) f2h(r[1]) << 16), f2h(r[2]) | ((uint32_t) f2h(r[3]) << 16));
 }
 

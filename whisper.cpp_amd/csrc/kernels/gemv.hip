@@ -357,8 +357,8 @@ static int launch_gemv_T(mi355x_ctx * ctx, const GemvArgs & k, int T, dim3 grid,
 
 extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
-    static const bool use_v2 = !(getenv("GGML_MI355X_GEMV_V1") && atoi(getenv("GGML_MI355X_GEMV_V1")));
-    if (use_v2) {
+    {   // the lean decode kernels (decode.hip) take every quantized shape of the whisper graphs; what is left for k_gemv below:
+        // F16 weights (f16 models), LDS-heavy shapes (K*T too large for the 64 KB planes)
         const int rc = mi355x_gemv8(ctx, d);
         if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
