@@ -495,3 +495,167 @@ void oracle_flash_attn(const float * q, const uint16_t * k, const uint16_t * v, 
     }
     free(qh); free(acc);
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ggml_flash_attn_ext as the AVX2 + FMA + F16C CPU build DISPATCHES it (ggml-cpu/ops.cpp:9077-9230).  The arithmetic
+ * depends on the shape, three paths:
+ *   T == 1 and n_kv >= 512 : split-KV — the key range is cut into nth chunks (one per thread), each runs the vec path
+ *                            below over its keys, the f32 partials (M, S, VKQ) are merged by
+ *                            ggml_flash_attn_ext_reduce_partials (ops.cpp:8992-9075).  RESULT DEPENDS ON nth.
+ *   T >= 64                : tiled path (ops.cpp:8717-8990): q stays F32, K/V tiles converted to F32, scores and P.V by
+ *                            simd_gemm (sequential fma over the inner index, simd-gemm.h:24-58), softmax of a 64-key tile
+ *                            with ggml_v_expf (vec.h:1215-1252) and the 8-lane sum order of ggml_vec_soft_max_f32
+ *                            (vec.cpp:541-551); F32 accumulation.
+ *   otherwise              : vec path `one_chunk` (ops.cpp:8479-8715): q -> F16, score by ggml_vec_dot_f16 (vec.cpp:264,
+ *                            GGML_F16_STEP 32 / EPR 8, reduction simd-mappings.h:602-620), sequential online softmax with
+ *                            libm expf, V accumulated in F16 (ggml_vec_mad_f16 / ggml_vec_scale_f16: f32 fma, store as f16).
+ * Restated lane by lane in the SIMD order so that the result is bit-identical to the reference build in oracle/_ref
+ * (pinned by tests/golden/ops.npz: golden_flash_attn, golden_fattn_split, golden_fattn_tiled).
+ * ------------------------------------------------------------------------------------------------------------------ */
+static float fa_bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t fa_f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* one lane of ggml_v_expf (AVX2 variant), vec.h:1215-1252 */
+float oracle_v_expf(float x) {
+    const float r = 0x1.8p23f;
+    const float z = fmaf(x, 0x1.715476p+0f, r);
+    const float n = z - r;
+    const float b = fmaf(-n, 0x1.7f7d1cp-20f, fmaf(-n, 0x1.62e4p-1f, x));
+    const uint32_t e = fa_f_bits(z) << 23;
+    const float k = fa_bits_f(e + fa_f_bits(1.0f));
+    const int c = fabsf(n) > 126.0f;
+    const float u = b * b;
+    const float j = fmaf(fmaf(fmaf(0x1.0e4020p-7f, b, 0x1.573e2ep-5f), u, fmaf(0x1.555e66p-3f, b, 0x1.fffdb6p-2f)), u, 0x1.ffffecp-1f * b);
+    if (!c) return fmaf(j, k, k);
+    const uint32_t g = (n <= 0.0f) ? 0x82000000u : 0u;
+    const float s1 = fa_bits_f(g + 0x7f000000u);
+    const float s2 = fa_bits_f(e - g);
+    if (fabsf(n) > 192.0f) return s1 * s1;
+    return fmaf(s2, j, s2) * s1;
+}
+
+/* ggml_vec_dot_f16 for n % 32 == 0: four 8-lane f32 accumulators, fma per 32-element step, then x0+=x2, x1+=x3, x0+=x1,
+ * low half + high half, two horizontal adds */
+static float fa_dot_f16(const uint16_t * x, const uint16_t * y, int64_t n) {
+    float s[4][8];
+    for (int j = 0; j < 4; j++) for (int l = 0; l < 8; l++) s[j][l] = 0.0f;
+    for (int64_t i = 0; i < n; i += 32)
+        for (int j = 0; j < 4; j++) for (int l = 0; l < 8; l++)
+            s[j][l] = fmaf(oracle_f16_to_f32(x[i + j*8 + l]), oracle_f16_to_f32(y[i + j*8 + l]), s[j][l]);
+    float v[8], t0[4];
+    for (int l = 0; l < 8; l++) { const float a = s[0][l] + s[2][l], b = s[1][l] + s[3][l]; v[l] = a + b; }
+    for (int i = 0; i < 4; i++) t0[i] = v[i] + v[i + 4];
+    return (t0[0] + t0[1]) + (t0[2] + t0[3]);
+}
+
+/* vec path over keys [ic0, ic1) of one (query, head): leaves M, S and the F32 image of the F16 accumulator */
+static void fa_one_chunk(const uint16_t * qh, const uint16_t * k, const uint16_t * v, const uint16_t * mrow, int64_t D, int64_t H, int64_t h,
+                         int64_t ic0, int64_t ic1, float scale, float * M_out, float * S_out, float * vkq32) {
+    uint16_t acc[256];
+    for (int64_t d = 0; d < D; d++) acc[d] = 0;
+    float S = 0.0f, M = -INFINITY;
+    for (int64_t ic = ic0; ic < ic1; ic++) {
+        const float mv = mrow ? oracle_f16_to_f32(mrow[ic]) : 0.0f;
+        if (mv == -INFINITY) continue;
+        const uint16_t * kp = k + (ic*H + h)*D, * vp = v + (ic*H + h)*D;
+        float s = fa_dot_f16(kp, qh, D);
+        s = s*scale;
+        s += mv;
+        const float Mold = M;
+        float ms = 1.0f, vs = 1.0f;
+        if (s > M) {
+            M = s; ms = expf(Mold - M);
+            for (int64_t d = 0; d < D; d++) acc[d] = oracle_f32_to_f16(oracle_f16_to_f32(acc[d]) * ms);          /* ggml_vec_scale_f16 */
+        } else vs = expf(s - M);
+        for (int64_t d = 0; d < D; d++) acc[d] = oracle_f32_to_f16(fmaf(oracle_f16_to_f32(vp[d]), vs, oracle_f16_to_f32(acc[d])));   /* ggml_vec_mad_f16 */
+        S = S*ms; S = S + vs;                      /* two roundings: gcc specialises the statement per branch (ms == 1 or vs == 1), no fma in the reference build */
+    }
+    for (int64_t d = 0; d < D; d++) vkq32[d] = oracle_f16_to_f32(acc[d]);
+    *M_out = M; *S_out = S;
+}
+
+/* tiled path for ONE query row (rows of a tile are independent): 64-key tiles */
+static void fa_tiled_row(const float * q, const uint16_t * k, const uint16_t * v, const uint16_t * mrow, int64_t D, int64_t H, int64_t h,
+                         int64_t n_kv, float scale, float * out) {
+    float vkq[256], kq[64], vstale[64][256];
+    for (int64_t d = 0; d < D; d++) vkq[d] = 0.0f;
+    memset(vstale, 0, sizeof(vstale));
+    float S = 0.0f, M = -INFINITY;
+    for (int64_t ic = 0; ic < n_kv; ic += 64) {
+        const int kvt = (int) (n_kv - ic < 64 ? n_kv - ic : 64);
+        if (mrow) {
+            int can_skip = 1;
+            for (int tk = 0; tk < kvt; tk++) if (oracle_f16_to_f32(mrow[ic + tk]) != -INFINITY) can_skip = 0;
+            /* (the reference skips a tile only when EVERY row of the 64-query tile is masked; for one row the arithmetic below
+             * gives the same result: tile_max == -inf => no contribution) */
+            (void) can_skip;
+        }
+        for (int tk = 0; tk < 64; tk++) {
+            if (tk >= kvt) { kq[tk] = -INFINITY; continue; }
+            const uint16_t * kp = k + ((ic + tk)*H + h)*D;
+            float a = 0.0f;
+            for (int64_t d = 0; d < D; d++) a = fmaf(oracle_f16_to_f32(kp[d]), q[d], a);                 /* simd_gemm: sequential fma over dk */
+            a = a * scale;
+            if (mrow) a = a + oracle_f16_to_f32(mrow[ic + tk]);
+            kq[tk] = a;
+        }
+        for (int tk = 0; tk < kvt; tk++) { const uint16_t * vp = v + ((ic + tk)*H + h)*D; for (int64_t d = 0; d < D; d++) vstale[tk][d] = oracle_f16_to_f32(vp[d]); }
+        float tmax = -INFINITY;
+        for (int tk = 0; tk < 64; tk++) if (kq[tk] > tmax) tmax = kq[tk];
+        if (tmax == -INFINITY) continue;
+        const float Mold = M, Mnew = fmaxf(Mold, tmax);
+        if (Mnew > Mold) { const float ms = expf(Mold - Mnew); for (int64_t d = 0; d < D; d++) vkq[d] *= ms; S *= ms; }
+        M = Mnew;
+        double sum = 0.0;
+        for (int g = 0; g < 8; g++) {                                  /* ggml_vec_soft_max_f32: 8 lanes at a time */
+            float p[8];
+            for (int l = 0; l < 8; l++) { p[l] = oracle_v_expf(kq[g*8 + l] - Mnew); kq[g*8 + l] = p[l]; }
+            const float a0 = p[0] + p[4], a1 = p[1] + p[5], a2 = p[2] + p[6], a3 = p[3] + p[7];
+            sum += (double) ((a0 + a2) + (a1 + a3));
+        }
+        S = (float) ((double) S + sum);
+        for (int tk = 0; tk < 64; tk++) for (int64_t d = 0; d < D; d++) vkq[d] = fmaf(vstale[tk][d], kq[tk], vkq[d]);    /* simd_gemm: sequential fma over keys */
+    }
+    const float inv = S == 0.0f ? 0.0f : 1.0f / S;
+    for (int64_t d = 0; d < D; d++) out[d] = vkq[d] * inv;
+}
+
+void oracle_flash_attn_ext(const float * q, const uint16_t * k, const uint16_t * v, const uint16_t * mask, float * dst,
+                           int64_t D, int64_t T, int64_t H, int64_t n_kv, float scale, int nth) {
+    if (D > 256 || D % 32) return;
+    uint16_t qh[256];
+    float part[256];
+    if (nth < 1) nth = 1;
+    for (int64_t t = 0; t < T; t++) for (int64_t h = 0; h < H; h++) {
+        const float * qp = q + (t*H + h)*D;
+        float * out = dst + (t*H + h)*D;
+        const uint16_t * mrow = mask ? mask + t*n_kv : NULL;
+        if (T >= 64) { fa_tiled_row(qp, k, v, mrow, D, H, h, n_kv, scale, out); continue; }
+        for (int64_t d = 0; d < D; d++) qh[d] = oracle_f32_to_f16(qp[d]);
+        if (T == 1 && n_kv >= 512) {
+            const int64_t chunk = (n_kv + nth - 1) / nth;
+            float Mf = -INFINITY, Sf = 0.0f, fin[256];
+            for (int64_t d = 0; d < D; d++) fin[d] = 0.0f;
+            for (int c = 0; c < nth; c++) {
+                const int64_t ic0 = (int64_t) c * chunk, ic1 = ic0 + chunk < n_kv ? ic0 + chunk : n_kv;
+                if (ic0 >= n_kv) continue;
+                float Mc, Sc;
+                fa_one_chunk(qh, k, v, mrow, D, H, h, ic0, ic1, scale, &Mc, &Sc, part);
+                if (Sc == 0.0f) continue;
+                const float Mn = fmaxf(Mf, Mc);
+                const float so = expf(Mf - Mn), sn = expf(Mc - Mn);
+                /* a*b + c*d of the reference build (gcc -O3, -ffp-contract=fast): the second product is rounded, the first fused */
+                for (int64_t d = 0; d < D; d++) fin[d] = fmaf(fin[d], so, part[d] * sn);
+                Sf = fmaf(Sf, so, Sc * sn);
+                Mf = Mn;
+            }
+            if (Sf != 0.0f) { const float inv = 1.0f / Sf; for (int64_t d = 0; d < D; d++) fin[d] *= inv; }
+            for (int64_t d = 0; d < D; d++) out[d] = fin[d];
+        } else {
+            float M, S;
+            fa_one_chunk(qh, k, v, mrow, D, H, h, 0, n_kv, scale, &M, &S, part);
+            const float inv = S == 0.0f ? 0.0f : 1.0f / S;
+            for (int64_t d = 0; d < D; d++) out[d] = part[d] * inv;
+        }
+    }
+}

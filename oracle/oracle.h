@@ -63,6 +63,13 @@ void oracle_rope(const float * x, const int32_t * pos, float * y, int64_t ne0, i
 void oracle_flash_attn(const float * q, const uint16_t * k, const uint16_t * v, const uint16_t * mask, float * dst,
                        int64_t D, int64_t T, int64_t H, int64_t n_kv, float scale);
 
+/* flash_attn_ext exactly as the AVX2 CPU build dispatches it (ggml-cpu/ops.cpp:9077-9230): split-KV over `nth` threads for
+ * T == 1 && n_kv >= 512, the F32 tiled path for T >= 64, the F16-accumulating vec path otherwise.  Same layouts as above.
+ * Bit-identical to oracle/_ref (tests/test_oracle.py).  oracle_v_expf: one lane of ggml_v_expf (vec.h:1215-1252). */
+void  oracle_flash_attn_ext(const float * q, const uint16_t * k, const uint16_t * v, const uint16_t * mask, float * dst,
+                            int64_t D, int64_t T, int64_t H, int64_t n_kv, float scale, int nth);
+float oracle_v_expf(float x);
+
 #ifdef __cplusplus
 }
 #endif

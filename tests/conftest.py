@@ -60,6 +60,9 @@ def oracle():
     L.oracle_im2col_1d_f16.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, i32]
     L.oracle_rope.argtypes = [vp, vp, vp, i64, i64, i64, i32, i32, i32, f32, f32, f32, f32, f32, f32]
     L.oracle_flash_attn.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32]
+    L.oracle_flash_attn_ext.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32]
+    L.oracle_v_expf.argtypes = [f32]
+    L.oracle_v_expf.restype = f32
     return L
 
 

@@ -239,6 +239,27 @@ int main(int argc, char ** argv) {
             ggml_tensor * o = ggml_flash_attn_ext(b.ctx, ggml_permute(b.ctx, q, 0, 2, 1, 3), ggml_permute(b.ctx, k, 0, 2, 1, 3), ggml_permute(b.ctx, v, 0, 2, 1, 3),
                                                   ggml_cast(b.ctx, mf, GGML_TYPE_F16), 0.125f, 0.0f, 0.0f);
             return std::vector<ggml_tensor *>{ o }; }, false, false);
+        // the three arithmetic paths of the CPU dispatcher (ggml-cpu/ops.cpp:9077-9230; the CPU backend runs 8 threads here):
+        // split-KV (T == 1, n_kv >= 512), vec with a long F16 accumulation chain (T = 5), tiled F32 (T >= 64)
+        struct fa_case { const char * name; int T, H, n_kv, mask_from; };      // mask_from < 0: no mask; else key > mask_from + 3*t is -inf
+        const fa_case fa_cases[] = { { "golden_fattn_split", 1, 3, 1536, -1 }, { "golden_fattn_split_masked", 1, 2, 600, 520 },
+                                     { "golden_fattn_vec5", 5, 2, 1536, -1 }, { "golden_fattn_tiled", 70, 2, 200, 90 }, { "golden_fattn_tiled_nomask", 64, 2, 136, -1 } };
+        for (const fa_case & fc : fa_cases) {
+            run_case(fc.name, [=](builder & b) {
+                const int D = 64;
+                ggml_tensor * q = b.randn(GGML_TYPE_F32, {D, fc.H, fc.T}, 0.7f);
+                ggml_tensor * k = b.randn(GGML_TYPE_F16, {D, fc.H, fc.n_kv}, 0.7f);
+                ggml_tensor * v = b.randn(GGML_TYPE_F16, {D, fc.H, fc.n_kv}, 1.0f);
+                ggml_tensor * m = nullptr;
+                if (fc.mask_from >= 0) {
+                    const int n_kv = fc.n_kv, mf0 = fc.mask_from;
+                    ggml_tensor * mf = b.leaf(GGML_TYPE_F32, {n_kv, fc.T}, [=](int64_t i) { return (i % n_kv) > mf0 + (i / n_kv) * 3 ? -INFINITY : 0.0f; });
+                    m = ggml_cast(b.ctx, mf, GGML_TYPE_F16);
+                }
+                ggml_tensor * o = ggml_flash_attn_ext(b.ctx, ggml_permute(b.ctx, q, 0, 2, 1, 3), ggml_permute(b.ctx, k, 0, 2, 1, 3), ggml_permute(b.ctx, v, 0, 2, 1, 3),
+                                                      m, 0.125f, 0.0f, 0.0f);
+                return std::vector<ggml_tensor *>{ o }; }, false, false);
+        }
         if (getenv("OP_PARITY_DUMP")) { ggml_backend_free(g_gpu); ggml_backend_free(g_cpu); return 0; }
     }
 

@@ -191,3 +191,43 @@ def test_flash_attn(oracle, ops):
     oracle.oracle_flash_attn(ptr(q), ptr(k), ptr(v), ptr(mh), ptr(out), D, T, H, n_kv, 0.125)
     # same algorithm incl. f16 V accumulation; the reference's f16 dot / mad run in 8-lane SIMD order
     assert nmse(z[f"{case}.out0"], out) < 1e-5
+
+
+FA_CASES = {   # case: (T, H, n_kv, has_mask) — the three arithmetic paths of the CPU dispatcher (ggml-cpu/ops.cpp:9077-9230), 8 threads
+    "golden_flash_attn": (3, 2, 40, True), "golden_fattn_split": (1, 3, 1536, False), "golden_fattn_split_masked": (1, 2, 600, True),
+    "golden_fattn_vec5": (5, 2, 1536, False), "golden_fattn_tiled": (70, 2, 200, True), "golden_fattn_tiled_nomask": (64, 2, 136, False),
+}
+
+
+@pytest.mark.parametrize("case", list(FA_CASES))
+def test_flash_attn_dispatcher_is_bit_exact(oracle, ops, case):
+    """oracle_flash_attn_ext restates the reference's flash_attn_ext PER PATH (split-KV over the thread count for T == 1 and
+    n_kv >= 512, the F32 tiled path for T >= 64, the F16-accumulating vec path otherwise) in the AVX2 lane order:
+    every output word equals the reference's (vectors generated from oracle/_ref by tests/golden/make_golden.py)"""
+    z, man = ops
+    T, H, n_kv, has_mask = FA_CASES[case]
+    D = 64
+    q = _leaf(z, man, case, 0, np.float32)
+    k = _leaf(z, man, case, 1, np.uint16)
+    v = _leaf(z, man, case, 2, np.uint16)
+    mh = _leaf(z, man, case, 3, np.float32).astype(np.float16).view(np.uint16).copy() if has_mask else None
+    out = np.zeros(T * H * D, dtype=np.float32)
+    oracle.oracle_flash_attn_ext(ptr(q), ptr(k), ptr(v), ptr(mh) if has_mask else None, ptr(out), D, T, H, n_kv, 0.125, 8)
+    ref = z[f"{case}.out0"]
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    if case == "golden_fattn_split":
+        # the split-KV result depends on the thread count (chunk = ceil(n_kv / nth)): 4 threads give different words
+        out4 = np.zeros_like(out)
+        oracle.oracle_flash_attn_ext(ptr(q), ptr(k), ptr(v), None, ptr(out4), D, T, H, n_kv, 0.125, 4)
+        assert not np.array_equal(out4.view(np.uint32), ref.view(np.uint32)) and nmse(ref, out4) < 1e-4
+
+
+def test_v_expf_lane(oracle):
+    """one lane of ggml_v_expf (vec.h:1215-1252): max error 1.45 + 0.5 ulp by its own comment; exact at 0, flushes like the reference"""
+    assert oracle.oracle_v_expf(0.0) == 1.0
+    assert oracle.oracle_v_expf(float("-inf")) == 0.0
+    assert oracle.oracle_v_expf(-200.0) == 0.0
+    xs = np.linspace(-87.0, 0.0, 4001, dtype=np.float32)
+    got = np.array([oracle.oracle_v_expf(float(x)) for x in xs], dtype=np.float32)
+    ref = np.exp(xs.astype(np.float64))
+    assert np.max(np.abs(got - ref) / ref) < 3 * 2.0 ** -24
