@@ -47,6 +47,11 @@ GGML_MI355X_API void * ggml_backend_mi355x_reg(void);
 struct ggml_mi355x_feature { const char * name; const char * value; };
 GGML_MI355X_API struct ggml_mi355x_feature * ggml_backend_mi355x_get_features(void * reg);
 
+/* "ggml_backend_set_n_threads" (looked up by name by src/whisper.cpp:191-205 before every graph): the HIP path has no threads;
+ * the value only selects the key-range chunking of the reference-exact attention mode (GGML_MI355X_EXACT=1), because the
+ * reference CPU flash attention splits single-query steps over its threads (ggml-cpu/ops.cpp:9117-9150) */
+GGML_MI355X_API void ggml_backend_mi355x_set_n_threads(void * backend, int n_threads);
+
 /* Per-kernel profile of one backend (ggml_backend_t): enables hipEvent bracketing of every launch on the
  * backend's stream (graph replay is disabled while profiling).  Rows as in mi355x_prof_row. */
 struct ggml_mi355x_prof_row { const char * name; uint64_t calls; double total_ms; double algo_bytes; double algo_flops; };
@@ -74,6 +79,9 @@ GGML_MI355X_API int ggml_backend_mi355x_weight_buffers(int device, void ** bases
  *   GGML_MI355X_FUSE=0       run every ggml node as its own kernel (debug / parity bisect)
  *   GGML_MI355X_GRAPHS=0     do not build / replay hipGraphs
  *   GGML_MI355X_DEBUG=1      log unsupported ops and kernel-library errors to stderr
+ *   GGML_MI355X_STRICT=1     abort instead of letting the scheduler fall back to the CPU backend for an unsupported op
+ *   GGML_MI355X_EXACT=1      reference-exact arithmetic (test mode, slow): flash attention as the CPU dispatcher computes it
+ *                            (F16 accumulation / split over n_threads / F32 tiles), integer block dots for every column count
  */
 
 #ifdef __cplusplus

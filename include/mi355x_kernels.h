@@ -211,6 +211,15 @@ MI355X_API int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, 
                                      const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */,
                                      const mi355x_tensor * dst, float scale);
 
+/* ggml_flash_attn_ext with the ARITHMETIC of the reference CPU dispatcher (ggml-cpu/ops.cpp:9077-9230), opt-in: split-KV over
+ * `nth` chunks for T == 1 && n_kv >= 512 (the CPU's result depends on its thread count), the F32 tiled path with ggml_v_expf for
+ * T >= 64, the sequential F16-accumulating vec path otherwise; scores in the AVX2 lane order, libm-identical expf.  Same
+ * tensors as mi355x_flash_attn_ext.  Slow by construction (the key loop is sequential like the CPU's); used by the backend
+ * under GGML_MI355X_EXACT=1 to compare free-running decodes token for token with the CPU reference. */
+MI355X_API int mi355x_flash_attn_ext_exact(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k,
+                                           const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */,
+                                           const mi355x_tensor * dst, float scale, int nth);
+
 /* ggml_norm (ggml/src/ggml.c:3139; CPU ggml-cpu/ops.cpp:3698-3765) with optional fused affine
  * (the ggml_mul + ggml_add that always follow it in whisper, src/whisper.cpp:2109-2114). */
 MI355X_API int mi355x_norm(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst, float eps,

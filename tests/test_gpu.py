@@ -410,6 +410,54 @@ def test_flash_attn_vs_oracle(gpu, oracle, T, n_kv, H, mask):
     assert nmse(ref, got) < 1e-4, nmse(ref, got)
 
 
+@pytest.mark.parametrize("T,n_kv,H,mask,nth", [(1, 1536, 20, False, 8), (1, 1536, 20, False, 4), (1, 1536, 6, False, 32), (1, 600, 4, True, 8), (1, 37, 8, True, 8),
+                                                (5, 1536, 20, False, 8), (5, 77, 8, True, 8), (48, 300, 6, True, 8),
+                                                (64, 136, 4, False, 8), (70, 200, 4, True, 8), (256, 256, 8, True, 8), (300, 1536, 3, False, 8)])
+def test_reference_exact_flash_attn(gpu, oracle, T, n_kv, H, mask, nth):
+    """mi355x_flash_attn_ext_exact walks the reference CPU dispatcher's arithmetic (ggml-cpu/ops.cpp:9077-9230): split-KV over nth
+    for T == 1 and n_kv >= 512, F16-accumulating vec path for T < 64, F32 tiled path with ggml_v_expf for T >= 64.  Checked
+    against oracle_flash_attn_ext, which is bit-identical to the reference build (tests/test_oracle.py).  The kernels follow
+    the same operation order with a libm-identical expf, so the words themselves should agree; a rounding of the F16
+    accumulator that lands on the other side is allowed for (tolerance 1e-8 NMSE, 3000x below the F16-vs-F32 accumulation
+    difference of ~3e-5 that the mode exists to remove) and the fraction of identical words is reported."""
+    ctx, ka, torch = gpu
+    D = 64
+    rng = np.random.default_rng(T * 17 + n_kv + nth)
+    q = (rng.standard_normal((T, H, D)) * 0.6).astype(np.float32)
+    k = (rng.standard_normal((n_kv, H, D)) * 0.6).astype(np.float16)
+    v = rng.standard_normal((n_kv, H, D)).astype(np.float16)
+    mh = None
+    if mask:
+        mf = np.zeros((T, n_kv), dtype=np.float32)
+        for t in range(T):
+            mf[t, max(1, n_kv - T + t + 1):] = -np.inf
+        mh = mf.astype(np.float16)
+    ref = np.empty((T, H, D), dtype=np.float32)
+    oracle.oracle_flash_attn_ext(ptr(q), ptr(k.view(np.uint16)), ptr(v.view(np.uint16)), ptr(mh.view(np.uint16)) if mask else None, ptr(ref), D, T, H, n_kv, 0.125, nth)
+    q_d, k_d, v_d = dev(torch, q), dev(torch, k), dev(torch, v)
+    o_d = torch.zeros((T, H, D), dtype=torch.float32, device="cuda:0")
+    tq = ka.tensor(q_d.data_ptr(), ka.F32, [D, T, H], [4, H * D * 4, D * 4, T * H * D * 4])
+    tk = ka.tensor(k_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    tv = ka.tensor(v_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    to = ka.tensor(o_d.data_ptr(), ka.F32, [D, H, T])
+    tm = None
+    if mask:
+        m_d = dev(torch, mh)
+        tm = C.byref(ka.tensor(m_d.data_ptr(), ka.F16, [n_kv, T]))
+    ctx.check(ka.lib().mi355x_flash_attn_ext_exact(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), tm, C.byref(to), 0.125, nth), "flash_attn_exact")
+    ctx.sync()
+    got = o_d.cpu().numpy()
+    same = float((got.view(np.uint32) == ref.view(np.uint32)).mean())
+    err = nmse(ref, got)
+    print(f"exact attention T={T} n_kv={n_kv} H={H} nth={nth}: identical words {same:.4f}, NMSE {err:.2e}")
+    assert err < 1e-8, (err, same)
+    assert same > 0.9, same
+    # and the production kernel (F32 accumulation) differs from the same reference by the F16-accumulation error the mode removes
+    ctx.check(ka.lib().mi355x_flash_attn_ext(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), tm, C.byref(to), 0.125), "flash_attn")
+    ctx.sync()
+    assert nmse(ref, o_d.cpu().numpy()) < 1e-4
+
+
 @pytest.mark.parametrize("T,n_kv,H", [(1, 1536, 20), (1, 130, 8), (5, 300, 6), (8, 129, 4)])
 def test_attention_partials_feed_the_projection(gpu, oracle, T, n_kv, H):
     """decode attention leaves per-128-key partial records; the O-projection mat-vec combines them in its prologue.

@@ -14,6 +14,7 @@
 #include "ggml_mi355x.h"
 #include "mi355x_kernels.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cinttypes>
@@ -362,6 +363,11 @@ struct mi_backend_ctx {
     mi355x_ctx * k;
     std::string  name;
     bool         fuse, graphs, prof;
+    // GGML_MI355X_EXACT=1: walk the reference CPU path's arithmetic where it differs observably from ours — flash attention in
+    // the CPU dispatcher's three forms (F16 accumulation, split over n_threads, F32 tiles; fattn_exact.hip) and integer block dots
+    // for every column count (no f16-rounded d*q products) — so that free-running decodes can be compared token for token
+    bool         exact = false;
+    int          n_threads = 4;               // what the host passes through "ggml_backend_set_n_threads" (the CPU's split-KV chunking)
     // f16 activation scratch for the MFMA path, shared by consecutive mul_mats with the same src1
     void *       act = nullptr; size_t act_size = 0;
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
@@ -531,6 +537,22 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
     const int64_t K = w->ne[0], T = x->ne[1];
     const bool two_d = ggml_n_dims(w) <= 2 && x->ne[2] == 1 && x->ne[3] == 1;
 
+    if (b->exact && two_d && T > 8 && is_quant_type(w->type) && x->type == GGML_TYPE_F32) {
+        // reference-exact mode: the integer-dot mat-vec kernels on 8-column slices (same integer sums as the CPU's vec_dot, f32
+        // scale-accumulate) instead of the MFMA path whose activations are f16-rounded d*q products
+        for (int64_t t0 = 0; t0 < T; t0 += 8) {
+            const int64_t nt = std::min<int64_t>(8, T - t0);
+            mi355x_tensor sx = mx, sd = md;
+            sx.data = (char *) mx.data + t0 * mx.nb[1]; sx.ne[1] = nt;
+            sd.data = (char *) md.data + t0 * md.nb[1]; sd.ne[1] = nt;
+            mi355x_epilogue ep = c.ep;
+            if (ep.residual) ep.residual = (const float *) ((const char *) ep.residual + t0 * ep.residual_nb1);
+            const int rc = mi355x_mul_mat(b->k, &mw, &sx, &sd, has_ep ? &ep : nullptr);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+
     // MFMA path with shared prepared activation
     if (two_d && T > 8 && K % 8 == 0 && x->nb[0] == ggml_type_size(x->type) && (x->nb[1] % 16 == 0) && ((uintptr_t) x->data % 16 == 0) &&
         (x->type == GGML_TYPE_F32 || x->type == GGML_TYPE_F16) &&
@@ -646,7 +668,7 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
     }
     // cross-attention, T = 1: LN -> Q projection -> flash_attn_ext whose q is a pure view of the projection's result and
     // nothing else reads it => one launch computes the attention partials directly (k_qattn)
-    if (n == 1 && T == 1 && b->fuse && j_after < g->n_nodes && g->nodes[j_after]->op == GGML_OP_FLASH_ATTN_EXT) {
+    if (n == 1 && T == 1 && b->fuse && !b->exact && j_after < g->n_nodes && g->nodes[j_after]->op == GGML_OP_FLASH_ATTN_EXT) {
         const ggml_tensor * fa = g->nodes[j_after], * q = fa->src[0], * qsrc = ch[0].last;
         bool ok = q->view_src == qsrc && q->view_offs == 0 && qsrc->type == GGML_TYPE_F32 && ggml_is_contiguous(qsrc) && !qsrc->view_src &&
                   q->ne[0] == 64 && q->ne[1] == 1 && q->ne[3] == 1 && q->ne[2]*64 == qsrc->ne[0] && q->nb[0] == 4 && q->nb[2] == 64*4 &&
@@ -894,6 +916,13 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
                     if (rc != MI355X_E_UNSUPPORTED) i = j2;
                 }
             }
+            if (rc == MI355X_E_UNSUPPORTED) rc = run_node(b, n);
+            b->act_src = nullptr;
+        } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->exact) {
+            mi355x_tensor q = to_mt(n->src[0]), kk = to_mt(n->src[1]), v = to_mt(n->src[2]), d = to_mt(n), m;
+            if (n->src[3]) m = to_mt(n->src[3]);
+            float scale; memcpy(&scale, n->op_params, 4);
+            rc = mi355x_flash_attn_ext_exact(b->k, &q, &kk, &v, n->src[3] ? &m : nullptr, &d, scale, b->n_threads);
             if (rc == MI355X_E_UNSUPPORTED) rc = run_node(b, n);
             b->act_src = nullptr;
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->fuse && n->src[0]->ne[1] <= 8) {
@@ -1169,6 +1198,8 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
     mi_backend_ctx * b = new mi_backend_ctx();
     b->device = d->index; b->k = k; b->name = d->name;
     b->fuse = env_flag("GGML_MI355X_FUSE", true); b->graphs = env_flag("GGML_MI355X_GRAPHS", true); b->prof = env_flag("GGML_MI355X_PROF", false);
+    b->exact = env_flag("GGML_MI355X_EXACT", false);
+    if (b->exact) b->graphs = false;          // a test mode: thousands of small launches per graph, replay buys nothing
     if (b->prof) mi355x_prof_enable(k, 1);
     { std::lock_guard<std::mutex> lk(g_weights_mtx); g_backends.push_back(b); }
     return new ggml_backend{ mi_guid(), mi_backend_iface, dev, b };
@@ -1249,6 +1280,13 @@ extern "C" {
 
 ggml_mi355x_feature * ggml_backend_mi355x_get_features(void *) { return g_features; }
 
+// whisper.cpp hands its n_threads to every backend of the scheduler before each graph (src/whisper.cpp:191-205, looked up by
+// name).  The HIP path has no threads; the value is kept because the reference CPU flash attention splits the key range of a
+// single-query step over its threads (ggml-cpu/ops.cpp:9117-9150): the reference-exact mode reproduces that chunking.
+void ggml_backend_mi355x_set_n_threads(void * backend, int n_threads) {
+    mi_backend_ctx * b = as_ctx(backend); if (b && n_threads > 0) b->n_threads = n_threads;
+}
+
 void ggml_backend_mi355x_prof_enable(void * backend, int on) {
     mi_backend_ctx * b = as_ctx(backend); if (!b) return;
     b->prof = on != 0; mi355x_prof_enable(b->k, on);
@@ -1320,6 +1358,7 @@ int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes
 
 static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_get_features"))           return (void *) ggml_backend_mi355x_get_features;
+    if (!strcmp(name, "ggml_backend_set_n_threads"))          return (void *) ggml_backend_mi355x_set_n_threads;
     if (!strcmp(name, "ggml_backend_mi355x_prof_enable"))     return (void *) ggml_backend_mi355x_prof_enable;
     if (!strcmp(name, "ggml_backend_mi355x_prof_reset"))      return (void *) ggml_backend_mi355x_prof_reset;
     if (!strcmp(name, "ggml_backend_mi355x_prof_report"))     return (void *) ggml_backend_mi355x_prof_report;
