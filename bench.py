@@ -30,7 +30,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy, 79 % of spec) — reported beside the spec peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
 
 
@@ -136,6 +137,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU in the timed region (headline config: 1)")
     ap.add_argument("--multi-stream", type=int, default=4, help="also measure S concurrent streams on one GPU after the headline (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="whisper-bench", choices=["whisper-bench", "bounded"],
+                    help="whisper-bench: the metric's own tool, the reference build's `whisper-bench -ng -t N` (all four columns, after its own two "
+                         "heat-up rounds); bounded: 1 cold encode + 16 decodes through oracle/cpu_baseline.cpp, extrapolated (for very slow hosts)")
     ap.add_argument("--profile-only", action="store_true", help="print the per-kernel hipEvent profile of one chunk and exit")
     ap.add_argument("--profile-what", default="chunk", choices=["chunk", "batchd", "prompt"], help="what --profile-only measures")
     ap.add_argument("--no-profile", action="store_true", help="skip the hipEvent per-kernel pass (no roofline object; used under rocprofv3 --pmc)")
@@ -314,7 +318,8 @@ def main():
             else:
                 ach = dom["algo_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
                 out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+                                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                                   "measured_copy_ceiling": HBM_COPY_CEILING_GBS, "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4)}
             # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
             # MI355X_MICROARCH.md prescribes; profiles/pmc_traffic.json says how it was collected); null if not measured
             try:
@@ -339,19 +344,42 @@ def main():
                                     "encode_TFLOP": round(figs["encode_flop"] / 1e12, 3),
                                     "encode_TFLOPs_at_measured_ms": round(figs["encode_flop"] / (encode_ms * 1e-3) / 1e12, 2) if encode_ms > 0 else None}
         if world == 1 and not a.no_cpu_baseline:
-            exe = ROOT / "oracle" / "_ref" / "cpu_baseline"
             # threads actually used: ggml's CPU path stops scaling (and with 2-way SMT oversubscription collapses) well
             # below the 256 hardware threads of the GPU box's host; 32 = one thread per core of half a socket
             cores = max(1, min(32, (os.cpu_count() or 2) // 2))
-            n_dec = 16 if "large" in a.arch else 64
+            env = dict(os.environ, LD_LIBRARY_PATH=str(ROOT / "oracle" / "_ref"), OMP_PROC_BIND="close", OMP_PLACES="cores")
+            env.pop("GGML_BACKEND_PATH", None)
             try:
-                env = dict(os.environ, LD_LIBRARY_PATH=str(ROOT / "oracle" / "_ref"), OMP_PROC_BIND="close", OMP_PLACES="cores")
-                r = subprocess.run([str(exe), str(model), str(cores), str(n_dec), "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
-                cb = json.loads(r.stdout.strip().splitlines()[-1])
-                out["cpu_baseline"] = {"value": round(cb["encode_ms"] + a.n_decode * cb["decode_ms_per_token"], 2), "unit": "ms/chunk", "cores": cores,
-                                       "kind": "reference", "encode_ms": cb["encode_ms"], "decode_ms_per_token": cb["decode_ms_per_token"],
-                                       "sample": f"reference AVX2 CPU path (oracle/_ref, use_gpu=false): 1 cold whisper_encode + {n_dec} single-token decodes, "
-                                                 f"extrapolated to encode + {a.n_decode} x decode", "system_info": cb["system_info"].strip()}
+                if a.cpu_baseline == "whisper-bench":
+                    # the metric's own tool from the reference build (oracle/_ref, AVX2-only flags: oracle/Makefile), CPU only (-ng),
+                    # its own protocol: two heat-up rounds, then 1 encode, 256 x 1-token, 64 x 5-token, 16 x 256-token decodes
+                    # (examples/bench/bench.cpp:63-170; scripts/bench-all.sh:73-77 parses the same lines)
+                    import re
+                    t0 = time.perf_counter()
+                    r = subprocess.run([str(ROOT / "oracle" / "_ref" / "whisper-bench"), "-m", str(model), "-ng", "-t", str(cores)], env=env,
+                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+                    wall = time.perf_counter() - t0
+                    col = {}
+                    for name in ("encode", "decode", "batchd", "prompt"):
+                        mm = re.search(rf"{name} time =\s*([0-9.]+) ms /\s*(\d+) runs \(\s*([0-9.]+) ms per run\)", r.stdout)
+                        col[name] = (float(mm.group(1)), int(mm.group(2)), float(mm.group(3)))
+                    si = re.search(r"system_info: (.*)", r.stdout)
+                    enc_ms, dec_ms = col["encode"][2], col["decode"][0] / col["decode"][1]
+                    out["cpu_baseline"] = {"value": round(enc_ms + a.n_decode * dec_ms, 2), "unit": "ms/chunk", "cores": cores, "kind": "reference",
+                                           "encode_ms": enc_ms, "decode_ms_per_token": round(dec_ms, 4),
+                                           "batchd_ms_per_token": round(col["batchd"][0] / col["batchd"][1], 4), "prompt_ms_per_token": round(col["prompt"][0] / col["prompt"][1], 4),
+                                           "sample": f"oracle/_ref/whisper-bench -ng -t {cores} (reference build, AVX2-only flags, flash-attn on): warm, after the tool's own two heat-up "
+                                                     f"rounds; encode + {a.n_decode} x decode from its 'encode time' and 'decode time' lines; {wall:.0f} s of host wall time",
+                                           "system_info": si.group(1).strip() if si else None}
+                else:
+                    exe = ROOT / "oracle" / "_ref" / "cpu_baseline"
+                    n_dec = 16 if "large" in a.arch else 64
+                    r = subprocess.run([str(exe), str(model), str(cores), str(n_dec), "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
+                    cb = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["cpu_baseline"] = {"value": round(cb["encode_ms"] + a.n_decode * cb["decode_ms_per_token"], 2), "unit": "ms/chunk", "cores": cores,
+                                           "kind": "reference", "encode_ms": cb["encode_ms"], "decode_ms_per_token": cb["decode_ms_per_token"],
+                                           "sample": f"reference AVX2 CPU path (oracle/_ref, use_gpu=false): 1 cold whisper_encode + {n_dec} single-token decodes, "
+                                                     f"extrapolated to encode + {a.n_decode} x decode", "system_info": cb["system_info"].strip()}
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "ms/chunk", "cores": cores, "kind": "reference", "sample": f"failed: {e}"}
         print(json.dumps(out))

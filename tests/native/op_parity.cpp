@@ -180,6 +180,12 @@ static void run_case(const std::string & name, const build_fn & fn, bool node_mo
                 report(name + (outs.size() > 1 ? "#" + std::to_string(i) : "") + (pass ? "@replay" : ""), "sched", compare(ref[i], read_f32(outs[i])));
         }
         if (getenv("OP_PARITY_SPLITS")) fprintf(stderr, "%s: splits=%d\n", name.c_str(), ggml_backend_sched_get_n_splits(sched));
+        // every node on the plugin: one split, computed by the first backend.  (With GGML_MI355X_STRICT=1 an unsupported node
+        // already aborts inside supports_op; this is the positive statement of the same thing.)
+        if (getenv("OP_PARITY_ASSERT_SPLITS") && ggml_backend_sched_get_n_splits(sched) != 1) {
+            fprintf(stderr, "%s: scheduler produced %d splits (expected 1: the whole graph on the MI355X backend)\n", name.c_str(), ggml_backend_sched_get_n_splits(sched));
+            exit(6);
+        }
         ggml_backend_sched_free(sched);
         ggml_backend_buffer_free(wbuf);
         ggml_free(b.ctx);
