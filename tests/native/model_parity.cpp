@@ -63,6 +63,9 @@ int main(int argc, char ** argv) {
     for (int j = 0; j < n_mels; j++) for (int i = 0; i < n_len; i++)
         mel[(size_t) j * n_len + i] = 0.6f * sinf(0.013f * i + 0.21f * j) + 0.4f * ((rng() >> 8) * (1.0f / 8388608.0f) - 1.0f);
     whisper_set_mel(cpu, mel.data(), n_len, n_mels);
+    // self-test with MODEL_PARITY_PERTURB=eps: the reference against ITSELF on an input scaled by (1 + eps) — how far the reference's
+    // own logits move under a perturbation of the size of one f32 rounding (its int8 activation rounding decides discretely)
+    if (selftest && getenv("MODEL_PARITY_PERTURB")) { const float e = 1.0f + (float) atof(getenv("MODEL_PARITY_PERTURB")); for (auto & x : mel) x *= e; }
     whisper_set_mel(gpu, mel.data(), n_len, n_mels);
 
     auto t0 = std::chrono::steady_clock::now();
