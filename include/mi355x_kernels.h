@@ -85,6 +85,7 @@ MI355X_API int             mi355x_step_upload(mi355x_ctx * ctx);       /* host v
 /* arm: the NEXT mi355x_get_rows_add launch (the first kernel of a decoder graph) also stores the host values of slots 1..3 into the
  * device block — the values travel in that launch's own arguments, every later launch of the step sees them in stream order */
 MI355X_API void            mi355x_step_arm(mi355x_ctx * ctx, int on);
+MI355X_API int             mi355x_step_armed(mi355x_ctx * ctx);        /* 1 while no launch has taken the values yet (then: mi355x_step_upload) */
 
 /* launch recording: between begin/end no kernel is launched; launches are appended to the context's
  * plan instead (used by the backend to build / patch a hipGraph).  See ggml_mi355x.h. */

@@ -947,6 +947,8 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
                 }
             }
             if (rc == MI355X_E_UNSUPPORTED) rc = run_node(b, n);
+            // the fused embedding launch normally carries this step's numbers into the step block; if it was not produced, copy them
+            if (b->step_on && mi355x_step_armed(b->k) && mi355x_step_upload(b->k) != 0) rc = -2;
             b->act_src = nullptr;
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->exact) {
             mi355x_tensor q = to_mt(n->src[0]), kk = to_mt(n->src[1]), v = to_mt(n->src[2]), d = to_mt(n), m;

@@ -94,12 +94,14 @@ extern "C" int mi355x_step_set(mi355x_ctx * ctx, int slot, int64_t value) {
     return 0;
 }
 extern "C" void mi355x_step_arm(mi355x_ctx * ctx, int on) { ctx->step_armed = on != 0; }
+extern "C" int  mi355x_step_armed(mi355x_ctx * ctx) { return ctx->step_armed ? 1 : 0; }
 extern "C" void * mi355x_step_device(mi355x_ctx * ctx) { return ctx->step_dev; }
 extern "C" const int64_t * mi355x_step_host(mi355x_ctx * ctx) { return ctx->step_host; }
 extern "C" int mi355x_step_upload(mi355x_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
     HIP_OK(hipMemcpyAsync(ctx->step_dev, ctx->step_host, MI355X_STEP_SLOTS * 8, hipMemcpyHostToDevice, ctx->stream));
     HIP_OK(hipStreamSynchronize(ctx->stream));        // the host array may change right after this call
+    ctx->step_armed = false;
     return 0;
 }
 
