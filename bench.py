@@ -82,34 +82,28 @@ def load_host(plugin: Path):
     return w, p
 
 
-class _DevMem:
-    """expose a raw device range to torch through __cuda_array_interface__ (no copy)"""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
-def broadcast_weights(p, dist, torch, device: int, rank: int):
-    """one-time RCCL broadcast (over xGMI) of rank 0's WEIGHTS buffers into the identically laid out
-    buffers of every other replica.  Every context allocates the same tensors in the same order, so buffer i has the same
-    size on every rank (checked).  Outside the timed region; no collective is ever issued on the per-chunk path."""
-    cap = 64
-    bases, sizes = (C.c_void_p * cap)(), (C.c_size_t * cap)()
-    p.ggml_backend_mi355x_weight_buffers.argtypes = [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]
-    n = p.ggml_backend_mi355x_weight_buffers(device, bases, sizes, cap)
+def broadcast_weights(p, dist, torch, device: int, rank: int, world: int):
+    """one-time RCCL broadcast (over xGMI) of rank 0's WEIGHTS buffers into the identically laid out buffers
+    of every other replica, done NATIVELY by the plugin (ggml_backend_mi355x_broadcast_weights_rccl: its own communicator from a
+    unique id that rank 0 creates and this harness hands to every rank, ncclBroadcast per buffer, then a device-side checksum of
+    every buffer compared across all ranks).  Outside the timed region; no collective is ever issued on the per-chunk path.
+    Anything but a VERIFIED broadcast raises: replicas r > 0 never read the tensor payloads of the model file."""
+    from whisper_cpp_amd.dist_timing import all_ranks_ok, share_bytes
+    uid = (C.c_ubyte * 128)()
+    got_id = rank != 0 or p.ggml_backend_mi355x_rccl_unique_id(uid) == 0
+    if not all_ranks_ok(dist, torch, got_id, "cuda"):
+        raise RuntimeError("ggml_backend_mi355x_rccl_unique_id failed on rank 0 (librccl.so not loadable?)")
+    uid = (C.c_ubyte * 128)(*share_bytes(dist, torch, bytes(uid) if rank == 0 else None, 128, "cuda"))   # over the harness's own process group
+    stats = (C.c_double * 4)()
+    p.ggml_backend_mi355x_broadcast_weights_rccl.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
     t0 = time.perf_counter()
-    try:
-        from whisper_cpp_amd.dist_timing import broadcast_buffers
-        views = [torch.as_tensor(_DevMem(int(bases[i]), int(sizes[i])), device="cuda") for i in range(min(n, cap))]
-        total = broadcast_buffers(dist, torch, views, device="cuda", cap=cap, n=n)     # n > cap: every rank skips together
-        if total is None:
-            raise RuntimeError("weight buffer layout differs between ranks")
-        torch.cuda.synchronize()
-        return {"bytes": total, "buffers": n, "seconds": round(time.perf_counter() - t0, 4)}
-    except Exception as e:  # noqa: BLE001  (every rank already holds the weights from the model file: safe to continue)
-        if rank == 0:
-            print(f"bench.py: weight broadcast skipped: {e}", file=sys.stderr)
-        return None
+    rc = p.ggml_backend_mi355x_broadcast_weights_rccl(device, rank, world, uid, stats)
+    wall = time.perf_counter() - t0
+    if not all_ranks_ok(dist, torch, rc == 0 and stats[3] == 1.0, "cuda"):
+        raise RuntimeError(f"weight broadcast failed or could not be verified on some rank (this rank: rc={rc}, verified={stats[3]})")
+    return {"bytes": int(stats[0]), "buffers": int(stats[2]), "seconds": round(stats[1], 4), "GBps": round(stats[0] / max(stats[1], 1e-9) / 1e9, 2),
+            "verified": True, "transport": "RCCL ncclBroadcast issued by the plugin (ggml_backend_mi355x_broadcast_weights_rccl), checksums compared across ranks",
+            "seconds_incl_communicator_setup": round(wall, 3)}
 
 
 def algorithmic_figures(arch: str, qtype: str):
@@ -148,6 +142,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    under_torchrun = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # also with one process: the distribution path is exercised
     os.environ.setdefault("GGML_MI355X_STRICT", "1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # one hardware queue per concurrent stream (+ the upload stream): with ROCm's default of 4, two of the 4 + 1 HIP streams of
@@ -160,7 +155,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if under_torchrun:
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -183,12 +178,28 @@ def main():
 
     plugin = ROOT / "whisper.cpp_amd" / "lib" / "libggml-mi355x.so"
     w, p = load_host(plugin)
-    cp = w.whisper_context_default_params()
-    cp.use_gpu, cp.flash_attn, cp.gpu_device = True, True, local_rank
-    ctx = w.whisper_init_from_file_with_params(str(model).encode(), cp)
-    if not ctx:
-        raise SystemExit("whisper_init_from_file_with_params failed")
-    bcast = broadcast_weights(p, dist, torch, local_rank, rank) if dist is not None else None
+    bcast, payload_read = None, None
+    if dist is None:
+        cp = w.whisper_context_default_params()
+        cp.use_gpu, cp.flash_attn, cp.gpu_device = True, True, local_rank
+        ctx = w.whisper_init_from_file_with_params(str(model).encode(), cp)
+        if not ctx:
+            raise SystemExit("whisper_init_from_file_with_params failed")
+    else:
+        # replicas r > 0 open the model through the payload-skipping whisper_model_loader of the native host library (header,
+        # filters, vocabulary only) and receive every weight byte from rank 0's HBM; an unverified broadcast ends the run (rc != 0)
+        from whisper_cpp_amd import host_api
+        rd = C.c_int64(0)
+        ctx = host_api.lib().mi355x_host_open(str(model).encode(), 1, local_rank, 1, 1 if rank > 0 else 0, C.byref(rd))
+        if not ctx:
+            raise SystemExit("mi355x_host_open failed")
+        try:
+            bcast = broadcast_weights(p, dist, torch, local_rank, rank, world)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: rank {rank}: {e}", file=sys.stderr)
+            os._exit(3)
+        bcast["model_file_bytes_read_by_this_rank"] = int(rd.value)
+        bcast["model_file_bytes"] = Path(model).stat().st_size
     n_mels = w.whisper_model_n_mels(ctx)
     mel = (np.random.default_rng(42 + rank).random((n_mels, 3000), dtype=np.float32) * 2 - 1)
     w.whisper_set_mel(ctx, mel.ctypes.data_as(C.c_void_p), 3000, n_mels)

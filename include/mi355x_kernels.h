@@ -299,6 +299,11 @@ MI355X_API int mi355x_debug_read_stamps(mi355x_ctx * ctx, unsigned long long * o
 /* wide empty launch on `stream` (hipStream_t): wakes the whole chip ahead of the first real dispatch of a decode step */
 MI355X_API int mi355x_wake(void * stream, int nblocks);
 
+/* order-independent 128-bit checksum of a device range on `stream` (hipStream_t): out[0] = sum of the 64-bit words, out[1] = sum of
+ * word * (2*index + 1), mod 2^64; dev_out16 is 16 bytes of DEVICE memory.  Used to verify that every replica's weight buffers equal
+ * rank 0's after the one-time broadcast. */
+MI355X_API int mi355x_checksum(void * stream, const void * dptr, size_t nbytes, void * dev_out16);
+
 /* memset / memcpy helpers on the context stream */
 MI355X_API int mi355x_memset(mi355x_ctx * ctx, void * dptr, int value, size_t n);
 

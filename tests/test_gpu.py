@@ -865,3 +865,38 @@ def test_bench_smoke():
         assert k in d, k
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
     assert d["multi_stream"]["streams"] == 4 and d["multi_stream"]["chunks_per_s"] > 0, d["multi_stream"]
+
+
+def test_bench_under_torchrun_exercises_the_native_weight_distribution():
+    """one rank under torchrun: the multi-process path of bench.py end to end on real hardware — mi355x_host_open, a RCCL communicator
+    created by the plugin from the shared unique id, ncclBroadcast of every weights buffer, device-side checksums compared across ranks.
+    (More than one rank needs more than one GPU; the driver's scaling run is the first time that happens.)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+                        str(ROOT / "bench.py"), "--gpus", "1", "--arch", "base.en", "--qtype", "q5_0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--multi-stream", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    wb = d["weight_broadcast"]
+    assert wb and wb["verified"] is True and wb["bytes"] > 10e6 and wb["buffers"] >= 1, wb
+    assert d["value"] > 0
+
+
+def test_native_harness_streams_on_the_gpu_are_bit_identical_to_a_single_stream():
+    """the C++ harness (one thread per whisper_state, include/mi355x_host.h): 4 concurrent streams on one MI355X, stream 0's logits
+    equal to the same stream running alone; throughput reported"""
+    from synth_model import make_model
+    from whisper_cpp_amd import host_api as h
+    m = make_model("base.en", "q5_0")
+    n_vocab = 51864
+    r4 = h.run(m, use_gpu=True, n_devices=1, streams=4, n_decode=12, steps=2, warmup=1)
+    assert r4["rc"] == 0 and r4["error"] == "", r4
+    rows4 = np.zeros(4 * n_vocab, dtype=np.float32)
+    assert h.lib().mi355x_host_last_logits(rows4.ctypes.data, rows4.size) == 4 * n_vocab
+    r1 = h.run(m, use_gpu=True, n_devices=1, streams=1, n_decode=12, steps=2, warmup=1)
+    assert r1["rc"] == 0, r1
+    row1 = np.zeros(n_vocab, dtype=np.float32)
+    assert h.lib().mi355x_host_last_logits(row1.ctypes.data, row1.size) == n_vocab
+    rows4 = rows4.reshape(4, n_vocab)
+    assert np.isfinite(rows4).all() and np.array_equal(rows4[0], row1) and not np.array_equal(rows4[0], rows4[1])
+    assert r4["chunks_per_s"] > 0

@@ -275,31 +275,26 @@ import torch
 import torch.distributed as dist
 import __graft_entry__ as g
 g.load_package()
-from whisper_cpp_amd.dist_timing import broadcast_buffers
+from whisper_cpp_amd.dist_timing import all_ranks_ok, share_bytes
 dist.init_process_group("gloo")
 rank = dist.get_rank()
-gen = torch.Generator().manual_seed(100 + rank)
-# case 1: identical layout -> every rank ends up with rank 0's bytes
-bufs = [torch.randint(0, 256, (n,), dtype=torch.uint8, generator=gen) for n in (4096, 1000, 77)]
-g0 = torch.Generator().manual_seed(100)
-want = [torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g0) for n in (4096, 1000, 77)]
-total = broadcast_buffers(dist, torch, bufs)
-ok1 = total == 5173 and all(torch.equal(a, b) for a, b in zip(bufs, want))
-# case 2: rank 1 has a different layout -> BOTH ranks skip, nobody hangs, buffers untouched
-mine = [torch.full((64 + 8 * rank,), rank + 1, dtype=torch.uint8)]
-r2 = broadcast_buffers(dist, torch, mine)
-ok2 = r2 is None and bool((mine[0] == rank + 1).all())
-# case 3: more buffers than the cap on one rank -> skip together
-r3 = broadcast_buffers(dist, torch, [torch.zeros(8, dtype=torch.uint8)], cap=4, n=(9 if rank == 0 else 1))
-ok3 = r3 is None
+# the unique id of the plugin's RCCL communicator: created on rank 0, identical on every rank afterwards
+uid = bytes(range(100, 228)) if rank == 0 else None
+got = share_bytes(dist, torch, uid, 128)
+ok1 = got == bytes(range(100, 228))
+# every rank verified -> go on; ONE rank failing its checksum -> everybody stops together
+ok2 = all_ranks_ok(dist, torch, True) is True
+ok3 = all_ranks_ok(dist, torch, rank != 1) is False
 open(os.path.join({out!r}, "b%d.txt" % rank), "w").write("%d %d %d" % (ok1, ok2, ok3))
 dist.destroy_process_group()
 """
 
 
-def test_two_rank_weight_broadcast_logic(tmp_path):
-    """the one collective of the system (weights, once, at load — SURVEY.md 8e) on gloo with world size 2: data lands, and a
-    layout mismatch on ANY rank makes ALL ranks skip instead of deadlocking inside a broadcast"""
+def test_two_rank_weight_distribution_protocol(tmp_path):
+    """the host side of the one collective of the system (weights, once, at load — SURVEY.md 8e) on gloo with world size 2: the
+    128-byte communicator id reaches every rank, and a failed / unverified broadcast on ANY rank stops ALL ranks (bench.py then
+    exits non-zero instead of benchmarking a replica with different weights).  The broadcast itself is issued by the plugin
+    (ggml_backend_mi355x_broadcast_weights_rccl) and needs GPUs."""
     script = tmp_path / "b.py"
     script.write_text(_BCAST_WORKER.format(root=str(ROOT), out=str(tmp_path)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
@@ -330,3 +325,57 @@ def test_reference_is_sensitive_to_one_ulp(tmp_path):
     assert 1e-6 < out["q5_0"]["mean_nmse"] < 5e-4, out["q5_0"]       # the floor the GPU tolerances (5e-4) are set against
     assert out["f16"]["mean_nmse"] < 1e-5, out["f16"]
     assert out["q5_0"]["mean_nmse"] > 20 * out["f16"]["mean_nmse"], out
+
+
+def _host_api():
+    from whisper_cpp_amd import host_api
+    if not host_api.HOST_SO.exists():
+        pytest.skip("libmi355x_host.so not built (needs the reference tree)")
+    return host_api
+
+
+def test_payload_skipping_loader_serves_header_and_stops_at_the_tensors(tmp_path):
+    """replicas r > 0 get their weights by broadcast: their whisper_model_loader (include/whisper.h:153-159) serves hyper-parameters,
+    mel filters and vocabulary and reports end-of-file where the tensor records begin — the reference allocates every tensor and
+    loads none (src/whisper.cpp:1944-1946).  Run here on the CPU backend: the model opens, and only the header was read."""
+    from synth_model import make_model
+    h = _host_api()
+    m = make_model("micro", "q5_0", tmp_path)
+    out = (C.c_int64 * 3)()
+    rc = h.lib().mi355x_host_probe_skipping_loader(str(m).encode(), out)
+    assert rc == 0
+    read, fsize, off = int(out[0]), int(out[1]), int(out[2])
+    assert fsize == m.stat().st_size and 0 < off < fsize
+    assert read == off                      # exactly the header / filters / vocabulary, not one payload byte
+    assert read < fsize // 4
+
+
+def test_native_harness_two_contexts_two_streams_on_cpu(tmp_path):
+    """the N-contexts x S-states harness (one thread per whisper_state, all started together, wall = slowest thread) on the
+    reference CPU backend: 2 x 2 streams complete, throughput is reported, the streams are distinct and repeatable"""
+    from synth_model import make_model
+    h = _host_api()
+    m = make_model("micro", "q5_0", tmp_path)
+    r = h.run(m, use_gpu=False, n_devices=2, streams=2, n_decode=6, steps=2, warmup=1, n_threads=2)
+    assert r["rc"] == 0 and r["error"] == "", r
+    assert r["n_devices"] == 2 and r["streams_per_device"] == 2
+    assert r["wall_s"] > 0 and abs(r["chunks_per_s"] - 8 / r["wall_s"]) < 1e-6 * r["chunks_per_s"]
+    assert r["payload_bytes_read"] == 2 * r["file_bytes"]          # CPU mode: every context reads the whole file, nothing is skipped
+    n_vocab = 51864
+    buf = np.zeros(4 * n_vocab, dtype=np.float32)
+    assert h.lib().mi355x_host_last_logits(buf.ctypes.data, buf.size) == 4 * n_vocab
+    rows = buf.reshape(4, n_vocab)
+    assert np.isfinite(rows).all() and not np.array_equal(rows[0], rows[1])           # different mel per stream
+    r2 = h.run(m, use_gpu=False, n_devices=1, streams=1, n_decode=6, steps=1, warmup=0, n_threads=2)
+    buf2 = np.zeros(n_vocab, dtype=np.float32)
+    assert r2["rc"] == 0 and h.lib().mi355x_host_last_logits(buf2.ctypes.data, buf2.size) == n_vocab
+    assert np.array_equal(buf2, rows[0])                                              # stream (0, 0) alone == inside the 2 x 2 run
+
+
+def test_native_harness_refuses_gpu_mode_without_the_plugin(tmp_path):
+    from synth_model import make_model
+    h = _host_api()
+    m = make_model("micro", "q5_0", tmp_path)
+    cfg = h.Config(str(m).encode(), b"/nonexistent/libggml-mi355x.so", 1, 1, 0, 1, 2, 1, 0, 2, 1, 1)
+    res = h.Result()
+    assert h.lib().mi355x_host_run(C.byref(cfg), C.byref(res)) != 0 and b"plugin" in res.error

@@ -95,10 +95,28 @@ def build_backend():
     return so
 
 
+def build_host():
+    """native host harness above whisper.h (include/mi355x_host.h): compiled against the reference's PUBLIC headers where they lie,
+    linked against the unmodified reference application's libwhisper (host/_whisper)."""
+    so = LIB / "libmi355x_host.so"
+    src = CSRC / "host" / "host_harness.cpp"
+    if not (REF / "include" / "whisper.h").exists():
+        if so.exists():
+            return so
+        raise RuntimeError(f"{REF} not found and no prebuilt {so}")
+    refdir = PKG / "host" / "_whisper"
+    if _stale(so, [src, ROOT / "include" / "mi355x_host.h"]):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-pthread",
+              f"-I{ROOT / 'include'}", f"-I{REF / 'include'}", f"-I{REF / 'ggml' / 'include'}", str(src), "-o", str(so),
+              f"-L{refdir}", "-lwhisper", "-lggml", "-lggml-base", "-Wl,-rpath,$ORIGIN/../host/_whisper"])
+    return so
+
+
 def build_all(verbose=False):
     k = build_kernels(verbose)
     o = build_oracle()
     b = build_backend()
+    build_host()
     return k, o, b
 
 
@@ -110,5 +128,7 @@ if __name__ == "__main__":
         print(build_oracle())
     elif which == "backend":
         print(build_backend())
+    elif which == "host":
+        print(build_host())
     else:
         print(build_all(True))

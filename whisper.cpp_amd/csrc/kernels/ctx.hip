@@ -320,3 +320,31 @@ extern "C" int mi355x_repack_to_planar(int type, const void * ggml_blocks, void 
 extern "C" int mi355x_repack_from_planar(int type, const void * planar, void * ggml_blocks, int64_t nelements) {
     return repack<false>(type, (const uint8_t *) planar, (uint8_t *) ggml_blocks, nelements);
 }
+
+// ---- buffer checksum (multi-GPU weight distribution: every replica's weights must equal rank 0's) ------------------------
+// out[0] = sum of the 64-bit words, out[1] = sum of word * (2*index + 1), both mod 2^64: independent of the summation order,
+// sensitive to any changed, missing or transposed word.  Tail bytes (< 8) are folded in as one zero-padded word.
+__global__ void __launch_bounds__(256) k_checksum(const uint64_t * __restrict__ p, size_t nwords, const uint8_t * tail, int ntail, unsigned long long * out) {
+    unsigned long long s0 = 0, s1 = 0;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t) gridDim.x * 256) {
+        const unsigned long long w = p[i];
+        s0 += w; s1 += w * (2ull * i + 1ull);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && ntail > 0) {
+        unsigned long long w = 0;
+        for (int b = 0; b < ntail; b++) w |= (unsigned long long) tail[b] << (8*b);
+        s0 += w; s1 += w * (2ull * nwords + 1ull);
+    }
+    // wave reduction (integer adds: order does not matter), one atomic pair per wave
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o, 64); s1 += __shfl_xor(s1, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], s0); atomicAdd(&out[1], s1); }
+}
+extern "C" int mi355x_checksum(void * stream, const void * dptr, size_t nbytes, void * dev_out16) {
+    HIP_OK(hipMemsetAsync(dev_out16, 0, 16, (hipStream_t) stream));
+    if (nbytes == 0) return 0;
+    const size_t nwords = nbytes / 8;
+    const int ntail = (int) (nbytes % 8);
+    size_t nb = (nwords + 255) / 256; if (nb < 1) nb = 1; if (nb > 4096) nb = 4096;
+    k_checksum<<<dim3((uint32_t) nb), dim3(256), 0, (hipStream_t) stream>>>((const uint64_t *) dptr, nwords, (const uint8_t *) dptr + nwords*8, ntail, (unsigned long long *) dev_out16);
+    return (int) hipGetLastError();
+}

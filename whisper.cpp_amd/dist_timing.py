@@ -47,24 +47,18 @@ def aggregate(elapsed_s: float, steps: int, world: int):
     return ms_per_step, ms_per_step / world, world * steps / elapsed_s
 
 
-def broadcast_buffers(dist, torch, views, device="cpu", cap: int = 64, n: int | None = None):
-    """One-time weight distribution: broadcast rank 0's buffers into the identically laid out buffers of
-    every other rank.  `views` = one flat uint8 tensor per weight buffer, aliasing the buffer (device memory under RCCL,
-    host memory under gloo in the CPU test).  Every rank first learns rank 0's buffer count and sizes; if ANY rank's layout
-    differs, all ranks skip together (an all-reduce MIN carries the decision, so no rank is left waiting inside a
-    collective) and keep the weights they loaded from the model file.  `n` = the rank's true buffer count when it exceeds
-    `cap` (then everybody skips too).  Returns bytes broadcast, or None when skipped."""
-    n = len(views) if n is None else n
-    sizes = [int(v.numel()) for v in views[:cap]]
-    meta = torch.tensor([n] + sizes + [0] * (cap - len(sizes)), dtype=torch.int64, device=device)
-    ref = meta.clone()
-    dist.broadcast(ref, src=0)
-    ok = torch.tensor([1 if torch.equal(ref, meta) and 0 < n <= cap else 0], dtype=torch.int32, device=device)
+def share_bytes(dist, torch, payload: bytes | None, n: int, device="cpu") -> bytes:
+    """rank 0's `n` bytes on every rank (the 128-byte RCCL unique id of the plugin's weight broadcast travels this way, over the
+    harness's own process group)."""
+    t = torch.tensor(list(payload) if payload is not None else [0] * n, dtype=torch.uint8, device=device)
+    assert t.numel() == n
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().tolist())
+
+
+def all_ranks_ok(dist, torch, ok_local: bool, device="cpu") -> bool:
+    """True only if EVERY rank reports success (all-reduce MIN): a replica whose weights could not be verified makes the whole job
+    fail together instead of benchmarking a different model on one GPU."""
+    ok = torch.tensor([1 if ok_local else 0], dtype=torch.int32, device=device)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
-        return None
-    total = 0
-    for v in views:
-        dist.broadcast(v, src=0)
-        total += int(v.numel())
-    return total
+    return int(ok.item()) == 1
