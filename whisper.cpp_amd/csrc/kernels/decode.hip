@@ -25,6 +25,20 @@
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+// A step-block value.  The block is written by a KERNEL of the same graph (the embedding launch, mi355x_step_arm) and read through a
+// wave-uniform address, which the compiler would turn into a scalar load: the scalar data cache is not refreshed between the
+// kernels of a replayed graph (measured: the previous step's values were read).  An agent-scope atomic load is a vector load
+// served by L2.
+__device__ __forceinline__ int64_t step_load(const int64_t * p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// low 32 bits of a slot (key counts): with the 64-bit form the compiler reuses the dead high register of the pair right away, which
+// puts an s_waitcnt vmcnt(0) in front of the K / V request burst
+__device__ __forceinline__ int step_load32(const int64_t * p) {
+    return __hip_atomic_load((const int *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct DGSeg {
     const void *  w;  int64_t nbt;  int N;  int has_scale;
     const float * bias; float scale; int gelu;
@@ -440,7 +454,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
                 if (sg.has_scale) v = v * sg.scale;
                 if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
                 if (sg.residual)  v = v + *(const float *) ((const char *) sg.residual + (int64_t) j8*sg.res_nb1 + (int64_t) row*4);
-                char * dp = (char *) sg.dst + *sg.dst_off + (int64_t) j8*sg.dst_nb1;
+                char * dp = (char *) sg.dst + step_load(sg.dst_off) + (int64_t) j8*sg.dst_nb1;
                 if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
             }
             #pragma unroll
@@ -525,8 +539,8 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     sg.w = sgr.w; sg.nbt = sgr.nbt; sg.bias = sgr.bias; sg.residual = sgr.residual; sg.res_nb1 = sgr.res_nb1;
     sg.dst = sgr.dst; sg.dst_nb1 = sgr.dst_nb1; sg.scale = sgr.scale; sg.has_scale = sgr.has_scale; sg.gelu = sgr.gelu; sg.dst_f16 = sgr.dst_f16;
     sg.dst_off = sgr.dst_off;
-    // this step's write position in the KV cache (a scalar load behind the kernarg batch, consumed only by the final store)
-    const int64_t dst_off = *sg.dst_off;
+    // this step's write position in the KV cache (issued with the first loads, consumed only by the final store)
+    const int64_t dst_off = step_load(sg.dst_off);
     asm volatile("" :: "s"(sg.w), "s"(sg.nbt), "s"(sg.bias), "s"(sg.residual), "s"(sg.res_nb1), "s"(sg.dst), "s"(sg.dst_nb1),
                        "s"(sg.scale), "s"(sg.has_scale), "s"(sg.gelu), "s"(sg.dst_f16), "s"(a.gelu_tab),
                        "s"(a.x), "s"(a.x_nb1), "s"(a.ln_w), "s"(a.ln_b), "s"(a.part_o), "s"(a.part_ml), "s"(a.nparts), "s"(a.eps));
@@ -1079,8 +1093,8 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     const int kbeg = p*128 + wave*32;
     // live key count: by value, or this step's value from the step block (the scalar load is issued here and only consumed by
     // the mask addresses and the score masking below, so the K / V request burst does not wait for it)
-    const int64_t nkv_s = *a.nkv_ptr;
-    const int n_kv = a.nkv_from_step ? (int) nkv_s : a.n_kv;
+    const int nkv_s = step_load32(a.nkv_ptr);
+    const int n_kv = a.nkv_from_step ? nkv_s : a.n_kv;
     const int n_safe = a.n_kv_safe;
 
     // all K and V rows of this wave are requested up front: 8 x 16 B per lane in flight
@@ -1094,6 +1108,7 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
         kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k.nb[1]);
         vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v.nb[1]);
     }
+    __builtin_amdgcn_sched_barrier(0);          // the K / V burst is issued before anything that has to wait for the live key count
     // q (rounded to f16 like the CPU's q_to_vec_dot), this lane's 8 dims of every query
     float qf[T][8];
     #pragma unroll
