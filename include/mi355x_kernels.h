@@ -299,6 +299,15 @@ MI355X_API int mi355x_debug_read_stamps(mi355x_ctx * ctx, unsigned long long * o
 /* wide empty launch on `stream` (hipStream_t): wakes the whole chip ahead of the first real dispatch of a decode step */
 MI355X_API int mi355x_wake(void * stream, int nblocks);
 
+/* whisper's log-mel front end (log_mel_spectrogram, src/whisper.cpp:3046-3283; whisper_pcm_to_mel :3901) for PCM resident in HBM:
+ * pcm_dev f32 [n_samples] (16 kHz, [-1, 1]), filters_dev f32 [n_mel][201] (the model file's filterbank, whisper_filters), mel_dev f32
+ * [n_mel][n_len] with n_len = mi355x_log_mel_n_len(n_samples) = (n_samples + 30 s) / 160 — exactly the layout whisper_set_mel takes
+ * (data[j * n_len + i], src/whisper.cpp:2406).  Reflective 200-sample padding in front, 30 s of zeros behind, Hann 400 / hop 160,
+ * power spectrum, filterbank (f64 sums), log10, clamp to (max - 8), (x + 4) / 4.  Runs on the context's stream. */
+MI355X_API int mi355x_log_mel_n_len(int n_samples);
+MI355X_API int mi355x_log_mel(mi355x_ctx * ctx, const float * pcm_dev, int n_samples, const float * filters_dev, int n_mel, int n_fft_bins /* 201 */,
+                              float * mel_dev, int n_len);
+
 /* order-independent 128-bit checksum of a device range on `stream` (hipStream_t): out[0] = sum of the 64-bit words, out[1] = sum of
  * word * (2*index + 1), mod 2^64; dev_out16 is 16 bytes of DEVICE memory.  Used to verify that every replica's weight buffers equal
  * rank 0's after the one-time broadcast. */

@@ -659,3 +659,88 @@ void oracle_flash_attn_ext(const float * q, const uint16_t * k, const uint16_t *
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * log-mel front end: whisper's log_mel_spectrogram (src/whisper.cpp:3046-3283) — reflective 200-sample pad in front, 30 s of
+ * zeros behind, Hann window 400 (periodic, :3031-3039), hop 160, the recursive radix-2 FFT that ends in 25-point DFTs
+ * (:3046-3111, sin / cos table of 400 entries made with sinf / cosf :3022-3028), power spectrum, filterbank with f64 sums in
+ * groups of four (:3141-3158), log10, clamp to (max - 8), (x + 4) / 4.  out[j * n_len + i]; n_len = (n + 480000) / 160.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static float mel_sin[400], mel_cos[400], mel_hann[400];
+static int mel_tab_ready = 0;
+static void mel_tables(void) {
+    if (mel_tab_ready) return;
+    for (int i = 0; i < 400; i++) {
+        const double theta = (2 * M_PI * i) / 400;
+        mel_sin[i] = sinf((float) theta); mel_cos[i] = cosf((float) theta);
+        mel_hann[i] = (float) (0.5 * (1.0 - cosf((float) ((2.0 * M_PI * i) / 400))));
+    }
+    mel_tab_ready = 1;
+}
+static void mel_dft(const float * in, int N, float * out) {
+    const int step = 400 / N;
+    for (int k = 0; k < N; k++) {
+        float re = 0, im = 0;
+        for (int n = 0; n < N; n++) { const int idx = (k * n * step) % 400; re += in[n]*mel_cos[idx]; im -= in[n]*mel_sin[idx]; }
+        out[k*2 + 0] = re; out[k*2 + 1] = im;
+    }
+}
+static void mel_fft(float * in, int N, float * out) {
+    if (N == 1) { out[0] = in[0]; out[1] = 0; return; }
+    const int h = N / 2;
+    if (N - h*2 == 1) { mel_dft(in, N, out); return; }
+    float * even = in + N;
+    for (int i = 0; i < h; i++) even[i] = in[2*i];
+    float * even_fft = out + 2*N;
+    mel_fft(even, h, even_fft);
+    float * odd = even;
+    for (int i = 0; i < h; i++) odd[i] = in[2*i + 1];
+    float * odd_fft = even_fft + N;
+    mel_fft(odd, h, odd_fft);
+    const int step = 400 / N;
+    for (int k = 0; k < h; k++) {
+        const int idx = k * step;
+        const float re = mel_cos[idx], im = -mel_sin[idx];
+        const float ro = odd_fft[2*k], io = odd_fft[2*k + 1];
+        out[2*k]           = even_fft[2*k]     + re*ro - im*io;
+        out[2*k + 1]       = even_fft[2*k + 1] + re*io + im*ro;
+        out[2*(k + h)]     = even_fft[2*k]     - re*ro + im*io;
+        out[2*(k + h) + 1] = even_fft[2*k + 1] - re*io - im*ro;
+    }
+}
+int64_t oracle_log_mel_n_len(int64_t n_samples) { return (n_samples + 480000) / 160; }
+void oracle_log_mel(const float * pcm, int64_t n, const float * filters, int64_t n_mel, float * out) {
+    mel_tables();
+    const int N = 400, step = 160, bins = 201;
+    const int64_t total = n + 480000 + 400, n_len = (total - N) / step;
+    float * pad = (float *) calloc((size_t) total, sizeof(float));
+    memcpy(pad + 200, pcm, (size_t) n * sizeof(float));
+    const int64_t nref = n - 1 < 200 ? (n - 1 < 0 ? 0 : n - 1) : 200;
+    for (int64_t k = 1; k <= nref; k++) pad[200 - k] = pcm[k];                      /* reverse_copy(samples + 1, ...) */
+    const int64_t ns = n + 200;                                                    /* the worker's n_samples */
+    const int64_t live = ns / step + 1 < n_len ? ns / step + 1 : n_len;
+    float * fin = (float *) calloc(2 * N, sizeof(float)), * fout = (float *) calloc(8 * N, sizeof(float));
+    double * tmp = (double *) malloc((size_t) n_mel * n_len * sizeof(double));
+    for (int64_t i = 0; i < n_len; i++) {
+        if (i >= live) { for (int64_t j = 0; j < n_mel; j++) tmp[j*n_len + i] = log10(1e-10); continue; }
+        const int64_t off = i * step;
+        const int64_t m = N < ns - off ? N : ns - off;
+        for (int64_t j = 0; j < m; j++) fin[j] = mel_hann[j] * pad[off + j];
+        for (int64_t j = m < 0 ? 0 : m; j < 2*N; j++) fin[j] = 0.0f;
+        mel_fft(fin, N, fout);
+        for (int j = 0; j < bins; j++) fout[j] = fout[2*j]*fout[2*j] + fout[2*j + 1]*fout[2*j + 1];
+        for (int64_t j = 0; j < n_mel; j++) {
+            const float * f = filters + j * bins;
+            double sum = 0.0; int k = 0;
+            for (; k < bins - 3; k += 4) sum += fout[k]*f[k] + fout[k + 1]*f[k + 1] + fout[k + 2]*f[k + 2] + fout[k + 3]*f[k + 3];
+            for (; k < bins; k++) sum += fout[k]*f[k];
+            sum = log10(sum > 1e-10 ? sum : 1e-10);
+            tmp[j*n_len + i] = (double) (float) sum;                              /* mel.data is float */
+        }
+    }
+    double mmax = -1e20;
+    for (int64_t i = 0; i < n_mel*n_len; i++) if (tmp[i] > mmax) mmax = tmp[i];
+    mmax -= 8.0;
+    for (int64_t i = 0; i < n_mel*n_len; i++) { double v = tmp[i] < mmax ? mmax : tmp[i]; out[i] = (float) ((v + 4.0) / 4.0); }
+    free(pad); free(fin); free(fout); free(tmp);
+}

@@ -70,6 +70,12 @@ void  oracle_flash_attn_ext(const float * q, const uint16_t * k, const uint16_t 
                             int64_t D, int64_t T, int64_t H, int64_t n_kv, float scale, int nth);
 float oracle_v_expf(float x);
 
+/* whisper's log-mel front end (log_mel_spectrogram, src/whisper.cpp:3046-3283) incl. its recursive FFT; pcm f32 [n] at 16 kHz,
+ * filters f32 [n_mel][201], out f32 [n_mel][n_len], n_len = oracle_log_mel_n_len(n).  Pinned against the reference's own
+ * front end run on samples/jfk.wav (tests/golden/mel.npz, made by tests/golden/make_golden.py through oracle/_ref/mel_ref). */
+int64_t oracle_log_mel_n_len(int64_t n_samples);
+void    oracle_log_mel(const float * pcm, int64_t n, const float * filters, int64_t n_mel, float * out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,9 @@ def oracle():
     L.oracle_rope.argtypes = [vp, vp, vp, i64, i64, i64, i32, i32, i32, f32, f32, f32, f32, f32, f32]
     L.oracle_flash_attn.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32]
     L.oracle_flash_attn_ext.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, f32, i32]
+    L.oracle_log_mel_n_len.argtypes = [i64]
+    L.oracle_log_mel_n_len.restype = i64
+    L.oracle_log_mel.argtypes = [vp, i64, vp, i64, vp]
     L.oracle_v_expf.argtypes = [f32]
     L.oracle_v_expf.restype = f32
     return L

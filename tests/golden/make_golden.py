@@ -91,6 +91,35 @@ def blocks_npz():
     print("blocks.npz:", sorted(out))
 
 
+def mel_npz():
+    """the reference's own log-mel front end on real speech: samples/jfk.wav (11 s, 16 kHz mono, the file the north star names) with
+    the real 80-band filterbank of models/for-tests-ggml-base.en.bin, through oracle/_ref/mel_ref (which includes the reference's
+    src/whisper.cpp in place).  Stored: the PCM (int16), the filterbank, the mel up to the last frame that sees audio + its tail value."""
+    import struct
+    import wave
+    ref = Path(os.environ.get("WHISPER_REF", "/root/reference"))
+    w = wave.open(str(ref / "samples" / "jfk.wav"))
+    assert w.getframerate() == 16000 and w.getnchannels() == 1 and w.getsampwidth() == 2
+    pcm16 = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2")
+    model = ref / "models" / "for-tests-ggml-base.en.bin"
+    with open(model, "rb") as f:
+        f.read(4 + 44)
+        nm, nf = struct.unpack("ii", f.read(8))
+        filt = np.frombuffer(f.read(nm * nf * 4), dtype=np.float32).reshape(nm, nf).copy()
+    with tempfile.TemporaryDirectory() as d:
+        (pcm16.astype(np.float32) / 32768.0).tofile(Path(d) / "pcm.f32")          # the conversion whisper-cli applies (examples/common-whisper.cpp)
+        subprocess.run([str(REF / "mel_ref"), str(model), str(Path(d) / "pcm.f32"), str(Path(d) / "mel.bin"), "4"], check=True, stderr=subprocess.DEVNULL)
+        raw = (Path(d) / "mel.bin").read_bytes()
+    n_mel, n_len, n_org = struct.unpack("iii", raw[:12])
+    mel = np.frombuffer(raw[12:], dtype=np.float32).reshape(n_mel, n_len)
+    keep = 1104
+    assert np.all(mel[:, keep:] == mel[0, -1])
+    np.savez_compressed(HERE / "mel.npz", pcm16=pcm16, filters=filt, mel_head=mel[:, :keep].copy(), tail_value=np.float32(mel[0, -1]),
+                        n_len=np.int32(n_len), n_len_org=np.int32(n_org))
+    print("mel.npz:", n_mel, n_len, n_org, "tail", mel[0, -1])
+
+
 if __name__ == "__main__":
     ops_npz()
     blocks_npz()
+    mel_npz()

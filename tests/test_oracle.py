@@ -231,3 +231,27 @@ def test_v_expf_lane(oracle):
     got = np.array([oracle.oracle_v_expf(float(x)) for x in xs], dtype=np.float32)
     ref = np.exp(xs.astype(np.float64))
     assert np.max(np.abs(got - ref) / ref) < 3 * 2.0 ** -24
+
+
+def _mel_golden():
+    z = np.load(G / "mel.npz")
+    n_len = int(z["n_len"])
+    mel = np.full((z["filters"].shape[0], n_len), z["tail_value"], dtype=np.float32)
+    mel[:, :z["mel_head"].shape[1]] = z["mel_head"]
+    return z, mel
+
+
+def test_log_mel_matches_the_reference_front_end_on_real_speech(oracle):
+    """oracle_log_mel (recursive FFT and all) against whisper's own log_mel_spectrogram run on samples/jfk.wav with the real 80-band
+    filterbank (golden generated through oracle/_ref/mel_ref).  The reference build contracts a*b + c*d chains of its butterflies
+    into fmas (-ffp-contract=fast), the oracle is compiled without contraction: agreement to a few f32 roundings of the spectrum."""
+    z, want = _mel_golden()
+    pcm = (z["pcm16"].astype(np.float32) / 32768.0)
+    filt = np.ascontiguousarray(z["filters"])
+    n_len = oracle.oracle_log_mel_n_len(len(pcm))
+    assert n_len == want.shape[1] == 4100 and int(z["n_len_org"]) == 1099
+    out = np.zeros((filt.shape[0], n_len), dtype=np.float32)
+    oracle.oracle_log_mel(ptr(pcm), len(pcm), ptr(filt), filt.shape[0], ptr(out))
+    assert np.abs(out - want).max() < 2e-5, np.abs(out - want).max()
+    assert nmse(want, out) < 1e-12
+    assert np.array_equal(out[:, 1104:], want[:, 1104:])        # frames no sample reaches: the clamped floor, exactly

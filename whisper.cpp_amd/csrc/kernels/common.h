@@ -39,6 +39,7 @@ struct mi355x_ctx {
     int64_t *   step_dev = nullptr;
     int64_t     step_host[MI355X_STEP_SLOTS] = { 0 };
     bool        step_armed = false;      // the next mi355x_get_rows_add launch publishes slots 1..3
+    float *     mel_tab = nullptr;       // sin / cos / Hann tables + the running maximum of mi355x_log_mel (device)
     // recording
     bool                        recording = false;
     bool                        record_invalid = false;
@@ -56,6 +57,7 @@ struct mi355x_ctx {
 void * mi355x_debug_stamps(mi355x_ctx * ctx);
 
 void   mi355x_set_error(const char * fmt, ...);
+#define HIP_CHECK_RET(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mi355x_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return (int) e_; } } while (0)
 // scratch: returns a device pointer valid until the NEXT mi355x_scratch_reset on this ctx
 void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes);
 void   mi355x_scratch_reset(mi355x_ctx * ctx);

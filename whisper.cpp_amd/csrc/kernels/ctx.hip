@@ -81,6 +81,7 @@ extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
     for (void * r : ctx->scratch_retired) (void) hipFree(r);
     if (ctx->gelu_tab) (void) hipFree(ctx->gelu_tab);
     if (ctx->step_dev) (void) hipFree(ctx->step_dev);
+    if (ctx->mel_tab)  (void) hipFree(ctx->mel_tab);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -23,7 +23,7 @@ SYMBOLS = [
     "mi355x_prof_reset", "mi355x_type_is_quantized", "mi355x_type_row_bytes", "mi355x_repack_to_planar",
     "mi355x_repack_from_planar", "mi355x_mul_mat", "mi355x_prep_act", "mi355x_gemm_f16act", "mi355x_dequant_f16", "mi355x_gemv_fused",
     "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_partial_step", "mi355x_flash_attn_combine", "mi355x_step_set", "mi355x_step_device", "mi355x_step_host", "mi355x_step_upload", "mi355x_step_arm", "mi355x_step_armed", "mi355x_ln_q_attn_partial", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
-    "mi355x_get_rows", "mi355x_get_rows_add", "mi355x_im2col_1d", "mi355x_soft_max", "mi355x_rope", "mi355x_concat", "mi355x_memset", "mi355x_checksum", "mi355x_debug_read_stamps", "mi355x_wake",
+    "mi355x_get_rows", "mi355x_get_rows_add", "mi355x_im2col_1d", "mi355x_soft_max", "mi355x_rope", "mi355x_concat", "mi355x_memset", "mi355x_checksum", "mi355x_log_mel", "mi355x_log_mel_n_len", "mi355x_debug_read_stamps", "mi355x_wake",
 ]
 
 
@@ -114,6 +114,8 @@ def lib() -> C.CDLL:
         L.mi355x_rope.argtypes = [C.c_void_p, TP, TP, C.c_void_p, TP, C.POINTER(RopeParams)]
         L.mi355x_concat.argtypes = [C.c_void_p, TP, TP, TP, C.c_int]
         L.mi355x_checksum.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.mi355x_log_mel_n_len.argtypes = [C.c_int]
+        L.mi355x_log_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.mi355x_memset.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]
         L.mi355x_debug_read_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
