@@ -944,3 +944,23 @@ def test_gpu_log_mel_matches_the_reference_front_end_on_real_speech(gpu, oracle)
     print(f"mi355x_log_mel: 30 s chunk, 128 bands: {dt * 1e3:.3f} ms (reference CPU front end: ~16 ms on 4 threads)")
     assert np.abs(o2.cpu().numpy() - ref).max() < 1e-4
     assert dt < 5e-3
+
+
+@pytest.mark.parametrize("arch,qtype", [("large-v3-2l", "q8_0"), ("large-v3-turbo", "q8_0")])
+def test_language_detection_through_the_plugin(plugin_env, arch, qtype):
+    """whisper_lang_auto_detect (src/whisper.cpp:4047-4121: encode, decode the SOT token, softmax over the 100
+    language tokens) on a multilingual model, reference CPU backend vs plugin: same language, probability vector within 2e-2
+    absolute (the logits differ at the reference's one-ulp floor, TOL_SINGLE; the probabilities of a random-weight model are
+    spread over many languages, so the top-2 gap is stated and the argmax must agree unless that gap is below the difference)."""
+    from synth_model import make_model
+    m = make_model(arch, qtype)
+    env = dict(plugin_env, GGML_MI355X_STRICT="1")
+    r = subprocess.run([str(_native("lang_detect")), str(m)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    keep = ROOT / "gpurun_out"
+    if keep.exists():
+        (keep / f"lang_detect_{arch}_{qtype}.json").write_text(r.stdout)
+    assert d["n_lang"] == 100 and abs(d["sum_gpu"] - 1.0) < 1e-4
+    assert d["max_abs_prob_diff"] < 2e-2, d
+    assert d["id_cpu"] == d["id_gpu"] or (d["p_top_cpu"] - d["p_second_cpu"]) < 2 * d["max_abs_prob_diff"], d
