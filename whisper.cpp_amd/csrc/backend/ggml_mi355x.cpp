@@ -1109,7 +1109,11 @@ static void mi_backend_synchronize(ggml_backend_t backend) {
 // that can be folded away.  Anything unexpected simply leaves the step block unused: the by-value paths are always correct.
 static void mi_prescan_step(mi_backend_ctx * b, const ggml_cgraph * g) {
     b->step_on = false; b->mask_cast = nullptr; b->mask_cast_done = false;
-    static const bool enabled = env_flag("GGML_MI355X_STEP_BLOCK", true);
+    // Measured on large-v3 Q5_0 (profiles/r02_step_block_sweep.txt): patched nodes per step 64 -> 2 and host patch time 22.7 -> 1.9 ms
+    // per chunk as intended, but the decode step got SLOWER, 1.547 -> 1.583 ms/token (GPU span 329 -> 336 ms per chunk): the host's
+    // patching was already hidden behind the previous graph segment, while every self-attention and K/V-store kernel now starts with
+    // one more dependent memory round trip.  Kept as an opt-in (kernel-level tests keep it honest), off by default.
+    static const bool enabled = env_flag("GGML_MI355X_STEP_BLOCK", false);
     if (!enabled || !b->fuse || b->exact || b->prof) return;
     int first = 0;
     while (first < g->n_nodes && (op_is_empty(g->nodes[first]) || !(g->nodes[first]->flags & GGML_TENSOR_FLAG_COMPUTE))) first++;
