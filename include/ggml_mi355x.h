@@ -69,17 +69,33 @@ GGML_MI355X_API void ggml_backend_mi355x_stats(uint64_t * out);
  * eager launches}; [4..7] milliseconds inside {set_tensor, get_tensor, cpy_tensor, synchronize}; [8..11] their call counts */
 GGML_MI355X_API void ggml_backend_mi355x_host_times(double * out);
 
-/* Multi-GPU weight distribution: device-to-device copy of every WEIGHTS buffer allocated on
- * `src_device` into the identically laid out buffers on `dst_device` of the same process (xGMI peer copy).
- * Across processes the same buffers are broadcast with RCCL by the host harness through
- * ggml_backend_mi355x_weight_buffers (base pointers + sizes in allocation order). */
-GGML_MI355X_API int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap);
+/* Multi-GPU weight distribution.  Replicas are independent streams: the only exchange is the ONE-TIME copy of
+ * rank 0's WEIGHTS buffers into the identically laid out buffers of the other replicas (every context allocates the same tensors in
+ * the same order, src/whisper.cpp:1685-1859; buffer counts and sizes are compared first).  The reference has no such call site: it
+ * re-reads the model file and uploads tensor by tensor for every context (src/whisper.cpp:1934-1938).
+ *   ggml_backend_mi355x_broadcast_weights_peer   one process, several devices: hipMemcpyPeerAsync over xGMI, then checksums
+ *   ggml_backend_mi355x_rccl_unique_id           rank 0 of a multi-process job: 128-byte id for the host harness to hand to every rank
+ *   ggml_backend_mi355x_broadcast_weights_rccl   one process per device: RCCL communicator from that id (librccl.so is dlopen()ed),
+ *                                                ncclBroadcast of every buffer from rank 0, device-side checksums compared across ranks
+ *   ggml_backend_mi355x_weights_checksum         {sum, index-weighted sum} mod 2^64 of every WEIGHTS buffer (mi355x_checksum)
+ *   ggml_backend_mi355x_defer_weights            while on, set_tensor of weight tensors is skipped (they arrive by broadcast)
+ *   ggml_backend_mi355x_weight_buffers           base pointers + sizes in allocation order (for harnesses with their own transport)
+ * stats[0..3] = bytes moved, seconds, buffers, verified (1: every destination buffer's checksum equals the source's).  Return 0 on
+ * success; -1 transport unavailable / failed, -2 layout differs between replicas, -3 copy failed, -4 checksum mismatch. */
+GGML_MI355X_API int  ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap);
+GGML_MI355X_API int  ggml_backend_mi355x_weights_checksum(int device, uint64_t * out_pairs, int cap);
+GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, double * stats4);
+GGML_MI355X_API int  ggml_backend_mi355x_rccl_unique_id(void * out128);
+GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, const void * unique_id128, double * stats4);
+GGML_MI355X_API void ggml_backend_mi355x_defer_weights(int on);
 
 /* Runtime switches (environment):
  *   GGML_MI355X_FUSE=0       run every ggml node as its own kernel (debug / parity bisect)
  *   GGML_MI355X_GRAPHS=0     do not build / replay hipGraphs
  *   GGML_MI355X_DEBUG=1      log unsupported ops and kernel-library errors to stderr
  *   GGML_MI355X_STRICT=1     abort instead of letting the scheduler fall back to the CPU backend for an unsupported op
+ *   GGML_MI355X_STEP_BLOCK=1 decoder graphs take the live key count / KV write offset from device memory (zero node patches per step;
+ *                            measured slower than patching) — off by default
  *   GGML_MI355X_EXACT=1      reference-exact arithmetic (test mode, slow): flash attention as the CPU dispatcher computes it
  *                            (F16 accumulation / split over n_threads / F32 tiles), integer block dots for every column count
  */

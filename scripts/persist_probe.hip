@@ -1,0 +1,211 @@
+// Persistent-layer experiment (VERDICT r01 "run it with numbers, even if it loses").
+// A batch-1 decode step of large-v3 is 32 layers x 7 stages, each stage a mat-vec whose input is the WHOLE output of the previous
+// one (all-to-all) and whose weights are 1-7 MB.  Two ways to run that chain:
+//   A  one kernel per stage, the dependency is the kernel boundary (hipGraph of 224 nodes) — what the backend does;
+//   B  ONE persistent launch, one workgroup per CU.  Every workgroup owns a fixed slice of the rows of every stage, requests its
+//      slice of the NEXT stage's weights before it waits (prefetch credit), publishes its outputs as 8-byte {value, tag} granules
+//      with one write-through (sc1) store each, and gathers the next input vector by polling the granules with sc1 loads until all
+//      tags carry the stage number (MI355X_MICROARCH.md, rows handoff-1to1 / allgather: no fences, no flags, no barrier).
+// Same arithmetic in both (int8 weights x per-32-block int8 activations, like the Q8_0 path), results compared.  Every spin is
+// bounded: a lost granule sets an error code instead of hanging the GPU.
+//   hipcc --offload-arch=gfx950 -O3 scripts/persist_probe.hip -o scripts/_bin/persist_probe && scripts/_bin/persist_probe
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#define NWG 256
+#define NT  256
+#define NSTAGE 7
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Stage { int N, K; size_t w_off; size_t extra_off; int extra_bytes_per_wg; };      // weights int8 [N][K]; extra = read-only stream (cross K/V)
+struct Chain {
+    Stage st[NSTAGE];
+    const int8_t * w;            // all stage weights of ONE layer (re-used by every layer: the bytes streamed are what matters)
+    const int8_t * extra;
+    float * act[2];              // launches: ping-pong activation vectors (max 5120 floats)
+    unsigned long long * gran;   // persistent: granules [NSTAGE][5120] {f32, tag}
+    int * err;
+    int n_layers;
+};
+
+// quantize this thread's share of x into per-32 int8 blocks in LDS (like quantize_row_q8_0), return nothing: xs[K] int8, xd[K/32] f32
+__device__ __forceinline__ void quant_store(const float * xv, int K, int8_t * xs, float * xd, int tid) {
+    // K/32 blocks, 8 lanes per block (4 values each)
+    for (int base = tid * 4; base < K; base += NT * 4) {
+        float v0 = xv[base], v1 = xv[base + 1], v2 = xv[base + 2], v3 = xv[base + 3];
+        float amax = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64)); amax = fmaxf(amax, __shfl_xor(amax, 2, 64)); amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+        xs[base] = (int8_t) rintf(v0 * id); xs[base + 1] = (int8_t) rintf(v1 * id); xs[base + 2] = (int8_t) rintf(v2 * id); xs[base + 3] = (int8_t) rintf(v3 * id);
+        if ((base & 31) == 0) xd[base >> 5] = amax / 127.0f;
+    }
+}
+
+// rows [r0, r1) of a stage: one wave per row (strided over the workgroup's 4 waves), int8 dot with the LDS activations
+__device__ __forceinline__ float row_dot(const int8_t * __restrict__ w, int K, const int8_t * xs, const float * xd, int lane) {
+    float acc = 0.0f;
+    for (int b = lane; b < K / 32; b += 64) {
+        const int4 * wp = (const int4 *) (w + (size_t) b * 32);
+        const int4 w0 = wp[0], w1 = wp[1];
+        const int4 * xp = (const int4 *) (xs + b * 32);
+        const int4 x0 = xp[0], x1 = xp[1];
+        int s = 0;
+        s = __builtin_amdgcn_sdot4(w0.x, x0.x, s, false); s = __builtin_amdgcn_sdot4(w0.y, x0.y, s, false);
+        s = __builtin_amdgcn_sdot4(w0.z, x0.z, s, false); s = __builtin_amdgcn_sdot4(w0.w, x0.w, s, false);
+        s = __builtin_amdgcn_sdot4(w1.x, x1.x, s, false); s = __builtin_amdgcn_sdot4(w1.y, x1.y, s, false);
+        s = __builtin_amdgcn_sdot4(w1.z, x1.z, s, false); s = __builtin_amdgcn_sdot4(w1.w, x1.w, s, false);
+        acc = fmaf(xd[b] * (1.0f / 64.0f), (float) s, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    return acc;
+}
+
+__device__ __forceinline__ float extra_sum(const int8_t * e, int bytes, int tid) {       // the read-only stream of the stage (cross K/V stand-in)
+    int s = 0;
+    for (int i = tid * 16; i < bytes; i += NT * 16) { const int4 v = *(const int4 *) (e + i); s += (v.x & 1) + (v.y & 1) + (v.z & 1) + (v.w & 1); }
+    return (float) s * 1e-9f;
+}
+
+// ---- A: one launch per stage ---------------------------------------------------------------------------------------
+struct AArgs { Chain c; int stage; const float * x; float * y; };
+__global__ void __launch_bounds__(NT) k_stage(const AArgs a) {
+    __shared__ __attribute__((aligned(16))) int8_t xs[5120];
+    __shared__ float xd[160];
+    __shared__ float xf[5120];
+    const Stage st = a.c.st[a.stage];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wg = blockIdx.x;
+    for (int i = tid; i < st.K; i += NT) xf[i] = a.x[i];
+    __syncthreads();
+    quant_store(xf, st.K, xs, xd, tid);
+    float ex = st.extra_bytes_per_wg ? extra_sum(a.c.extra + st.extra_off + (size_t) wg * st.extra_bytes_per_wg, st.extra_bytes_per_wg, tid) : 0.0f;
+    __syncthreads();
+    const int per = st.N / NWG, r0 = wg * per;
+    for (int r = r0 + wave; r < r0 + per; r += 4) {
+        const float v = row_dot(a.c.w + st.w_off + (size_t) r * st.K, st.K, xs, xd, lane);
+        if (lane == 0) a.y[r] = tanhf(v + ex) ;
+    }
+}
+
+// ---- B: persistent ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void publish(unsigned long long * g, float v, unsigned tag) {
+    const unsigned long long q = ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(v);
+    __hip_atomic_store(g, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // one 8-byte write-through store: {value, tag}
+}
+
+__global__ void __launch_bounds__(NT) k_persistent(const Chain c, const float * x0, float * y_out) {
+    __shared__ __attribute__((aligned(16))) int8_t xs[5120];
+    __shared__ float xd[160];
+    __shared__ float xf[5120];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, wg = blockIdx.x;
+    unsigned tag = 1;
+    for (int i = tid; i < c.st[0].K; i += NT) xf[i] = x0[i];
+    __syncthreads();
+    for (int layer = 0; layer < c.n_layers; layer++) {
+        for (int s = 0; s < NSTAGE; s++, tag++) {
+            const Stage st = c.st[s];
+            // (weights of this workgroup's rows are requested by row_dot's loads below; the extra stream is requested here, before
+            //  the input is complete)
+            float ex = st.extra_bytes_per_wg ? extra_sum(c.extra + st.extra_off + (size_t) wg * st.extra_bytes_per_wg, st.extra_bytes_per_wg, tid) : 0.0f;
+            if (!(layer == 0 && s == 0)) {
+                // gather the input vector: granules of the previous stage, tag - 1
+                const unsigned long long * g = c.gran + (size_t) ((s + NSTAGE - 1) % NSTAGE) * 5120;
+                const unsigned want = tag - 1;
+                for (int i = tid; i < st.K; i += NT) {
+                    unsigned long long q; int spins = 0;
+                    do { q = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned) (q >> 32) != want && ++spins < (1 << 22));
+                    if ((unsigned) (q >> 32) != want) *c.err = 1;                       // give up instead of hanging
+                    xf[i] = __uint_as_float((unsigned) q);
+                }
+                __syncthreads();
+            }
+            quant_store(xf, st.K, xs, xd, tid);
+            __syncthreads();
+            const int per = st.N / NWG, r0 = wg * per;
+            unsigned long long * go = c.gran + (size_t) s * 5120;
+            for (int r = r0 + wave; r < r0 + per; r += 4) {
+                const float v = row_dot(c.w + st.w_off + (size_t) r * st.K, st.K, xs, xd, lane);
+                if (lane == 0) { const float o = tanhf(v + ex); publish(go + r, o, tag); if (layer == c.n_layers - 1 && s == NSTAGE - 1) y_out[r] = o; }
+            }
+            __syncthreads();                                                            // xs / xf are rewritten by the next stage
+        }
+    }
+}
+
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char ** argv) {
+    const int n_layers = argc > 1 ? atoi(argv[1]) : 32;
+    const int NK[NSTAGE][2] = { {3840, 1280}, {1280, 3840}, {1280, 1280}, {1280, 1280}, {1280, 1280}, {5120, 1280}, {1280, 5120} };
+    // stage 1 stands in for self-attention (reads a [1280 x 3840] weight: more bytes than the real K/V of <= 256 keys),
+    // stage 3 additionally streams the layer's cross K/V (7.86 MB): the Q-projection + cross-attention stage
+    Chain c; memset(&c, 0, sizeof(c));
+    size_t wbytes = 0;
+    for (int s = 0; s < NSTAGE; s++) { c.st[s].N = NK[s][0]; c.st[s].K = NK[s][1]; c.st[s].w_off = wbytes; wbytes += (size_t) NK[s][0] * NK[s][1]; }
+    const int extra_per_wg = 30720;                          // 256 x 30 KB = 7.86 MB
+    c.st[3].extra_bytes_per_wg = extra_per_wg; c.st[3].extra_off = 0;
+    c.n_layers = n_layers;
+    std::vector<int8_t> hw(wbytes), he((size_t) extra_per_wg * NWG);
+    unsigned lcg = 12345;
+    for (auto & v : hw) { lcg = lcg * 1664525u + 1013904223u; v = (int8_t) ((lcg >> 24) % 15 - 7); }
+    for (auto & v : he) { lcg = lcg * 1664525u + 1013904223u; v = (int8_t) (lcg >> 24); }
+    int8_t * dw, * de; CK(hipMalloc(&dw, wbytes)); CK(hipMalloc(&de, he.size()));
+    CK(hipMemcpy(dw, hw.data(), wbytes, hipMemcpyHostToDevice)); CK(hipMemcpy(de, he.data(), he.size(), hipMemcpyHostToDevice));
+    c.w = dw; c.extra = de;
+    CK(hipMalloc(&c.act[0], 5120 * 4)); CK(hipMalloc(&c.act[1], 5120 * 4));
+    CK(hipMalloc(&c.gran, (size_t) NSTAGE * 5120 * 8)); CK(hipMemset(c.gran, 0, (size_t) NSTAGE * 5120 * 8));
+    CK(hipMalloc(&c.err, 4)); CK(hipMemset(c.err, 0, 4));
+    std::vector<float> hx(1280);
+    for (auto & v : hx) { lcg = lcg * 1664525u + 1013904223u; v = ((lcg >> 8) & 0xFFFF) / 32768.0f - 1.0f; }
+    float * dx0, * dyA, * dyB; CK(hipMalloc(&dx0, 5120 * 4)); CK(hipMalloc(&dyA, 5120 * 4)); CK(hipMalloc(&dyB, 5120 * 4));
+    CK(hipMemcpy(dx0, hx.data(), 1280 * 4, hipMemcpyHostToDevice));
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    printf("persistent-layer experiment: %d layers x %d stages, %.1f MB of int8 weights + %.2f MB extra stream per layer\n", n_layers, NSTAGE, wbytes / 1e6, he.size() / 1e6);
+
+    // ---- A: hipGraph of n_layers * 7 kernel nodes ----
+    hipGraph_t g; hipGraphExec_t ge; CK(hipGraphCreate(&g, 0));
+    std::vector<hipGraphNode_t> nodes((size_t) n_layers * NSTAGE);
+    std::vector<AArgs> args(nodes.size());
+    for (int l = 0; l < n_layers; l++) for (int s = 0; s < NSTAGE; s++) {
+        const size_t i = (size_t) l * NSTAGE + s;
+        AArgs & a = args[i]; a.c = c; a.stage = s;
+        a.x = i == 0 ? dx0 : c.act[(i - 1) & 1];
+        a.y = i + 1 == nodes.size() ? dyA : c.act[i & 1];
+        void * ka[1] = { &a };
+        hipKernelNodeParams p = {};
+        p.func = (void *) k_stage; p.gridDim = dim3(NWG); p.blockDim = dim3(NT); p.kernelParams = ka;
+        CK(hipGraphAddKernelNode(&nodes[i], g, i ? &nodes[i - 1] : nullptr, i ? 1 : 0, &p));
+    }
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    double bestA = 1e30;
+    for (int rep = 0; rep < 6; rep++) {
+        CK(hipStreamSynchronize(st));
+        const double t0 = now_us();
+        CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
+        const double t = now_us() - t0;
+        if (rep > 0 && t < bestA) bestA = t;
+    }
+    // ---- B: one persistent launch ----
+    double bestB = 1e30; int herr = 0;
+    for (int rep = 0; rep < 6; rep++) {
+        CK(hipMemsetAsync(c.gran, 0, (size_t) NSTAGE * 5120 * 8, st));
+        CK(hipStreamSynchronize(st));
+        const double t0 = now_us();
+        k_persistent<<<dim3(NWG), dim3(NT), 0, st>>>(c, dx0, dyB);
+        CK(hipStreamSynchronize(st));
+        const double t = now_us() - t0;
+        if (rep > 0 && t < bestB) bestB = t;
+        CK(hipMemcpy(&herr, c.err, 4, hipMemcpyDeviceToHost));
+        if (herr) { printf("persistent: a granule never arrived (bounded spin gave up) — residency or visibility problem\n"); break; }
+    }
+    std::vector<float> ya(1280), yb(1280);
+    CK(hipMemcpy(ya.data(), dyA, 1280 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(yb.data(), dyB, 1280 * 4, hipMemcpyDeviceToHost));
+    int same = 0; for (int i = 0; i < 1280; i++) same += memcmp(&ya[i], &yb[i], 4) == 0;
+    printf("A  launches  : %8.1f us per step = %6.2f us per layer = %5.2f us per stage\n", bestA, bestA / n_layers, bestA / n_layers / NSTAGE);
+    printf("B  persistent: %8.1f us per step = %6.2f us per layer = %5.2f us per stage   (B / A = %.2f, outputs identical: %d / 1280, err %d)\n",
+           bestB, bestB / n_layers, bestB / n_layers / NSTAGE, bestB / bestA, same, herr);
+    return 0;
+}

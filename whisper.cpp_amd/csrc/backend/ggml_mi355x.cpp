@@ -375,8 +375,10 @@ struct mi_backend_ctx {
     // the kernel library's step block (mi355x_kernels.h) and the recorded launch arguments stay identical: replay without patching
     bool         step_on = false;             // this graph uses the step block
     int64_t      step_nkv = 0, step_kvoff = 0;
-    const ggml_tensor * mask_cast = nullptr;  // F32 -> F16 cast of KQ_mask whose only readers are decode attentions: folded into them
-    bool         mask_cast_done = false;               // what the host passes through "ggml_backend_set_n_threads" (the CPU's split-KV chunking)
+    // (Folding whisper's F32 -> F16 cast of KQ_mask into the attention kernels was tried and is WRONG behind the scheduler: the F32
+    //  mask is a split input whose device copy ggml-alloc considers dead after its only reader, the cast node, so its memory is
+    //  handed to later tensors of the same graph (sched n_copies == 1 does not pin inputs, ggml-backend.cpp split_graph).  Every
+    //  layer's attention reads the mask: only the F16 copy lives that long.)               // what the host passes through "ggml_backend_set_n_threads" (the CPU's split-KV chunking)
     // f16 activation scratch for the MFMA path, shared by consecutive mul_mats with the same src1
     void *       act = nullptr; size_t act_size = 0;
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
@@ -724,8 +726,7 @@ static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int
     const int64_t T = q->ne[1];
     if (T > 8 || q->ne[3] != 1 || fa->type != GGML_TYPE_F32 || !ggml_is_contiguous(fa)) return false;
     mi355x_tensor mq = to_mt(q), mk = to_mt(k), mv = to_mt(v), mm_;
-    const bool folded = m && m == b->mask_cast && !b->mask_cast_done;      // read whisper's F32 mask directly, the cast node is skipped
-    if (m) mm_ = to_mt(folded ? m->src[0] : m);
+    if (m) mm_ = to_mt(m);
     float scale; memcpy(&scale, fa->op_params, 4);
     mi355x_attn_partials parts;
     int rc = MI355X_E_UNSUPPORTED;
@@ -738,12 +739,6 @@ static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int
         if (cap >= b->step_nkv) rc = mi355x_flash_attn_partial_step(b->k, &mq, &mk, &mv, &mm_, scale, 1, (int) cap, &parts);
     }
     if (rc == MI355X_E_UNSUPPORTED) rc = mi355x_flash_attn_partial(b->k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
-    if (rc == MI355X_E_UNSUPPORTED && folded) {
-        // the fused path is not available after all: materialise the F16 mask now, every later reader uses it
-        b->mask_cast_done = true;
-        const int rc2 = run_node(b, b->mask_cast);
-        if (rc2) { rc_out = rc2; end_out = i; return true; }
-    }
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = i;
     if (rc) return true;
@@ -915,7 +910,6 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         if (max_launches > 0 && b->recording && mi355x_record_count(b->k) >= max_launches) break;
         const ggml_tensor * n = g->nodes[i];
         if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
-        if (n == b->mask_cast && !b->mask_cast_done) continue;              // folded into the attention kernels that read it
         int rc = MI355X_E_UNSUPPORTED;
         if (n->op == GGML_OP_MUL_MAT) {
             mm_chain c;
@@ -962,10 +956,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->fuse && n->src[0]->ne[1] <= 8) {
             int end = i, rc2 = MI355X_E_UNSUPPORTED;
             if (try_fattn_gemv(b, g, i, end, rc2)) { rc = rc2; i = end; }
-            else {
-                if (n->src[3] && n->src[3] == b->mask_cast && !b->mask_cast_done) { b->mask_cast_done = true; rc = run_node(b, b->mask_cast); if (rc) return rc; }
-                rc = run_node(b, n);
-            }
+            else rc = run_node(b, n);
             b->act_src = nullptr;
         } else {
             rc = run_node(b, n);
@@ -1108,7 +1099,7 @@ static void mi_backend_synchronize(ggml_backend_t backend) {
 // (T <= 8) with a mask.  Finds the live key count, the KV write offset (first F16 ggml_cpy into a cache view) and the mask cast
 // that can be folded away.  Anything unexpected simply leaves the step block unused: the by-value paths are always correct.
 static void mi_prescan_step(mi_backend_ctx * b, const ggml_cgraph * g) {
-    b->step_on = false; b->mask_cast = nullptr; b->mask_cast_done = false;
+    b->step_on = false;
     // Measured on large-v3 Q5_0 (profiles/r02_step_block_sweep.txt): patched nodes per step 64 -> 2 and host patch time 22.7 -> 1.9 ms
     // per chunk as intended, but the decode step got SLOWER, 1.547 -> 1.583 ms/token (GPU span 329 -> 336 ms per chunk): the host's
     // patching was already hidden behind the previous graph segment, while every self-attention and K/V-store kernel now starts with
@@ -1123,15 +1114,10 @@ static void mi_prescan_step(mi_backend_ctx * b, const ggml_cgraph * g) {
         if (j2 >= g->n_nodes || g->nodes[j1]->op != GGML_OP_GET_ROWS || g->nodes[j2]->op != GGML_OP_ADD) return;
     }
     int64_t nkv = -1, kvoff = -1;
-    const ggml_tensor * cast = nullptr; int cast_readers = 0;
     for (int i = first; i < g->n_nodes; i++) {
         const ggml_tensor * n = g->nodes[i];
         if (n->op == GGML_OP_FLASH_ATTN_EXT && n->src[3] && n->src[0]->ne[1] <= 8) {
             if (nkv < 0) nkv = n->src[1]->ne[1];
-            const ggml_tensor * m = n->src[3];
-            if (!cast && m->op == GGML_OP_CPY && m->type == GGML_TYPE_F16 && m->src[0] && m->src[0]->type == GGML_TYPE_F32 &&
-                ggml_is_contiguous(m) && ggml_is_contiguous(m->src[0]) && ggml_are_same_shape(m, m->src[0]) && !m->view_src && !(m->flags & GGML_TENSOR_FLAG_OUTPUT)) cast = m;
-            if (m == cast) cast_readers++;
         } else if (n->op == GGML_OP_CPY && n->type == GGML_TYPE_F16 && n->view_src && kvoff < 0 && n->src[0] && n->src[0]->type == GGML_TYPE_F32 && ggml_is_contiguous(n)) {
             kvoff = (int64_t) n->view_offs;
         }
@@ -1140,7 +1126,6 @@ static void mi_prescan_step(mi_backend_ctx * b, const ggml_cgraph * g) {
     b->step_on = true; b->step_nkv = nkv; b->step_kvoff = kvoff;
     (void) mi355x_step_set(b->k, 1, nkv); (void) mi355x_step_set(b->k, 2, kvoff); (void) mi355x_step_set(b->k, 3, 0);
     mi355x_step_arm(b->k, 1);
-    if (cast && cast_readers == use_count(g, cast)) b->mask_cast = cast;
 }
 
 static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
