@@ -94,8 +94,6 @@ GGML_MI355X_API void ggml_backend_mi355x_defer_weights(int on);
  *   GGML_MI355X_GRAPHS=0     do not build / replay hipGraphs
  *   GGML_MI355X_DEBUG=1      log unsupported ops and kernel-library errors to stderr
  *   GGML_MI355X_STRICT=1     abort instead of letting the scheduler fall back to the CPU backend for an unsupported op
- *   GGML_MI355X_STEP_BLOCK=1 decoder graphs take the live key count / KV write offset from device memory (zero node patches per step;
- *                            measured slower than patching) — off by default
  *   GGML_MI355X_EXACT=1      reference-exact arithmetic (test mode, slow): flash attention as the CPU dispatcher computes it
  *                            (F16 accumulation / split over n_threads / F32 tiles), integer block dots for every column count
  */

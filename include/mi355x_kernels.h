@@ -71,22 +71,6 @@ MI355X_API void *       mi355x_ctx_stream(mi355x_ctx * ctx);            /* hipSt
 MI355X_API int          mi355x_ctx_synchronize(mi355x_ctx * ctx);
 MI355X_API const char * mi355x_last_error(void);
 
-/* Step block: MI355X_STEP_SLOTS int64 values per context in device memory (slot 0 is always 0).  A decode step differs from the
- * previous one in two numbers only — the live key count of the self-attention cache and the byte offset at which the new K / V
- * rows are stored (src/whisper.cpp:2597-2598, :2885) — so kernels that take them from a slot (mi355x_gemv_seg.dst_step_slot,
- * mi355x_flash_attn_partial_step) have argument structs that are IDENTICAL from step to step: a recorded launch plan can be
- * replayed (hipGraph) without patching a single node.  mi355x_step_set updates the host copy; the caller moves the MI355X_STEP_SLOTS
- * values to mi355x_step_device() in stream order before the launches that read them (or calls mi355x_step_upload, synchronous). */
-#define MI355X_STEP_SLOTS 8
-MI355X_API int             mi355x_step_set(mi355x_ctx * ctx, int slot /* 1 .. MI355X_STEP_SLOTS-1 */, int64_t value);
-MI355X_API void *          mi355x_step_device(mi355x_ctx * ctx);       /* device address of the MI355X_STEP_SLOTS x int64 block */
-MI355X_API const int64_t * mi355x_step_host(mi355x_ctx * ctx);         /* host values (what the next upload will write) */
-MI355X_API int             mi355x_step_upload(mi355x_ctx * ctx);       /* host values -> device on the context's stream, then sync */
-/* arm: the NEXT mi355x_get_rows_add launch (the first kernel of a decoder graph) also stores the host values of slots 1..3 into the
- * device block — the values travel in that launch's own arguments, every later launch of the step sees them in stream order */
-MI355X_API void            mi355x_step_arm(mi355x_ctx * ctx, int on);
-MI355X_API int             mi355x_step_armed(mi355x_ctx * ctx);        /* 1 while no launch has taken the values yet (then: mi355x_step_upload) */
-
 /* launch recording: between begin/end no kernel is launched; launches are appended to the context's
  * plan instead (used by the backend to build / patch a hipGraph).  See ggml_mi355x.h. */
 typedef struct mi355x_launch {
@@ -173,7 +157,7 @@ typedef struct mi355x_gemv_seg {
     mi355x_epilogue ep;
     void *        dst;             /* [N, T] */
     int32_t       dst_type;        /* F32 or F16 */
-    int32_t       dst_step_slot;   /* 0: none; s > 0: the value of step-block slot s (bytes) is added to dst when the kernel RUNS */
+    int32_t       reserved;
     int64_t       dst_nb1;         /* byte stride between columns */
 } mi355x_gemv_seg;
 
@@ -212,13 +196,6 @@ typedef struct mi355x_attn_partials {
 MI355X_API int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                                          const mi355x_tensor * mask /* nullable */, float scale, mi355x_attn_partials * out);
 MI355X_API int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_partials * p, const mi355x_tensor * dst);
-/* The same with the live key count taken from step-block slot nkv_slot (> 0; its host value must equal k->ne[1]) at run time.
- * n_kv_cap = rows of K / V that are addressable memory (the cache's capacity, >= k->ne[1]): the launch covers ceil(n_kv_cap/128)
- * chunks, chunks beyond the live count leave empty records.  `mask` may be the F32 [n_kv, T] tensor whisper uploads (the F32->F16
- * ggml_cast in front of flash_attn_ext, src/whisper.cpp:2520, folded in).  Nothing in the launch arguments depends on n_kv. */
-MI355X_API int mi355x_flash_attn_partial_step(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
-                                              const mi355x_tensor * mask /* nullable */, float scale, int nkv_slot, int n_kv_cap, mi355x_attn_partials * out);
-
 /* Decoder cross-attention in one launch (T = 1): q = scale_q * (W_q . LayerNorm(x) + bias) is recomputed per (head, 128-key
  * chunk) workgroup and fed straight into mi355x_flash_attn_partial's arithmetic (src/whisper.cpp:2684-2726 =
  * ggml_norm, mul, add, mul_mat, add, scale, flash_attn_ext).  `qproj` describes the projection exactly like a

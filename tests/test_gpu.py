@@ -507,72 +507,6 @@ def test_attention_partials_feed_the_projection(gpu, oracle, T, n_kv, H):
     assert nmse(want, y_d.cpu().numpy()) < 1e-9
 
 
-@pytest.mark.parametrize("T,n_kv", [(1, 1), (1, 37), (1, 129), (1, 300), (5, 77), (5, 260)])
-def test_step_block_attention_and_kv_store_equal_the_by_value_launches(gpu, oracle, T, n_kv):
-    """The decode step's two changing numbers travel through the step block (mi355x_step_set): the self-attention reads its live key
-    count from slot 1 (launch sized for the cache's capacity, F32 mask read directly), the K / V store adds the byte offset of slot 2.
-    Both must be bit-identical to the launches that take the numbers by value, with rows beyond the live count holding garbage."""
-    ctx, ka, torch = gpu
-    D, H, cap = 64, 6, 512
-    K = H * D
-    rng = np.random.default_rng(T * 7 + n_kv)
-    q = (rng.standard_normal((T, H, D)) * 0.6).astype(np.float32)
-    k = (rng.standard_normal((cap, H, D)) * 0.6).astype(np.float16)       # rows >= n_kv: stale cache contents
-    v = rng.standard_normal((cap, H, D)).astype(np.float16)
-    mf = np.zeros((T, n_kv), dtype=np.float32)
-    for t in range(T):
-        mf[t, max(1, n_kv - T + t + 1):] = -np.inf
-    q_d, k_d, v_d, mf_d, mh_d = dev(torch, q), dev(torch, k), dev(torch, v), dev(torch, mf), dev(torch, mf.astype(np.float16))
-    tq = ka.tensor(q_d.data_ptr(), ka.F32, [D, T, H], [4, H * D * 4, D * 4, T * H * D * 4])
-    tk = ka.tensor(k_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, cap * H * D * 2])
-    tv = ka.tensor(v_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, cap * H * D * 2])
-    tmh = ka.tensor(mh_d.data_ptr(), ka.F16, [n_kv, T])
-    tmf = ka.tensor(mf_d.data_ptr(), ka.F32, [n_kv, T])
-    outs = []
-    for step in (False, True):
-        parts = ka.AttnPartials()
-        if step:
-            ctx.check(ka.lib().mi355x_step_set(ctx.h, 1, n_kv), "step_set")
-            ctx.check(ka.lib().mi355x_step_upload(ctx.h), "step_upload")
-            ctx.check(ka.lib().mi355x_flash_attn_partial_step(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), C.byref(tmf), 1.0, 1, cap, C.byref(parts)), "fattn_partial_step")
-            assert parts.nparts == cap // 128
-        else:
-            ctx.check(ka.lib().mi355x_flash_attn_partial(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), C.byref(tmh), 1.0, C.byref(parts)), "fattn_partial")
-        o_d = torch.zeros((T, H, D), dtype=torch.float32, device="cuda:0")
-        torch.cuda.synchronize()
-        to = ka.tensor(o_d.data_ptr(), ka.F32, [D, H, T])
-        ctx.check(ka.lib().mi355x_flash_attn_combine(ctx.h, C.byref(parts), C.byref(to)), "fattn_combine")
-        ctx.sync()
-        outs.append(o_d.cpu().numpy())
-    assert np.isfinite(outs[1]).all()
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
-    # K store of a [K -> N] projection into an F16 cache at row offset `pos`: by value vs through slot 2
-    N, pos = 384, 11
-    x = rng.standard_normal((T, K)).astype(np.float32)
-    wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-    _, planar = quantize(oracle, ka, 6, wf)
-    x_d, w_d = dev(torch, x), dev(torch, planar)
-    caches = []
-    for step in (False, True):
-        c_d = torch.zeros((64, N), dtype=torch.float16, device="cuda:0")
-        torch.cuda.synchronize()
-        d = ka.GemvDesc()
-        d.x, d.x_nb1, d.K, d.T, d.nseg = x_d.data_ptr(), K * 4, K, T, 1
-        d.seg[0].w, d.seg[0].wtype, d.seg[0].N = w_d.data_ptr(), 6, N
-        d.seg[0].dst_type, d.seg[0].dst_nb1 = ka.F16, N * 2
-        if step:
-            ctx.check(ka.lib().mi355x_step_set(ctx.h, 2, pos * N * 2), "step_set")
-            ctx.check(ka.lib().mi355x_step_upload(ctx.h), "step_upload")
-            d.seg[0].dst, d.seg[0].dst_step_slot = c_d.data_ptr(), 2
-        else:
-            d.seg[0].dst = c_d.data_ptr() + pos * N * 2
-        ctx.check(ka.lib().mi355x_gemv_fused(ctx.h, C.byref(d)), "gemv_fused")
-        ctx.sync()
-        caches.append(c_d.cpu().numpy())
-    assert np.array_equal(caches[0].view(np.uint16), caches[1].view(np.uint16))
-    assert np.any(caches[0][pos:pos + T] != 0) and not np.any(caches[0][:pos] != 0)
-
-
 @pytest.mark.parametrize("t", ["q5_0", "q8_0", "q4_0", "q4_K"])
 @pytest.mark.parametrize("n_kv", [1536, 130])
 def test_fused_ln_q_attention_matches_unfused_sequence(gpu, oracle, t, n_kv):

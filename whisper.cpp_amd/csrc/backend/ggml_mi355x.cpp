@@ -370,15 +370,6 @@ struct mi_backend_ctx {
     // for every column count (no f16-rounded d*q products) — so that free-running decodes can be compared token for token
     bool         exact = false;
     int          n_threads = 4;
-    // per-graph step parameters (decoder graphs: src/whisper.cpp:2466-2844).  From one decode step to the next only two numbers
-    // change — the live key count of the self-attention cache and the byte offset of the new K / V rows — so they travel through
-    // the kernel library's step block (mi355x_kernels.h) and the recorded launch arguments stay identical: replay without patching
-    bool         step_on = false;             // this graph uses the step block
-    int64_t      step_nkv = 0, step_kvoff = 0;
-    // (Folding whisper's F32 -> F16 cast of KQ_mask into the attention kernels was tried and is WRONG behind the scheduler: the F32
-    //  mask is a split input whose device copy ggml-alloc considers dead after its only reader, the cast node, so its memory is
-    //  handed to later tensors of the same graph (sched n_copies == 1 does not pin inputs, ggml-backend.cpp split_graph).  Every
-    //  layer's attention reads the mask: only the F16 copy lives that long.)               // what the host passes through "ggml_backend_set_n_threads" (the CPU's split-KV chunking)
     // f16 activation scratch for the MFMA path, shared by consecutive mul_mats with the same src1
     void *       act = nullptr; size_t act_size = 0;
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
@@ -677,11 +668,6 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
         sg.w = w->data; sg.wtype = (int32_t) w->type; sg.N = (int32_t) w->ne[1]; sg.ep = ch[s].ep;
         sg.dst = ch[s].last->data; sg.dst_type = (int32_t) ch[s].last->type;
         sg.dst_nb1 = ch[s].last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch[s].last == ch[s].mm ? (int64_t) ch[s].mm->nb[1] : (int64_t) ch[s].last->nb[1]);
-        // store into the KV cache (fused ggml_cpy to an F16 view of it, W:2597-2598): this step's row offset comes from the step block
-        const ggml_tensor * l = ch[s].last;
-        if (b->step_on && l->type == GGML_TYPE_F16 && l->op == GGML_OP_CPY && l->view_src && (int64_t) l->view_offs >= b->step_kvoff) {
-            sg.dst = (char *) l->data - b->step_kvoff; sg.dst_step_slot = 2;
-        }
     }
     // cross-attention, T = 1: LN -> Q projection -> flash_attn_ext whose q is a pure view of the projection's result and
     // nothing else reads it => one launch computes the attention partials directly (k_qattn)
@@ -729,16 +715,7 @@ static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int
     if (m) mm_ = to_mt(m);
     float scale; memcpy(&scale, fa->op_params, 4);
     mi355x_attn_partials parts;
-    int rc = MI355X_E_UNSUPPORTED;
-    if (b->step_on && m && k->ne[1] == b->step_nkv && v->ne[1] == b->step_nkv && k->view_src && v->view_src) {
-        // rows of K / V that are addressable behind this layer's view (the cache's capacity): the launch covers them, the live count
-        // is read from the step block
-        const int64_t cap_k = ((int64_t) ggml_nbytes(k->view_src) - (int64_t) k->view_offs) / (int64_t) k->nb[1];
-        const int64_t cap_v = ((int64_t) ggml_nbytes(v->view_src) - (int64_t) v->view_offs) / (int64_t) v->nb[1];
-        const int64_t cap = std::min<int64_t>(std::min(cap_k, cap_v), 512);
-        if (cap >= b->step_nkv) rc = mi355x_flash_attn_partial_step(b->k, &mq, &mk, &mv, &mm_, scale, 1, (int) cap, &parts);
-    }
-    if (rc == MI355X_E_UNSUPPORTED) rc = mi355x_flash_attn_partial(b->k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
+    int rc = mi355x_flash_attn_partial(b->k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = i;
     if (rc) return true;
@@ -943,8 +920,6 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
                 }
             }
             if (rc == MI355X_E_UNSUPPORTED) rc = run_node(b, n);
-            // the fused embedding launch normally carries this step's numbers into the step block; if it was not produced, copy them
-            if (b->step_on && mi355x_step_armed(b->k) && mi355x_step_upload(b->k) != 0) rc = -2;
             b->act_src = nullptr;
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->exact) {
             mi355x_tensor q = to_mt(n->src[0]), kk = to_mt(n->src[1]), v = to_mt(n->src[2]), d = to_mt(n), m;
@@ -1094,40 +1069,6 @@ static void mi_backend_synchronize(ggml_backend_t backend) {
     if (b->span_pending) mi_span_drain(b);
 }
 
-// Decoder-graph signature: the first compute node is the token-embedding gather that mi_emit_range fuses with the positional
-// gather and their add (one launch: it carries this step's numbers into the step block), and the graph holds decode attentions
-// (T <= 8) with a mask.  Finds the live key count, the KV write offset (first F16 ggml_cpy into a cache view) and the mask cast
-// that can be folded away.  Anything unexpected simply leaves the step block unused: the by-value paths are always correct.
-static void mi_prescan_step(mi_backend_ctx * b, const ggml_cgraph * g) {
-    b->step_on = false;
-    // Measured on large-v3 Q5_0 (profiles/r02_step_block_sweep.txt): patched nodes per step 64 -> 2 and host patch time 22.7 -> 1.9 ms
-    // per chunk as intended, but the decode step got SLOWER, 1.547 -> 1.583 ms/token (GPU span 329 -> 336 ms per chunk): the host's
-    // patching was already hidden behind the previous graph segment, while every self-attention and K/V-store kernel now starts with
-    // one more dependent memory round trip.  Kept as an opt-in (kernel-level tests keep it honest), off by default.
-    static const bool enabled = env_flag("GGML_MI355X_STEP_BLOCK", false);
-    if (!enabled || !b->fuse || b->exact || b->prof) return;
-    int first = 0;
-    while (first < g->n_nodes && (op_is_empty(g->nodes[first]) || !(g->nodes[first]->flags & GGML_TENSOR_FLAG_COMPUTE))) first++;
-    if (first >= g->n_nodes || g->nodes[first]->op != GGML_OP_GET_ROWS) return;
-    {   // the fused embedding launch must be the one mi_emit_range will produce
-        const int j1 = next_real(g, first), j2 = j1 < g->n_nodes ? next_real(g, j1) : g->n_nodes;
-        if (j2 >= g->n_nodes || g->nodes[j1]->op != GGML_OP_GET_ROWS || g->nodes[j2]->op != GGML_OP_ADD) return;
-    }
-    int64_t nkv = -1, kvoff = -1;
-    for (int i = first; i < g->n_nodes; i++) {
-        const ggml_tensor * n = g->nodes[i];
-        if (n->op == GGML_OP_FLASH_ATTN_EXT && n->src[3] && n->src[0]->ne[1] <= 8) {
-            if (nkv < 0) nkv = n->src[1]->ne[1];
-        } else if (n->op == GGML_OP_CPY && n->type == GGML_TYPE_F16 && n->view_src && kvoff < 0 && n->src[0] && n->src[0]->type == GGML_TYPE_F32 && ggml_is_contiguous(n)) {
-            kvoff = (int64_t) n->view_offs;
-        }
-    }
-    if (nkv < 1 || kvoff < 0 || nkv > 512) return;
-    b->step_on = true; b->step_nkv = nkv; b->step_kvoff = kvoff;
-    (void) mi355x_step_set(b->k, 1, nkv); (void) mi355x_step_set(b->k, 2, kvoff); (void) mi355x_step_set(b->k, 3, 0);
-    mi355x_step_arm(b->k, 1);
-}
-
 static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     if (hipSetDevice(b->device) != hipSuccess) return GGML_STATUS_FAILED;
@@ -1142,7 +1083,6 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
             io.wake_seq = b->io_seen;
         }
     }
-    mi_prescan_step(b, cgraph);
     // GPU span bookkeeping (two event records per call)
     static const bool span_on = env_flag("GGML_MI355X_SPAN", true);
     int span_idx = -1;

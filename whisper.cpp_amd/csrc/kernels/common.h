@@ -35,10 +35,6 @@ struct mi355x_ctx {
     size_t      scratch_size = 0;
     size_t      scratch_used = 0;        // bump pointer, reset per op group
     std::vector<void *> scratch_retired; // outgrown arenas that may still back pointers of the current op group
-    // step block: MI355X_STEP_SLOTS x int64 on the device (slot 0 always holds 0) + the host's current values (mi355x_step_set)
-    int64_t *   step_dev = nullptr;
-    int64_t     step_host[MI355X_STEP_SLOTS] = { 0 };
-    bool        step_armed = false;      // the next mi355x_get_rows_add launch publishes slots 1..3
     float *     mel_tab = nullptr;       // sin / cos / Hann tables + the running maximum of mi355x_log_mel (device)
     // recording
     bool                        recording = false;

@@ -60,9 +60,6 @@ extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) ctx->n_cu = p.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
-    if (hipMalloc((void **) &ctx->step_dev, MI355X_STEP_SLOTS * 8) != hipSuccess || hipMemset(ctx->step_dev, 0, MI355X_STEP_SLOTS * 8) != hipSuccess) {
-        mi355x_set_error("step block allocation failed"); (void) hipStreamDestroy(ctx->stream); delete ctx; return nullptr;
-    }
     std::vector<uint16_t> tab(65536);
     mi355x_gelu_table_host(tab.data());
     if (hipMalloc((void **) &ctx->gelu_tab, 65536*2) != hipSuccess ||
@@ -80,31 +77,12 @@ extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
     if (ctx->scratch)  (void) hipFree(ctx->scratch);
     for (void * r : ctx->scratch_retired) (void) hipFree(r);
     if (ctx->gelu_tab) (void) hipFree(ctx->gelu_tab);
-    if (ctx->step_dev) (void) hipFree(ctx->step_dev);
     if (ctx->mel_tab)  (void) hipFree(ctx->mel_tab);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 extern "C" void * mi355x_ctx_stream(mi355x_ctx * ctx) { return (void *) ctx->stream; }
-
-// ---- step block ---------------------------------------------------------------------------------
-extern "C" int mi355x_step_set(mi355x_ctx * ctx, int slot, int64_t value) {
-    if (slot < 1 || slot >= MI355X_STEP_SLOTS) return MI355X_E_UNSUPPORTED;
-    ctx->step_host[slot] = value;
-    return 0;
-}
-extern "C" void mi355x_step_arm(mi355x_ctx * ctx, int on) { ctx->step_armed = on != 0; }
-extern "C" int  mi355x_step_armed(mi355x_ctx * ctx) { return ctx->step_armed ? 1 : 0; }
-extern "C" void * mi355x_step_device(mi355x_ctx * ctx) { return ctx->step_dev; }
-extern "C" const int64_t * mi355x_step_host(mi355x_ctx * ctx) { return ctx->step_host; }
-extern "C" int mi355x_step_upload(mi355x_ctx * ctx) {
-    (void) hipSetDevice(ctx->device);
-    HIP_OK(hipMemcpyAsync(ctx->step_dev, ctx->step_host, MI355X_STEP_SLOTS * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_OK(hipStreamSynchronize(ctx->stream));        // the host array may change right after this call
-    ctx->step_armed = false;
-    return 0;
-}
 
 // A wide do-nothing launch.  The first chip-wide dispatch after the GPU has sat idle for a few hundred microseconds (the
 // host-side part of a decode step) stalls ~30 us (profiles: gap before the first mat-vec of every step, while the

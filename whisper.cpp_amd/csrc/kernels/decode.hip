@@ -25,26 +25,11 @@
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// A step-block value.  The block is written by a KERNEL of the same graph (the embedding launch, mi355x_step_arm) and read through a
-// wave-uniform address, which the compiler would turn into a scalar load: the scalar data cache is not refreshed between the
-// kernels of a replayed graph (measured: the previous step's values were read).  An agent-scope atomic load is a vector load
-// served by L2.
-__device__ __forceinline__ int64_t step_load(const int64_t * p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// low 32 bits of a slot (key counts): with the 64-bit form the compiler reuses the dead high register of the pair right away, which
-// puts an s_waitcnt vmcnt(0) in front of the K / V request burst
-__device__ __forceinline__ int step_load32(const int64_t * p) {
-    return __hip_atomic_load((const int *) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 struct DGSeg {
     const void *  w;  int64_t nbt;  int N;  int has_scale;
     const float * bias; float scale; int gelu;
     const float * residual; int64_t res_nb1;
     void * dst; int64_t dst_nb1; int dst_f16; int pad;
-    const int64_t * dst_off;           // byte offset added to dst: a slot of the context's step block (slot 0 holds 0), see mi355x_step_set
 };
 struct DGArgs {
     const float * x; int64_t x_nb1; int K; int has_norm; float eps; int nseg;
@@ -454,7 +439,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
                 if (sg.has_scale) v = v * sg.scale;
                 if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
                 if (sg.residual)  v = v + *(const float *) ((const char *) sg.residual + (int64_t) j8*sg.res_nb1 + (int64_t) row*4);
-                char * dp = (char *) sg.dst + step_load(sg.dst_off) + (int64_t) j8*sg.dst_nb1;
+                char * dp = (char *) sg.dst + (int64_t) j8*sg.dst_nb1;
                 if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
             }
             #pragma unroll
@@ -535,12 +520,9 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     // compiler they are fetched one by one at their first use, i.e. serialized scalar-cache misses at the kernel tail.
     const DGSeg & sgr = NSEG1 ? a.seg[0] : a.seg[s];
     struct { const void * w; int64_t nbt; const float * bias; const float * residual; int64_t res_nb1; void * dst; int64_t dst_nb1;
-             float scale; int has_scale, gelu, dst_f16; const int64_t * dst_off; } sg;
+             float scale; int has_scale, gelu, dst_f16; } sg;
     sg.w = sgr.w; sg.nbt = sgr.nbt; sg.bias = sgr.bias; sg.residual = sgr.residual; sg.res_nb1 = sgr.res_nb1;
     sg.dst = sgr.dst; sg.dst_nb1 = sgr.dst_nb1; sg.scale = sgr.scale; sg.has_scale = sgr.has_scale; sg.gelu = sgr.gelu; sg.dst_f16 = sgr.dst_f16;
-    sg.dst_off = sgr.dst_off;
-    // this step's write position in the KV cache (issued with the first loads, consumed only by the final store)
-    const int64_t dst_off = step_load(sg.dst_off);
     asm volatile("" :: "s"(sg.w), "s"(sg.nbt), "s"(sg.bias), "s"(sg.residual), "s"(sg.res_nb1), "s"(sg.dst), "s"(sg.dst_nb1),
                        "s"(sg.scale), "s"(sg.has_scale), "s"(sg.gelu), "s"(sg.dst_f16), "s"(a.gelu_tab),
                        "s"(a.x), "s"(a.x_nb1), "s"(a.ln_w), "s"(a.ln_b), "s"(a.part_o), "s"(a.part_ml), "s"(a.nparts), "s"(a.eps));
@@ -896,7 +878,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         if (sg.has_scale) v = v * sg.scale;
         if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
         if (sg.residual)  v = v + res_v;
-        char * dp = (char *) sg.dst + dst_off + (int64_t) tcol*sg.dst_nb1;
+        char * dp = (char *) sg.dst + (int64_t) tcol*sg.dst_nb1;
         if (sg.dst_f16) ((uint16_t *) dp)[row + rlane] = f2h(v); else ((float *) dp)[row + rlane] = v;
     }
     DG_STAMP(6);
@@ -997,8 +979,6 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         o.bias = g.ep.bias; o.scale = g.ep.scale; o.has_scale = g.ep.has_scale; o.gelu = g.ep.gelu;
         o.residual = g.ep.residual; o.res_nb1 = g.ep.residual_nb1;
         o.dst = g.dst; o.dst_nb1 = g.dst_nb1; o.dst_f16 = g.dst_type == MI355X_TYPE_F16;
-        if (g.dst_step_slot < 0 || g.dst_step_slot >= MI355X_STEP_SLOTS) return MI355X_E_UNSUPPORTED;
-        o.dst_off = ctx->step_dev + g.dst_step_slot;
         ntot += g.N;
         wbytes += (double) mi355x_type_row_bytes(wt, K) * g.N;
     }
@@ -1076,13 +1056,9 @@ struct FDArgs {
     int has_mask; float scale;
     int T, n_kv, H, rk2, rv2, nparts;
     float * part_o; float * part_ml;
-    // per-step form (mi355x_flash_attn_partial_step): the live key count comes from the context's step block, so the argument
-    // struct is the same for every decode step; n_kv_safe = rows of K / V that are valid MEMORY (the cache's capacity), nparts
-    // covers it; chunks beyond the live count leave empty records (m = -1e30, l = 0)
-    const int64_t * nkv_ptr; int nkv_from_step; int n_kv_safe; int mask_nb1_per_key;
 };
 
-template <int T, bool MF32>
+template <int T>
 __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     __shared__ __attribute__((aligned(16))) float wo[4][T][64];
     __shared__ float wml[4][T][2];
@@ -1091,11 +1067,6 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2;
     const int p = blockIdx.x;
     const int kbeg = p*128 + wave*32;
-    // live key count: by value, or this step's value from the step block (the scalar load is issued here and only consumed by
-    // the mask addresses and the score masking below, so the K / V request burst does not wait for it)
-    const int nkv_s = step_load32(a.nkv_ptr);
-    const int n_kv = a.nkv_from_step ? nkv_s : a.n_kv;
-    const int n_safe = a.n_kv_safe;
 
     // all K and V rows of this wave are requested up front: 8 x 16 B per lane in flight
     const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2] + dc*16;
@@ -1104,11 +1075,10 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     uint4 kr[4], vr[4];
     #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int key = kbeg + kg + 8*i, kc = key < n_safe ? key : n_safe - 1;
+        const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
         kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k.nb[1]);
         vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v.nb[1]);
     }
-    __builtin_amdgcn_sched_barrier(0);          // the K / V burst is issued before anything that has to wait for the live key count
     // q (rounded to f16 like the CPU's q_to_vec_dot), this lane's 8 dims of every query
     float qf[T][8];
     #pragma unroll
@@ -1120,19 +1090,15 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     }
     // mask values of this lane's keys: requested together with everything else (a dependent load later would be a
     // serialized miss: the mask was written by the preceding cast kernel, on another XCD)
-    // MF32: the mask is still the F32 tensor whisper uploads (the F32 -> F16 cast node is folded in: the value is rounded to f16
-    // here exactly as ggml_cpy would have)
-    float mkf[T][4];
+    uint16_t mkh[T][4];
     const char * mbase = a.has_mask ? a.m.data : (const char *) a.k.data;       // dummy (valid) address without a mask
-    constexpr int MES = MF32 ? 4 : 2;
-    const int64_t mnb1 = a.has_mask ? (a.mask_nb1_per_key ? (int64_t) n_kv * MES : a.m.nb[1]) : 0;
+    const int64_t mnb1 = a.has_mask ? a.m.nb[1] : 0;
     #pragma unroll
     for (int t = 0; t < T; t++)
         #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int key = kbeg + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
-            const char * mp = mbase + (int64_t) t*mnb1 + (int64_t) kc*MES;
-            if constexpr (MF32) mkf[t][i] = round_f16(*(const float *) mp); else mkf[t][i] = h2f(*(const uint16_t *) mp);
+            const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
+            mkh[t][i] = *(const uint16_t *) (mbase + (int64_t) t*mnb1 + (int64_t) kc*2);
         }
     float sc[T][4];
     #pragma unroll
@@ -1148,8 +1114,8 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
             #pragma unroll
             for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[t][e], s);
             s = group_sum<8>(s);
-            const float x = s * a.scale + (a.has_mask ? mkf[t][i] : 0.0f);
-            sc[t][i] = key < n_kv ? x : -INFINITY;
+            const float x = s * a.scale + (a.has_mask ? h2f(mkh[t][i]) : 0.0f);
+            sc[t][i] = key < a.n_kv ? x : -INFINITY;
         }
     }
     #pragma unroll
@@ -1467,77 +1433,43 @@ static int fattn_dec_check(const mi355x_tensor * q, const mi355x_tensor * k, con
     if (k->ne[2] <= 0 || H % k->ne[2] || v->ne[2] <= 0 || H % v->ne[2]) return MI355X_E_UNSUPPORTED;
     if (((uintptr_t) q->data | q->nb[1] | q->nb[2]) % 16 || ((uintptr_t) k->data | k->nb[1] | k->nb[2]) % 16 ||
         ((uintptr_t) v->data | v->nb[1] | v->nb[2]) % 16) return MI355X_E_UNSUPPORTED;
-    if (mask) {
-        const int es = mask->type == MI355X_TYPE_F16 ? 2 : (mask->type == MI355X_TYPE_F32 ? 4 : 0);          // F32: the cast node folded in
-        if (!es || mask->ne[0] < n_kv || mask->ne[1] < T || mask->nb[0] != es || mask->ne[2] != 1 || mask->ne[3] != 1) return MI355X_E_UNSUPPORTED;
-    }
-    return 0;
-}
-
-template <bool MF32>
-static int launch_fattn_dec(mi355x_ctx * ctx, int T, dim3 grid, const FDArgs & a, double bytes, double flops) {
-    const dim3 block(256);
-    switch (T) {
-        case 1: return emit(ctx, "fattn_dec", k_fattn_dec<1, MF32>, grid, block, 0, a, bytes, flops);
-        case 2: return emit(ctx, "fattn_dec", k_fattn_dec<2, MF32>, grid, block, 0, a, bytes, flops);
-        case 3: return emit(ctx, "fattn_dec", k_fattn_dec<3, MF32>, grid, block, 0, a, bytes, flops);
-        case 4: return emit(ctx, "fattn_dec", k_fattn_dec<4, MF32>, grid, block, 0, a, bytes, flops);
-        case 5: return emit(ctx, "fattn_dec", k_fattn_dec<5, MF32>, grid, block, 0, a, bytes, flops);
-        case 6: return emit(ctx, "fattn_dec", k_fattn_dec<6, MF32>, grid, block, 0, a, bytes, flops);
-        case 7: return emit(ctx, "fattn_dec", k_fattn_dec<7, MF32>, grid, block, 0, a, bytes, flops);
-        default: return emit(ctx, "fattn_dec", k_fattn_dec<8, MF32>, grid, block, 0, a, bytes, flops);
-    }
-}
-
-// nkv_slot > 0: the live key count is read from that slot of the context's step block at run time (its current host value must
-// equal k->ne[1]); n_kv_cap = rows of K / V that are addressable (>= k->ne[1]): the launch covers ceil(n_kv_cap / 128) chunks
-static int flash_attn_partial_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
-                                   const mi355x_tensor * mask, float scale, int nkv_slot, int n_kv_cap, mi355x_attn_partials * out) {
-    const int rc0 = fattn_dec_check(q, k, v, mask);
-    if (rc0) return rc0;
-    const int T = (int) q->ne[1], H = (int) q->ne[2], n_kv = (int) k->ne[1];
-    if (nkv_slot < 0 || nkv_slot >= MI355X_STEP_SLOTS) return MI355X_E_UNSUPPORTED;
-    if (nkv_slot > 0 && (ctx->step_host[nkv_slot] != n_kv || n_kv_cap < n_kv)) return MI355X_E_UNSUPPORTED;
-    FDArgs a; memset(&a, 0, sizeof(a));
-    a.q = to_d(q); a.k = to_d(k); a.v = to_d(v);
-    if (mask) a.m = to_d(mask);
-    a.has_mask = mask != nullptr; a.scale = scale; a.T = T; a.n_kv = n_kv; a.H = H;
-    a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
-    a.nkv_ptr = ctx->step_dev + nkv_slot; a.nkv_from_step = nkv_slot > 0;
-    a.n_kv_safe = nkv_slot > 0 ? n_kv_cap : n_kv;
-    a.nparts = (a.n_kv_safe + 127) / 128;
-    if (nkv_slot > 0) {
-        // nothing in the argument struct may depend on the live count: the tensors' key extents are not read by the kernel, the
-        // mask's row stride is derived from the live count when the mask is the dense [n_kv, T] tensor whisper builds
-        a.n_kv = 0; a.k.ne[1] = a.v.ne[1] = 0;
-        if (mask) {
-            const int es = mask->type == MI355X_TYPE_F32 ? 4 : 2;
-            if (mask->nb[1] != (int64_t) n_kv * es) return MI355X_E_UNSUPPORTED;
-            a.mask_nb1_per_key = 1; a.m.ne[0] = 0; a.m.nb[1] = a.m.nb[2] = a.m.nb[3] = 0;
-        }
-    }
-    mi355x_scratch_reset(ctx);
-    const size_t nrec = (size_t) H * T * a.nparts;
-    a.part_o  = (float *) mi355x_scratch_alloc(ctx, nrec * 64 * 4);
-    a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
-    if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
-    const dim3 grid(a.nparts, H);
-    const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) T*H*64*4 + (double) nrec*66*4;
-    const double flops = 4.0 * T * (double) n_kv * 64 * H;
-    const int rc = (mask && mask->type == MI355X_TYPE_F32) ? launch_fattn_dec<true>(ctx, T, grid, a, bytes, flops) : launch_fattn_dec<false>(ctx, T, grid, a, bytes, flops);
-    if (rc) return rc;
-    out->part_o = a.part_o; out->part_ml = a.part_ml; out->nparts = a.nparts; out->T = T; out->H = H;
+    if (mask && (mask->type != MI355X_TYPE_F16 || mask->ne[0] < n_kv || mask->ne[1] < T || mask->nb[0] != 2 || mask->ne[2] != 1 || mask->ne[3] != 1)) return MI355X_E_UNSUPPORTED;
     return 0;
 }
 
 extern "C" int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                                          const mi355x_tensor * mask, float scale, mi355x_attn_partials * out) {
-    return flash_attn_partial_impl(ctx, q, k, v, mask, scale, 0, 0, out);
-}
-extern "C" int mi355x_flash_attn_partial_step(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
-                                              const mi355x_tensor * mask, float scale, int nkv_slot, int n_kv_cap, mi355x_attn_partials * out) {
-    if (nkv_slot <= 0) return MI355X_E_UNSUPPORTED;
-    return flash_attn_partial_impl(ctx, q, k, v, mask, scale, nkv_slot, n_kv_cap, out);
+    const int rc0 = fattn_dec_check(q, k, v, mask);
+    if (rc0) return rc0;
+    const int T = (int) q->ne[1], H = (int) q->ne[2], n_kv = (int) k->ne[1];
+    FDArgs a; memset(&a, 0, sizeof(a));
+    a.q = to_d(q); a.k = to_d(k); a.v = to_d(v);
+    if (mask) a.m = to_d(mask);
+    a.has_mask = mask != nullptr; a.scale = scale; a.T = T; a.n_kv = n_kv; a.H = H;
+    a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
+    a.nparts = (n_kv + 127) / 128;
+    mi355x_scratch_reset(ctx);
+    const size_t nrec = (size_t) H * T * a.nparts;
+    a.part_o  = (float *) mi355x_scratch_alloc(ctx, nrec * 64 * 4);
+    a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
+    if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
+    const dim3 grid(a.nparts, H), block(256);
+    const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) T*H*64*4 + (double) nrec*66*4;
+    const double flops = 4.0 * T * (double) n_kv * 64 * H;
+    int rc;
+    switch (T) {
+        case 1: rc = emit(ctx, "fattn_dec", k_fattn_dec<1>, grid, block, 0, a, bytes, flops); break;
+        case 2: rc = emit(ctx, "fattn_dec", k_fattn_dec<2>, grid, block, 0, a, bytes, flops); break;
+        case 3: rc = emit(ctx, "fattn_dec", k_fattn_dec<3>, grid, block, 0, a, bytes, flops); break;
+        case 4: rc = emit(ctx, "fattn_dec", k_fattn_dec<4>, grid, block, 0, a, bytes, flops); break;
+        case 5: rc = emit(ctx, "fattn_dec", k_fattn_dec<5>, grid, block, 0, a, bytes, flops); break;
+        case 6: rc = emit(ctx, "fattn_dec", k_fattn_dec<6>, grid, block, 0, a, bytes, flops); break;
+        case 7: rc = emit(ctx, "fattn_dec", k_fattn_dec<7>, grid, block, 0, a, bytes, flops); break;
+        default: rc = emit(ctx, "fattn_dec", k_fattn_dec<8>, grid, block, 0, a, bytes, flops); break;
+    }
+    if (rc) return rc;
+    out->part_o = a.part_o; out->part_ml = a.part_ml; out->nparts = a.nparts; out->T = T; out->H = H;
+    return 0;
 }
 
 extern "C" int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_partials * p, const mi355x_tensor * dst) {

@@ -257,12 +257,10 @@ extern "C" int mi355x_cpy(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355
 // -------------------------------------------------------------------------------------------------
 // optional fused second gather + add (token embedding + positional embedding, src/whisper.cpp:2524-2526):
 //   dst[:, r] = src[:, idx[r]] + add[:, add_idx[r]]     (add: F32 rows, 1-D index of the same length)
-struct GetRowsArgs { dtensor s, idx, d; int type; int64_t nbt; const char * add; int64_t add_nb1; const int32_t * add_idx; int64_t add_rows;
-                     int64_t * step_dst; int64_t step_vals[3]; };       // armed launch (mi355x_step_arm): also publishes step-block slots 1..3
+struct GetRowsArgs { dtensor s, idx, d; int type; int64_t nbt; const char * add; int64_t add_nb1; const int32_t * add_idx; int64_t add_rows; };
 template <int TYPE>
 __global__ void __launch_bounds__(256) k_get_rows(const GetRowsArgs a) {
     const int64_t r = blockIdx.x;     // flattened (i10, i11, i12)
-    if (a.step_dst && blockIdx.x == 0 && threadIdx.x < 3) a.step_dst[1 + threadIdx.x] = a.step_vals[threadIdx.x];
     const int64_t i10 = r % a.idx.ne[0], i11 = (r / a.idx.ne[0]) % a.idx.ne[1], i12 = r / (a.idx.ne[0]*a.idx.ne[1]);
     const int32_t row = *(const int32_t *) (a.idx.data + i10*a.idx.nb[0] + i11*a.idx.nb[1] + i12*a.idx.nb[2]);
     float * dst = (float *) (a.d.data + i10*a.d.nb[1] + i11*a.d.nb[2] + i12*a.d.nb[3]);
@@ -312,13 +310,8 @@ static int get_rows_impl(mi355x_ctx * ctx, const mi355x_tensor * s, const mi355x
     if (idx->type != MI355X_TYPE_I32 || d->type != MI355X_TYPE_F32 || d->nb[0] != 4) return MI355X_E_UNSUPPORTED;
     const int64_t nr = idx->ne[0]*idx->ne[1]*idx->ne[2];
     if (nr == 0) return 0;
-    GetRowsArgs k = { to_d(s), to_d(idx), to_d(d), s->type, 0, nullptr, 0, nullptr, 0, nullptr, { 0, 0, 0 } };
+    GetRowsArgs k = { to_d(s), to_d(idx), to_d(d), s->type, 0, nullptr, 0, nullptr, 0 };
     if (add) { k.add = (const char *) add->data; k.add_nb1 = add->nb[1]; k.add_idx = (const int32_t *) add_idx->data; k.add_rows = add->ne[1]; }
-    if (add && ctx->step_armed) {          // the first launch of a decode step carries this step's two numbers into the step block
-        ctx->step_armed = false;
-        k.step_dst = ctx->step_dev;
-        for (int i = 0; i < 3; i++) k.step_vals[i] = ctx->step_host[1 + i];
-    }
     const double bytes = (double) nr * (mi355x_type_row_bytes(s->type, s->ne[0]) + s->ne[0]*4.0);
     const dim3 g((uint32_t) nr), b(256);
     if (mi355x_type_is_quantized(s->type)) {

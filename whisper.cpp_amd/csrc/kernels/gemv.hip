@@ -384,9 +384,7 @@ extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         o.w = g.w; o.N = g.N; o.nbt = wt == MI355X_TYPE_F16 ? 0 : (int64_t) g.N * (K / blk);
         o.bias = g.ep.bias; o.scale = g.ep.scale; o.has_scale = g.ep.has_scale; o.gelu = g.ep.gelu;
         o.residual = g.ep.residual; o.res_nb1 = g.ep.residual_nb1;
-        if (g.dst_step_slot < 0 || g.dst_step_slot >= MI355X_STEP_SLOTS) return MI355X_E_UNSUPPORTED;
-        // (this kernel takes the destination by value: the step offset is resolved on the host)
-        o.dst = (char *) g.dst + ctx->step_host[g.dst_step_slot]; o.dst_nb1 = g.dst_nb1; o.dst_f16 = g.dst_type == MI355X_TYPE_F16;
+        o.dst = g.dst; o.dst_nb1 = g.dst_nb1; o.dst_f16 = g.dst_type == MI355X_TYPE_F16;
         ntot += g.N;
         wbytes += wt == MI355X_TYPE_F16 ? (double) g.N * K * 2 : (double) mi355x_type_row_bytes(wt, K) * g.N;
     }

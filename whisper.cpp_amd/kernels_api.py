@@ -22,7 +22,7 @@ SYMBOLS = [
     "mi355x_last_error", "mi355x_record_begin", "mi355x_record_count", "mi355x_record_end", "mi355x_prof_enable", "mi355x_prof_report",
     "mi355x_prof_reset", "mi355x_type_is_quantized", "mi355x_type_row_bytes", "mi355x_repack_to_planar",
     "mi355x_repack_from_planar", "mi355x_mul_mat", "mi355x_prep_act", "mi355x_gemm_f16act", "mi355x_dequant_f16", "mi355x_gemv_fused",
-    "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_partial_step", "mi355x_flash_attn_combine", "mi355x_step_set", "mi355x_step_device", "mi355x_step_host", "mi355x_step_upload", "mi355x_step_arm", "mi355x_step_armed", "mi355x_ln_q_attn_partial", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
+    "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_combine", "mi355x_ln_q_attn_partial", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
     "mi355x_get_rows", "mi355x_get_rows_add", "mi355x_im2col_1d", "mi355x_soft_max", "mi355x_rope", "mi355x_concat", "mi355x_memset", "mi355x_checksum", "mi355x_log_mel", "mi355x_log_mel_n_len", "mi355x_debug_read_stamps", "mi355x_wake",
 ]
 
@@ -38,7 +38,7 @@ class Epilogue(C.Structure):
 
 class GemvSeg(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wtype", C.c_int32), ("N", C.c_int32), ("ep", Epilogue), ("dst", C.c_void_p),
-                ("dst_type", C.c_int32), ("dst_step_slot", C.c_int32), ("dst_nb1", C.c_int64)]
+                ("dst_type", C.c_int32), ("reserved", C.c_int32), ("dst_nb1", C.c_int64)]
 
 
 class GemvDesc(C.Structure):
@@ -92,14 +92,6 @@ def lib() -> C.CDLL:
         L.mi355x_flash_attn_ext.argtypes = [C.c_void_p, TP, TP, TP, TP, TP, C.c_float]
         L.mi355x_flash_attn_ext_exact.argtypes = [C.c_void_p, TP, TP, TP, TP, TP, C.c_float, C.c_int]
         L.mi355x_flash_attn_partial.argtypes = [C.c_void_p, TP, TP, TP, TP, C.c_float, C.POINTER(AttnPartials)]
-        L.mi355x_flash_attn_partial_step.argtypes = [C.c_void_p, TP, TP, TP, TP, C.c_float, C.c_int, C.c_int, C.POINTER(AttnPartials)]
-        L.mi355x_step_set.argtypes = [C.c_void_p, C.c_int, C.c_int64]
-        L.mi355x_step_device.restype = C.c_void_p
-        L.mi355x_step_device.argtypes = [C.c_void_p]
-        L.mi355x_step_host.restype = C.POINTER(C.c_int64)
-        L.mi355x_step_host.argtypes = [C.c_void_p]
-        L.mi355x_step_upload.argtypes = [C.c_void_p]
-        L.mi355x_step_arm.argtypes = [C.c_void_p, C.c_int]
         L.mi355x_flash_attn_combine.argtypes = [C.c_void_p, C.POINTER(AttnPartials), TP]
         L.mi355x_ln_q_attn_partial.argtypes = [C.c_void_p, C.POINTER(GemvDesc), TP, TP, TP, C.c_float, C.POINTER(AttnPartials)]
         L.mi355x_norm.argtypes = [C.c_void_p, TP, TP, C.c_float, C.c_void_p, C.c_void_p]
