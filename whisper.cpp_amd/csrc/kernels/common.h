@@ -36,6 +36,7 @@ struct mi355x_ctx {
     size_t      scratch_used = 0;        // bump pointer, reset per op group
     std::vector<void *> scratch_retired; // outgrown arenas that may still back pointers of the current op group
     float *     mel_tab = nullptr;       // sin / cos / Hann tables + the running maximum of mi355x_log_mel (device)
+    uint64_t    n_eager = 0;             // launches issued directly on the stream so far (mi355x_eager_count)
     // recording
     bool                        recording = false;
     bool                        record_invalid = false;

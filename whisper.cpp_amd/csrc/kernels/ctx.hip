@@ -183,6 +183,7 @@ int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 gri
     int ev = -1;
     void * kargs[1] = { (void *) args };
     hipError_t e;
+    ctx->n_eager++;
     if (ctx->prof) {
         // hipExtLaunchKernel attaches the two events to the dispatch itself: they carry the kernel's own begin / end
         // timestamps (what rocprofv3 --kernel-trace reports), not the time of separately enqueued event markers,
@@ -225,6 +226,7 @@ int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 gri
 }
 
 extern "C" int  mi355x_record_count(mi355x_ctx * ctx) { return ctx->recording ? (int) ctx->plan.size() : 0; }
+extern "C" uint64_t mi355x_eager_count(mi355x_ctx * ctx) { return ctx->n_eager; }
 extern "C" void mi355x_record_begin(mi355x_ctx * ctx) { ctx->recording = true; ctx->record_invalid = false; ctx->plan.clear(); ctx->blob.clear(); }
 extern "C" int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size) {
     ctx->recording = false;
