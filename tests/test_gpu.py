@@ -612,7 +612,8 @@ def test_plugin_op_parity_against_reference_cpu_backend(plugin_env, tmp_path):
     """every hot-path op, node mode (ggml_backend_compare_graph_backend) and scheduler mode (fusion + hipGraph replay).
     STRICT: an op the plugin does not support aborts instead of running on the reference CPU backend (which would compare the
     CPU with itself), and the driver asserts that the scheduler produced ONE split — everything on the plugin."""
-    env = dict(plugin_env, GGML_MI355X_STRICT="1", OP_PARITY_ASSERT_SPLITS="1")
+    # GGML_MI355X_GRAPHS=1: the opt-in hipGraph replay stays covered here (second scheduler pass of every case = a replay)
+    env = dict(plugin_env, GGML_MI355X_STRICT="1", OP_PARITY_ASSERT_SPLITS="1", GGML_MI355X_GRAPHS="1")
     out = tmp_path / "op_parity.jsonl"
     with open(out, "w") as f:
         r = subprocess.run([str(_native("op_parity"))], env=env, stdout=f, stderr=subprocess.PIPE, text=True, timeout=1500)

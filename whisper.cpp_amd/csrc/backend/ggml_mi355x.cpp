@@ -1214,7 +1214,13 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
     if (!k) { GGML_LOG_ERROR("ggml-mi355x: failed to create kernel context on device %d: %s\n", d->index, mi355x_last_error()); return nullptr; }
     mi_backend_ctx * b = new mi_backend_ctx();
     b->device = d->index; b->k = k; b->name = d->name;
-    b->fuse = env_flag("GGML_MI355X_FUSE", true); b->graphs = env_flag("GGML_MI355X_GRAPHS", true); b->prof = env_flag("GGML_MI355X_PROF", false);
+    // hipGraph replay of the recorded launch sequence is OPT-IN (GGML_MI355X_GRAPHS=1).  Measured on large-v3 Q5_0, ROCm 7.2
+    // (profiles/r02_decode_launch_mode_sweep.txt, r02_stream_scaling_graphs_vs_eager.txt): plain launches 1.473 ms/token and 2.59
+    // chunks/s against 1.515 ms/token and 2.40-2.50 chunks/s with segmented graph replay, and no worse at 2-8 concurrent streams —
+    // the replayed (packet-captured) nodes cost ~0.2 us more each on the GPU than the same kernels launched directly, and at ~5 us
+    // per dependent kernel the host's 3.5 us per launch never becomes the bottleneck.  Replay still buys host CPU time (0.8 ms ->
+    // 0.1 ms per decode step): worth it only where host threads are scarcer than here.
+    b->fuse = env_flag("GGML_MI355X_FUSE", true); b->graphs = env_flag("GGML_MI355X_GRAPHS", false); b->prof = env_flag("GGML_MI355X_PROF", false);
     b->exact = env_flag("GGML_MI355X_EXACT", false);
     if (b->exact) b->graphs = false;          // a test mode: thousands of small launches per graph, replay buys nothing
     if (b->prof) mi355x_prof_enable(k, 1);
