@@ -1182,8 +1182,10 @@ struct QAArgs {
     const uint16_t * dummy;                                                            // any valid address (absent bias / mask)
 };
 
-template <int WT>
-__global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
+// NW = waves per workgroup (8 or 16): RW = 64 / NW rows of W_q and KW = 128 / NW keys per wave
+template <int WT, int NW>
+__global__ void __launch_bounds__(NW * 64) k_qattn(const QAArgs a) {
+    constexpr int RW = 64 / NW, KW = 128 / NW, KI = KW / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1193,46 +1195,46 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     // once per XCD — halves the PMC traffic but measured 8.4 -> 10.6 us: the head's 393 KB of K/V then also funnel through one
     // XCD.  Plain 2-D grid.)
     const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2, p = blockIdx.x;
-    const int kbeg = p*128 + wave*16;
+    const int kbeg = p*128 + wave*KW;
 
     // ---- load burst: activations, LN vectors, bias, K/V rows, mask, then the weights --------------------------------
     const int e4c = tid < K4 ? tid : K4 - 1;
     const float4 xv = *(const float4 *) (a.x + e4c*4);
     const float4 lw = *(const float4 *) (a.ln_w + e4c*4);
     const float4 lb = *(const float4 *) (a.ln_b + e4c*4);
-    const int qrow0 = hq*64 + wave*8;                                  // this wave's 8 rows of W_q
-    const float * bptr = a.bias ? a.bias + qrow0 + (lane & 7) : (const float *) a.dummy;
+    const int qrow0 = hq*64 + wave*RW;                                 // this wave's RW rows of W_q
+    const float * bptr = a.bias ? a.bias + qrow0 + (lane & (RW - 1)) : (const float *) a.dummy;
     const float bias_v = *bptr;
     const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2] + dc*16;
     const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2] + dc*16;
     const char * mbase = a.has_mask ? a.m.data : (const char *) a.dummy;
-    uint4 kr[2], vr[2]; uint16_t mkh[2];
+    uint4 kr[KI], vr[KI]; uint16_t mkh[KI];
     #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < KI; i++) {
         const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
         kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k.nb[1]);
         vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v.nb[1]);
         mkh[i] = *(const uint16_t *) (mbase + (a.has_mask ? (int64_t) kc*2 : 0));
     }
     __builtin_amdgcn_sched_barrier(0);
-    wblk<WT> wr[8];
+    wblk<WT> wr[RW];
     {
         const int gc = lane < nb ? lane : nb - 1;
         #pragma unroll
-        for (int r = 0; r < 8; r++) {
+        for (int r = 0; r < RW; r++) {
             if constexpr (Q4K) wblk_load_q4k(wr[r], (const char *) a.w, a.nbt, qrow0 + r, nsb, gc);
             else               wblk_load<WT>(wr[r], (const char *) a.w, a.nbt, (int64_t) (qrow0 + r) * nb + gc);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    float * red = (float *) smem;                                       // [2][8]
-    float * qs  = red + 16;                                             // [64] projected, f16-rounded q of this head
-    float * wo  = qs + 64;                                              // [8 waves][64] + [8][2] wave partials
-    float * wml = wo + 8*64;
-    uint32_t * lo = (uint32_t *) (smem + 4096);                          // Q4_K: the four Q8_K planes [4][K/64] uint4
+    float * red = (float *) smem;                                       // [2][NW]
+    float * qs  = red + 2*NW;                                           // [64] projected, f16-rounded q of this head
+    float * wo  = qs + 64;                                              // [NW waves][64] + [NW][2] wave partials
+    float * wml = wo + NW*64;
+    uint32_t * lo = (uint32_t *) (smem + 8192);                          // Q4_K: the four Q8_K planes [4][K/64] uint4
     uint32_t * hi = lo + (size_t) nb*4;
-    float * dx = Q4K ? (float *) (smem + 4096 + (size_t) K) : (float *) (hi + (size_t) nb*4);
+    float * dx = Q4K ? (float *) (smem + 8192 + (size_t) K) : (float *) (hi + (size_t) nb*4);
     int *   sx = Q4K ? (int *) (dx + nsb) : (int *) (dx + nb);          // Q4_K: per-32-element sums
 
     // ---- LayerNorm + Q8_0 quantization of the activation (ggml-cpu/ops.cpp:3698-3765, arch/x86/quants.c:302-398) ----
@@ -1243,16 +1245,16 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
         __syncthreads();
         float rs = 0.0f;
         #pragma unroll
-        for (int w = 0; w < 8; w++) rs += red[w];
+        for (int w = 0; w < NW; w++) rs += red[w];
         const float mean = rs / K;
         const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
         float pv = tid < K4 ? (d0*d0 + d1*d1) + (d2*d2 + d3*d3) : 0.0f;
         pv = wave_sum(pv);
-        if (lane == 0) red[8 + wave] = pv;
+        if (lane == 0) red[NW + wave] = pv;
         __syncthreads();
         float rv = 0.0f;
         #pragma unroll
-        for (int w = 0; w < 8; w++) rv += red[8 + w];
+        for (int w = 0; w < NW; w++) rv += red[NW + w];
         const float rstd = 1.0f / sqrtf(rv / K + a.eps);
         if (tid < K4) {
             float o[4] = { d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd };
@@ -1264,23 +1266,23 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     }
     __syncthreads();
 
-    // ---- q_h: 8 rows per wave ----------------------------------------------------------------------------------------
+    // ---- q_h: RW rows per wave ---------------------------------------------------------------------------------------
     {
         const int gc = lane < nb ? lane : nb - 1;
         float qv = 0.0f;
         if constexpr (Q4K) {
             #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < RW; r++) {
                 float a1[1] = { 0.0f }, am1[1] = { 0.0f };
                 wblk_dot_q4k<1>(wr[r], gc, lane < nb ? 1.0f : 0.0f, nb, nsb, (const uint4 *) lo, dx, sx, a1, am1);
                 const float acc = wave_sum(a1[0] + am1[0]);
-                qv = (lane & 7) == r ? acc : qv;
+                qv = (lane & (RW - 1)) == r ? acc : qv;
             }
         } else {
             const uint4 al = ((const uint4 *) lo)[gc], ah = ((const uint4 *) hi)[gc];
             const float dxa = dx[gc]; const int sxa = sx[gc];
             #pragma unroll
-            for (int r = 0; r < 8; r++) {
+            for (int r = 0; r < RW; r++) {
                 uint32_t vlo[4], vhi[4];
                 wblk_unpack<WT>(wr[r], vlo, vhi);
                 const float dw = lane < nb ? h2f(wr[r].d) : 0.0f;
@@ -1296,25 +1298,25 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
                 sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
                 if (off) sum -= off * sxa;
                 const float acc = wave_sum(fmaf(dw * dxa, (float) sum, 0.0f));
-                qv = (lane & 7) == r ? acc : qv;                        // lane r (mod 8) keeps row r
+                qv = (lane & (RW - 1)) == r ? acc : qv;                 // lane r (mod RW) keeps row r
             }
         }
-        if (lane < 8) {
+        if (lane < RW) {
             float v = qv;
             if (a.bias)       v = v + bias_v;
             if (a.has_qscale) v = v * a.qscale;
-            qs[wave*8 + lane] = round_f16(v);                           // the attention rounds q to f16 (q_to_vec_dot)
+            qs[wave*RW + lane] = round_f16(v);                           // the attention rounds q to f16 (q_to_vec_dot)
         }
     }
     __syncthreads();
 
-    // ---- attention over this wave's 16 keys (k_fattn_dec with 2 keys per lane) ------------------------------------------
+    // ---- attention over this wave's KW keys (k_fattn_dec with KI keys per lane) ------------------------------------------
     float qf[8];
     #pragma unroll
     for (int e = 0; e < 8; e++) qf[e] = qs[dc*8 + e];
-    float sc[2];
+    float sc[KI];
     #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < KI; i++) {
         const int key = kbeg + kg + 8*i;
         const uint32_t w[4] = { kr[i].x, kr[i].y, kr[i].z, kr[i].w };
         float s = 0.0f;
@@ -1324,13 +1326,16 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
         const float x = s * a.scale + (a.has_mask ? h2f(mkh[i]) : 0.0f);
         sc[i] = key < a.n_kv ? x : -INFINITY;
     }
-    float m = stride8_max(fmaxf(sc[0], sc[1]));
+    float m = sc[0];
+    #pragma unroll
+    for (int i = 1; i < KI; i++) m = fmaxf(m, sc[i]);
+    m = stride8_max(m);
     m = fmaxf(m, -1e30f);
     float l = 0.0f, o[8];
     #pragma unroll
     for (int e = 0; e < 8; e++) o[e] = 0.0f;
     #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < KI; i++) {
         const float pk = __expf(sc[i] - m);
         l += pk;
         const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
@@ -1352,10 +1357,10 @@ __global__ void __launch_bounds__(512) k_qattn(const QAArgs a) {
     if (tid < 64) {
         float M = -1e30f;
         #pragma unroll
-        for (int w = 0; w < 8; w++) M = fmaxf(M, wml[w*2]);
+        for (int w = 0; w < NW; w++) M = fmaxf(M, wml[w*2]);
         float O = 0.0f, L = 0.0f;
         #pragma unroll
-        for (int w = 0; w < 8; w++) {
+        for (int w = 0; w < NW; w++) {
             const float ww = __expf(wml[w*2] - M);
             O = fmaf(ww, wo[w*64 + tid], O);
             L = fmaf(ww, wml[w*2 + 1], L);
@@ -1392,16 +1397,23 @@ extern "C" int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc
     a.part_o  = (float *) mi355x_scratch_alloc(ctx, nrec * 64 * 4);
     a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
     if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
-    const dim3 grid(a.nparts, H), block(512);
-    const uint32_t lds = 4096 + (uint32_t) dg_act_bytes(wt, K, 1) + 64;
+    // 16 waves per workgroup: 4 rows of W_q and 8 keys per wave instead of 8 and 16 (the row loop is the kernel's longest serial part)
+    static const int nw = getenv("GGML_MI355X_QATTN_WAVES") ? atoi(getenv("GGML_MI355X_QATTN_WAVES")) : 8;
+    const dim3 grid(a.nparts, H), block(nw == 16 ? 1024 : 512);
+    const uint32_t lds = 8192 + (uint32_t) dg_act_bytes(wt, K, 1) + 64;
     const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) mi355x_type_row_bytes(wt, K) * N + (double) K*4 + (double) nrec*66*4;
     const double flops = 4.0 * (double) n_kv * 64 * H + 2.0 * (double) N * K;
     int rc;
-    switch (wt) {
-        case MI355X_TYPE_Q4_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_0>, grid, block, lds, a, bytes, flops); break;
-        case MI355X_TYPE_Q5_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q5_0>, grid, block, lds, a, bytes, flops); break;
-        case MI355X_TYPE_Q4_K: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_K>, grid, block, lds, a, bytes, flops); break;
-        default:               rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q8_0>, grid, block, lds, a, bytes, flops); break;
+    if (nw == 16) switch (wt) {
+        case MI355X_TYPE_Q4_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_0, 16>, grid, block, lds, a, bytes, flops); break;
+        case MI355X_TYPE_Q5_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q5_0, 16>, grid, block, lds, a, bytes, flops); break;
+        case MI355X_TYPE_Q4_K: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_K, 16>, grid, block, lds, a, bytes, flops); break;
+        default:               rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q8_0, 16>, grid, block, lds, a, bytes, flops); break;
+    } else switch (wt) {
+        case MI355X_TYPE_Q4_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_0, 8>, grid, block, lds, a, bytes, flops); break;
+        case MI355X_TYPE_Q5_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q5_0, 8>, grid, block, lds, a, bytes, flops); break;
+        case MI355X_TYPE_Q4_K: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_K, 8>, grid, block, lds, a, bytes, flops); break;
+        default:               rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q8_0, 8>, grid, block, lds, a, bytes, flops); break;
     }
     if (rc) return rc;
     out->part_o = a.part_o; out->part_ml = a.part_ml; out->nparts = a.nparts; out->T = 1; out->H = H;
