@@ -197,13 +197,6 @@ typedef struct mi355x_attn_partials {
 MI355X_API int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                                          const mi355x_tensor * mask /* nullable */, float scale, mi355x_attn_partials * out);
 MI355X_API int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_partials * p, const mi355x_tensor * dst);
-/* Decoder cross-attention in one launch (T = 1): q = scale_q * (W_q . LayerNorm(x) + bias) is recomputed per (head, 128-key
- * chunk) workgroup and fed straight into mi355x_flash_attn_partial's arithmetic (src/whisper.cpp:2684-2726 =
- * ggml_norm, mul, add, mul_mat, add, scale, flash_attn_ext).  `qproj` describes the projection exactly like a
- * mi355x_gemv_fused call would (has_norm = 1, one segment, N = H*64; seg[0].dst is not written). */
-MI355X_API int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc * qproj, const mi355x_tensor * k, const mi355x_tensor * v,
-                                        const mi355x_tensor * mask /* nullable */, float scale, mi355x_attn_partials * out);
-
 /* ggml_flash_attn_ext (ggml/src/ggml.c:5418-5460; CPU ggml-cpu/ops.cpp:8479-8715).
  * q: F32 [D, T, H] (any nb1/nb2), k/v: F16 [D, n_kv, H] views, mask: F16 [n_kv, >=T] or NULL,
  * dst: F32 [D, H, T].  D must be 64 (all Whisper models).  softmax(scale*q.k + mask) . v */

@@ -507,67 +507,6 @@ def test_attention_partials_feed_the_projection(gpu, oracle, T, n_kv, H):
     assert nmse(want, y_d.cpu().numpy()) < 1e-9
 
 
-@pytest.mark.parametrize("t", ["q5_0", "q8_0", "q4_0", "q4_K"])
-@pytest.mark.parametrize("n_kv", [1536, 130])
-def test_fused_ln_q_attention_matches_unfused_sequence(gpu, oracle, t, n_kv):
-    """k_qattn (LayerNorm + Q projection + decode attention in one launch, T = 1) against the oracle's
-    norm -> affine -> mul_mat -> +bias -> *scale -> flash_attn sequence, and bit-for-bit against our own unfused kernels"""
-    ctx, ka, torch = gpu
-    tid = QT[t]
-    H, D = 20, 64
-    K = N = H * D
-    rng = np.random.default_rng(n_kv + tid)
-    x = (rng.standard_normal((1, K)) * 1.5).astype(np.float32)
-    lw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
-    lb = (0.1 * rng.standard_normal(K)).astype(np.float32)
-    wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
-    blocks, planar = quantize(oracle, ka, tid, wf)
-    bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
-    qscale = 0.35355339
-    k = (rng.standard_normal((n_kv, H, D)) * 0.6).astype(np.float16)
-    v = rng.standard_normal((n_kv, H, D)).astype(np.float16)
-    # oracle sequence
-    nx = np.empty_like(x)
-    oracle.oracle_norm(ptr(x), ptr(nx), K, 1, 1e-5)
-    nx = (nx * lw[None, :]).astype(np.float32) + lb[None, :]
-    qref = np.empty((1, N), dtype=np.float32)
-    oracle.oracle_mul_mat(tid, ptr(blocks), ptr(np.ascontiguousarray(nx)), ptr(qref), K, N, 1)
-    qref = ((qref + bias[None, :]).astype(np.float32) * np.float32(qscale)).astype(np.float32)
-    att = np.empty((1, H, D), dtype=np.float32)
-    oracle.oracle_flash_attn(ptr(np.ascontiguousarray(qref.reshape(1, H, D))), ptr(k.view(np.uint16)), ptr(v.view(np.uint16)), None, ptr(att), D, 1, H, n_kv, qscale)
-    # fused launch
-    x_d, lw_d, lb_d, w_d, b_d, k_d, v_d = (dev(torch, a) for a in (x, lw, lb, planar, bias, k, v))
-    d = ka.GemvDesc()
-    d.x, d.x_nb1, d.K, d.T, d.has_norm, d.eps = x_d.data_ptr(), K * 4, K, 1, 1, 1e-5
-    d.ln_w, d.ln_b, d.nseg = lw_d.data_ptr(), lb_d.data_ptr(), 1
-    d.seg[0].w, d.seg[0].wtype, d.seg[0].N = w_d.data_ptr(), tid, N
-    d.seg[0].ep = ka.Epilogue(b_d.data_ptr(), qscale, 1, 0, None, 0)
-    tk = ka.tensor(k_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
-    tv = ka.tensor(v_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
-    parts = ka.AttnPartials()
-    ctx.check(ka.lib().mi355x_ln_q_attn_partial(ctx.h, C.byref(d), C.byref(tk), C.byref(tv), None, qscale, C.byref(parts)), "ln_q_attn_partial")
-    o_d = torch.zeros((1, H, D), dtype=torch.float32, device="cuda:0")
-    torch.cuda.synchronize()
-    to = ka.tensor(o_d.data_ptr(), ka.F32, [D, H, 1])
-    ctx.check(ka.lib().mi355x_flash_attn_combine(ctx.h, C.byref(parts), C.byref(to)), "combine")
-    ctx.sync()
-    got = o_d.cpu().numpy()
-    assert nmse(att, got) < 1e-4, nmse(att, got)
-    # unfused: our mat-vec (LN fused) then our attention on its output
-    q_d = torch.zeros((1, N), dtype=torch.float32, device="cuda:0")
-    torch.cuda.synchronize()
-    d.seg[0].dst, d.seg[0].dst_type, d.seg[0].dst_nb1 = q_d.data_ptr(), ka.F32, N * 4
-    ctx.check(ka.lib().mi355x_gemv_fused(ctx.h, C.byref(d)), "gemv")
-    tq = ka.tensor(q_d.data_ptr(), ka.F32, [D, 1, H], [4, H * D * 4, D * 4, H * D * 4])
-    o2 = torch.zeros((1, H, D), dtype=torch.float32, device="cuda:0")
-    torch.cuda.synchronize()
-    to2 = ka.tensor(o2.data_ptr(), ka.F32, [D, H, 1])
-    ctx.check(ka.lib().mi355x_flash_attn_ext(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), None, C.byref(to2), qscale), "fattn")
-    ctx.sync()
-    assert nmse(qref, q_d.cpu().numpy()) < 1e-9
-    assert nmse(o2.cpu().numpy(), got) < 1e-10          # same q bits; only the key partition of the softmax differs
-
-
 def test_flash_attn_full_size_property(gpu):
     """encoder size (T = 1500, n_kv = 1536 incl. zero-padded keys, 20 heads): with V == 1 every output must be exactly 1
     up to rounding (softmax rows sum to one), and the zero pad keys must take softmax mass like the reference's do."""

@@ -655,7 +655,6 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
         n++;
     }
     if (n != nuse) return false;
-    const int j_after = j;                                   // first real node after the last chain
     mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
     d.x = (const float *) x->data; d.x_nb1 = (int64_t) x->nb[1]; d.K = (int) K; d.T = (int) T;
     d.has_norm = 1; memcpy(&d.eps, ln.norm->op_params, sizeof(float)); d.ln_w = ln.w; d.ln_b = ln.b; d.nseg = n;
@@ -670,32 +669,9 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
         sg.dst = ch[s].last->data; sg.dst_type = (int32_t) ch[s].last->type;
         sg.dst_nb1 = ch[s].last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch[s].last == ch[s].mm ? (int64_t) ch[s].mm->nb[1] : (int64_t) ch[s].last->nb[1]);
     }
-    // cross-attention, T = 1: LN -> Q projection -> flash_attn_ext whose q is a pure view of the projection's result and
-    // nothing else reads it => one launch computes the attention partials directly (k_qattn)
-    if (n == 1 && T == 1 && b->fuse && !b->exact && j_after < g->n_nodes && g->nodes[j_after]->op == GGML_OP_FLASH_ATTN_EXT) {
-        const ggml_tensor * fa = g->nodes[j_after], * q = fa->src[0], * qsrc = ch[0].last;
-        bool ok = q->view_src == qsrc && q->view_offs == 0 && qsrc->type == GGML_TYPE_F32 && ggml_is_contiguous(qsrc) && !qsrc->view_src &&
-                  q->ne[0] == 64 && q->ne[1] == 1 && q->ne[3] == 1 && q->ne[2]*64 == qsrc->ne[0] && q->nb[0] == 4 && q->nb[2] == 64*4 &&
-                  use_count(g, qsrc) == 1 && !(qsrc->flags & GGML_TENSOR_FLAG_OUTPUT) && !fa->src[4] && ggml_is_contiguous(fa) && fa->type == GGML_TYPE_F32;
-        for (const ggml_tensor * t = q; ok && t != qsrc; t = t->src[0]) {             // the view chain q -> ... -> projection result
-            if (!op_is_empty(t) || !t->src[0] || use_count(g, t) != 1 || (t->flags & GGML_TENSOR_FLAG_OUTPUT)) ok = false;
-        }
-        if (ok) {
-            float max_bias, softcap, scale;
-            memcpy(&scale, fa->op_params, 4); memcpy(&max_bias, (const float *) fa->op_params + 1, 4); memcpy(&softcap, (const float *) fa->op_params + 2, 4);
-            if (max_bias == 0.0f && softcap == 0.0f) {
-                mi355x_tensor mk = to_mt(fa->src[1]), mv = to_mt(fa->src[2]), mm_;
-                if (fa->src[3]) mm_ = to_mt(fa->src[3]);
-                mi355x_attn_partials parts;
-                const int rc = mi355x_ln_q_attn_partial(b->k, &d, &mk, &mv, fa->src[3] ? &mm_ : nullptr, scale, &parts);
-                if (rc != MI355X_E_UNSUPPORTED) {
-                    rc_out = rc; end_out = j_after;
-                    if (rc == 0) attn_consume(b, g, j_after, parts, end_out, rc_out);
-                    return true;
-                }
-            }
-        }
-    }
+    // (A one-launch "LN + Q projection + cross-attention" kernel existed in round 1.  Re-measured with plain launches it LOSES to the
+    //  two launches it replaced, 1.478 -> 1.435 ms/token with it switched off (profiles/r02_decode_env_sweep_final.txt): 64 rows of
+    //  W_q per workgroup serialise what 256 workgroups otherwise do in parallel, and a dependent boundary costs only ~1.5 us.  Removed.)
     const int rc = mi355x_gemv_fused(b->k, &d);
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = ch[n - 1].end;

@@ -1165,261 +1165,6 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------------
-// k_qattn: LayerNorm + Q projection + decode attention in ONE launch (decoder cross-attention, T = 1,
-// src/whisper.cpp:2684-2726).  Workgroup (chunk c, head h), 8 waves: recomputes the 64 rows of W_q that make up head h
-// (56 KB of Q5_0 weights, identical for the workgroups of all key chunks of that head: one HBM read, the rest L2 hits),
-// then attends to its 128 keys exactly like k_fattn_dec and leaves the same partial record.  Replaces the separate
-// "LN + Q_cross" mat-vec: one launch (~4.5 us + ~1.1 us boundary) less per decoder layer.
-// Same arithmetic as the unfused sequence: LN -> Q8_0 activations -> int8 dots -> +bias -> *scale -> f16 rounding of q
-// -> f32 scores, softmax, f32 P.V.
-// ---------------------------------------------------------------------------------------------------
-struct QAArgs {
-    const float * x; const float * ln_w; const float * ln_b; float eps; int K;         // activation row (T = 1) and LayerNorm
-    const void * w; int64_t nbt; const float * bias; float qscale; int has_qscale;     // W_q [K, H*64] planar, bias, ggml_scale
-    dtensor k, v, m; int has_mask; float scale; int n_kv, H, rk2, rv2, nparts;
-    float * part_o; float * part_ml;
-    const uint16_t * dummy;                                                            // any valid address (absent bias / mask)
-};
-
-// NW = waves per workgroup (8 or 16): RW = 64 / NW rows of W_q and KW = 128 / NW keys per wave
-template <int WT, int NW>
-__global__ void __launch_bounds__(NW * 64) k_qattn(const QAArgs a) {
-    constexpr int RW = 64 / NW, KW = 128 / NW, KI = KW / 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int K = a.K, nb = Q4K ? K >> 6 : K >> 5, K4 = K >> 2, nsb = K >> 8;     // nb = lane-units per row (Q4_K: 64-element chunks)
-    const int kg = lane >> 3, dc = lane & 7;
-    // (an XCD-aware order — all key chunks of a head on one XCD, so that W_q of the head is fetched from HBM once instead of
-    // once per XCD — halves the PMC traffic but measured 8.4 -> 10.6 us: the head's 393 KB of K/V then also funnel through one
-    // XCD.  Plain 2-D grid.)
-    const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2, p = blockIdx.x;
-    const int kbeg = p*128 + wave*KW;
-
-    // ---- load burst: activations, LN vectors, bias, K/V rows, mask, then the weights --------------------------------
-    const int e4c = tid < K4 ? tid : K4 - 1;
-    const float4 xv = *(const float4 *) (a.x + e4c*4);
-    const float4 lw = *(const float4 *) (a.ln_w + e4c*4);
-    const float4 lb = *(const float4 *) (a.ln_b + e4c*4);
-    const int qrow0 = hq*64 + wave*RW;                                 // this wave's RW rows of W_q
-    const float * bptr = a.bias ? a.bias + qrow0 + (lane & (RW - 1)) : (const float *) a.dummy;
-    const float bias_v = *bptr;
-    const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2] + dc*16;
-    const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2] + dc*16;
-    const char * mbase = a.has_mask ? a.m.data : (const char *) a.dummy;
-    uint4 kr[KI], vr[KI]; uint16_t mkh[KI];
-    #pragma unroll
-    for (int i = 0; i < KI; i++) {
-        const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
-        kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k.nb[1]);
-        vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v.nb[1]);
-        mkh[i] = *(const uint16_t *) (mbase + (a.has_mask ? (int64_t) kc*2 : 0));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    wblk<WT> wr[RW];
-    {
-        const int gc = lane < nb ? lane : nb - 1;
-        #pragma unroll
-        for (int r = 0; r < RW; r++) {
-            if constexpr (Q4K) wblk_load_q4k(wr[r], (const char *) a.w, a.nbt, qrow0 + r, nsb, gc);
-            else               wblk_load<WT>(wr[r], (const char *) a.w, a.nbt, (int64_t) (qrow0 + r) * nb + gc);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    float * red = (float *) smem;                                       // [2][NW]
-    float * qs  = red + 2*NW;                                           // [64] projected, f16-rounded q of this head
-    float * wo  = qs + 64;                                              // [NW waves][64] + [NW][2] wave partials
-    float * wml = wo + NW*64;
-    uint32_t * lo = (uint32_t *) (smem + 8192);                          // Q4_K: the four Q8_K planes [4][K/64] uint4
-    uint32_t * hi = lo + (size_t) nb*4;
-    float * dx = Q4K ? (float *) (smem + 8192 + (size_t) K) : (float *) (hi + (size_t) nb*4);
-    int *   sx = Q4K ? (int *) (dx + nsb) : (int *) (dx + nb);          // Q4_K: per-32-element sums
-
-    // ---- LayerNorm + Q8_0 quantization of the activation (ggml-cpu/ops.cpp:3698-3765, arch/x86/quants.c:302-398) ----
-    {
-        float ps = tid < K4 ? (xv.x + xv.y) + (xv.z + xv.w) : 0.0f;
-        ps = wave_sum(ps);
-        if (lane == 0) red[wave] = ps;
-        __syncthreads();
-        float rs = 0.0f;
-        #pragma unroll
-        for (int w = 0; w < NW; w++) rs += red[w];
-        const float mean = rs / K;
-        const float d0 = xv.x - mean, d1 = xv.y - mean, d2 = xv.z - mean, d3 = xv.w - mean;
-        float pv = tid < K4 ? (d0*d0 + d1*d1) + (d2*d2 + d3*d3) : 0.0f;
-        pv = wave_sum(pv);
-        if (lane == 0) red[NW + wave] = pv;
-        __syncthreads();
-        float rv = 0.0f;
-        #pragma unroll
-        for (int w = 0; w < NW; w++) rv += red[NW + w];
-        const float rstd = 1.0f / sqrtf(rv / K + a.eps);
-        if (tid < K4) {
-            float o[4] = { d0 * rstd, d1 * rstd, d2 * rstd, d3 * rstd };
-            o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
-            o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
-            if constexpr (Q4K) dg_q8_K_store(o, tid*4, 0, K, 1, lo, dx, sx);       // K % 256 == 0: whole waves take this branch
-            else               dg_q8_0_store(o, tid*4, 0, nb, lo, hi, dx, sx);
-        }
-    }
-    __syncthreads();
-
-    // ---- q_h: RW rows per wave ---------------------------------------------------------------------------------------
-    {
-        const int gc = lane < nb ? lane : nb - 1;
-        float qv = 0.0f;
-        if constexpr (Q4K) {
-            #pragma unroll
-            for (int r = 0; r < RW; r++) {
-                float a1[1] = { 0.0f }, am1[1] = { 0.0f };
-                wblk_dot_q4k<1>(wr[r], gc, lane < nb ? 1.0f : 0.0f, nb, nsb, (const uint4 *) lo, dx, sx, a1, am1);
-                const float acc = wave_sum(a1[0] + am1[0]);
-                qv = (lane & (RW - 1)) == r ? acc : qv;
-            }
-        } else {
-            const uint4 al = ((const uint4 *) lo)[gc], ah = ((const uint4 *) hi)[gc];
-            const float dxa = dx[gc]; const int sxa = sx[gc];
-            #pragma unroll
-            for (int r = 0; r < RW; r++) {
-                uint32_t vlo[4], vhi[4];
-                wblk_unpack<WT>(wr[r], vlo, vhi);
-                const float dw = lane < nb ? h2f(wr[r].d) : 0.0f;
-                constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
-                int sum = 0;
-                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
-                if (off) sum -= off * sxa;
-                const float acc = wave_sum(fmaf(dw * dxa, (float) sum, 0.0f));
-                qv = (lane & (RW - 1)) == r ? acc : qv;                 // lane r (mod RW) keeps row r
-            }
-        }
-        if (lane < RW) {
-            float v = qv;
-            if (a.bias)       v = v + bias_v;
-            if (a.has_qscale) v = v * a.qscale;
-            qs[wave*RW + lane] = round_f16(v);                           // the attention rounds q to f16 (q_to_vec_dot)
-        }
-    }
-    __syncthreads();
-
-    // ---- attention over this wave's KW keys (k_fattn_dec with KI keys per lane) ------------------------------------------
-    float qf[8];
-    #pragma unroll
-    for (int e = 0; e < 8; e++) qf[e] = qs[dc*8 + e];
-    float sc[KI];
-    #pragma unroll
-    for (int i = 0; i < KI; i++) {
-        const int key = kbeg + kg + 8*i;
-        const uint32_t w[4] = { kr[i].x, kr[i].y, kr[i].z, kr[i].w };
-        float s = 0.0f;
-        #pragma unroll
-        for (int e = 0; e < 4; e++) { s = fmaf(h2f((uint16_t) (w[e] & 0xFFFF)), qf[2*e], s); s = fmaf(h2f((uint16_t) (w[e] >> 16)), qf[2*e+1], s); }
-        s = group_sum<8>(s);
-        const float x = s * a.scale + (a.has_mask ? h2f(mkh[i]) : 0.0f);
-        sc[i] = key < a.n_kv ? x : -INFINITY;
-    }
-    float m = sc[0];
-    #pragma unroll
-    for (int i = 1; i < KI; i++) m = fmaxf(m, sc[i]);
-    m = stride8_max(m);
-    m = fmaxf(m, -1e30f);
-    float l = 0.0f, o[8];
-    #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = 0.0f;
-    #pragma unroll
-    for (int i = 0; i < KI; i++) {
-        const float pk = __expf(sc[i] - m);
-        l += pk;
-        const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
-        #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            o[2*e]   = fmaf(pk, h2f((uint16_t) (w[e] & 0xFFFF)), o[2*e]);
-            o[2*e+1] = fmaf(pk, h2f((uint16_t) (w[e] >> 16)),    o[2*e+1]);
-        }
-    }
-    l = stride8_sum(l);
-    #pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = stride8_sum(o[e]);
-    if (kg == 0) {
-        *(float4 *) &wo[wave*64 + dc*8]     = make_float4(o[0], o[1], o[2], o[3]);
-        *(float4 *) &wo[wave*64 + dc*8 + 4] = make_float4(o[4], o[5], o[6], o[7]);
-        if (dc == 0) { wml[wave*2] = m; wml[wave*2 + 1] = l; }
-    }
-    __syncthreads();
-    if (tid < 64) {
-        float M = -1e30f;
-        #pragma unroll
-        for (int w = 0; w < NW; w++) M = fmaxf(M, wml[w*2]);
-        float O = 0.0f, L = 0.0f;
-        #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const float ww = __expf(wml[w*2] - M);
-            O = fmaf(ww, wo[w*64 + tid], O);
-            L = fmaf(ww, wml[w*2 + 1], L);
-        }
-        const int64_t rec = (int64_t) hq * a.nparts + p;                // T == 1
-        a.part_o[rec*64 + tid] = O;
-        if (tid == 0) { a.part_ml[rec*2] = M; a.part_ml[rec*2 + 1] = L; }
-    }
-}
-
-extern "C" int mi355x_ln_q_attn_partial(mi355x_ctx * ctx, const mi355x_gemv_desc * d, const mi355x_tensor * k, const mi355x_tensor * v,
-                                        const mi355x_tensor * mask, float scale, mi355x_attn_partials * out) {
-    static const bool enabled = !(getenv("GGML_MI355X_QATTN") && !atoi(getenv("GGML_MI355X_QATTN")));
-    if (!enabled || d->T != 1 || d->nseg != 1 || !d->has_norm || !d->x || d->attn_part_o) return MI355X_E_UNSUPPORTED;
-    const int wt = d->seg[0].wtype, K = d->K, N = d->seg[0].N;
-    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;
-    if (wt == MI355X_TYPE_Q4_K && K % 256) return MI355X_E_UNSUPPORTED;
-    if (K % 32 || K > 2048 || N % 64 || d->seg[0].ep.gelu || d->seg[0].ep.residual) return MI355X_E_UNSUPPORTED;
-    if (((uintptr_t) d->x | (uintptr_t) d->ln_w | (uintptr_t) d->ln_b | (uintptr_t) d->seg[0].w) % 16) return MI355X_E_UNSUPPORTED;
-    const int H = N / 64, n_kv = (int) k->ne[1];
-    if (k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16 || k->ne[0] != 64 || v->ne[0] != 64 || v->ne[1] != n_kv || n_kv < 1 ||
-        k->ne[3] != 1 || v->ne[3] != 1 || k->nb[0] != 2 || v->nb[0] != 2 || k->ne[2] <= 0 || H % k->ne[2] || v->ne[2] <= 0 || H % v->ne[2]) return MI355X_E_UNSUPPORTED;
-    if (((uintptr_t) k->data | k->nb[1] | k->nb[2]) % 16 || ((uintptr_t) v->data | v->nb[1] | v->nb[2]) % 16) return MI355X_E_UNSUPPORTED;
-    if (mask && (mask->type != MI355X_TYPE_F16 || mask->ne[0] < n_kv || mask->nb[0] != 2 || mask->ne[2] != 1 || mask->ne[3] != 1)) return MI355X_E_UNSUPPORTED;
-    QAArgs a; memset(&a, 0, sizeof(a));
-    a.x = d->x; a.ln_w = d->ln_w; a.ln_b = d->ln_b; a.eps = d->eps; a.K = K;
-    a.w = d->seg[0].w; a.nbt = (int64_t) N * (K / (wt == MI355X_TYPE_Q4_K ? 256 : 32)); a.bias = d->seg[0].ep.bias; a.qscale = d->seg[0].ep.scale; a.has_qscale = d->seg[0].ep.has_scale;
-    a.k = to_d(k); a.v = to_d(v); if (mask) a.m = to_d(mask);
-    a.has_mask = mask != nullptr; a.scale = scale; a.n_kv = n_kv; a.H = H;
-    a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
-    a.nparts = (n_kv + 127) / 128; a.dummy = ctx->gelu_tab;
-    mi355x_scratch_reset(ctx);
-    const size_t nrec = (size_t) H * a.nparts;
-    a.part_o  = (float *) mi355x_scratch_alloc(ctx, nrec * 64 * 4);
-    a.part_ml = (float *) mi355x_scratch_alloc(ctx, nrec * 2 * 4);
-    if (!a.part_o || !a.part_ml) return (int) hipErrorOutOfMemory;
-    // 16 waves per workgroup: 4 rows of W_q and 8 keys per wave instead of 8 and 16 (the row loop is the kernel's longest serial part)
-    static const int nw = getenv("GGML_MI355X_QATTN_WAVES") ? atoi(getenv("GGML_MI355X_QATTN_WAVES")) : 8;
-    const dim3 grid(a.nparts, H), block(nw == 16 ? 1024 : 512);
-    const uint32_t lds = 8192 + (uint32_t) dg_act_bytes(wt, K, 1) + 64;
-    const double bytes = 2.0 * n_kv * 64 * 2 * H + (double) mi355x_type_row_bytes(wt, K) * N + (double) K*4 + (double) nrec*66*4;
-    const double flops = 4.0 * (double) n_kv * 64 * H + 2.0 * (double) N * K;
-    int rc;
-    if (nw == 16) switch (wt) {
-        case MI355X_TYPE_Q4_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_0, 16>, grid, block, lds, a, bytes, flops); break;
-        case MI355X_TYPE_Q5_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q5_0, 16>, grid, block, lds, a, bytes, flops); break;
-        case MI355X_TYPE_Q4_K: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_K, 16>, grid, block, lds, a, bytes, flops); break;
-        default:               rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q8_0, 16>, grid, block, lds, a, bytes, flops); break;
-    } else switch (wt) {
-        case MI355X_TYPE_Q4_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_0, 8>, grid, block, lds, a, bytes, flops); break;
-        case MI355X_TYPE_Q5_0: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q5_0, 8>, grid, block, lds, a, bytes, flops); break;
-        case MI355X_TYPE_Q4_K: rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q4_K, 8>, grid, block, lds, a, bytes, flops); break;
-        default:               rc = emit(ctx, "qattn", k_qattn<MI355X_TYPE_Q8_0, 8>, grid, block, lds, a, bytes, flops); break;
-    }
-    if (rc) return rc;
-    out->part_o = a.part_o; out->part_ml = a.part_ml; out->nparts = a.nparts; out->T = 1; out->H = H;
-    return 0;
-}
-
 struct FC2Args { const float * part_o; const float * part_ml; int nparts, T, H; dtensor d; };
 __global__ void __launch_bounds__(64) k_fattn_combine2(const FC2Args a) {
     const int t = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
