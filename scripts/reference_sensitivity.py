@@ -28,5 +28,14 @@ for arch, qtype in (("base.en", "q5_0"), ("base.en", "q8_0"), ("base.en", "f16")
     d = json.loads(r.stdout)
     out["cases"].append({"model": f"{arch} {qtype}", "perturbation": "8 threads vs 2 threads (single-token step, n_past = 3)", "logits_nmse": d["logits_nmse"],
                          "flash_attn_nodes_worst_nmse": d["per_op"]["FLASH_ATTN_EXT"]["worst_nmse"]})
+# whisper_full() end to end (mel front end, greedy and 5-beam search): the reference against itself on the PCM scaled by (1 + eps)
+for arch, qtype in (("micro", "q5_0"), ("base.en", "q5_0"), ("base.en", "q8_0")):
+    m = make_model(arch, qtype)
+    for eps in ("1e-6", "1e-4"):
+        r = subprocess.run([str(ROOT / "tests/native/bin/full_parity"), str(m), "48"], env=dict(env0, FULL_PARITY_PERTURB=eps), stdout=subprocess.PIPE, text=True, check=True)
+        d = json.loads(r.stdout)
+        out["cases"].append({"model": f"{arch} {qtype}", "perturbation": f"whisper_full on pcm * (1 + {eps})",
+                             "greedy_identical_prefix": f"{d['greedy']['identical_prefix']}/{d['greedy']['n_cpu']}",
+                             "beam5_identical_prefix": f"{d['beam5']['identical_prefix']}/{d['beam5']['n_cpu']}"})
 (ROOT / "profiles" / "r02_reference_self_sensitivity.json").write_text(json.dumps(out, indent=1))
 print(json.dumps(out["cases"], indent=1))

@@ -63,7 +63,10 @@ int main(int argc, char ** argv) {
         // self-test with FULL_PARITY_THREADS_B=n: reference CPU path with 8 threads against the reference CPU path with n
         // threads (different f32 summation order only) — how stable free-running decoding of this model is in the reference itself
         const int tb = selftest && getenv("FULL_PARITY_THREADS_B") ? atoi(getenv("FULL_PARITY_THREADS_B")) : 8;
-        const std::vector<int> b = run(argv[1], !selftest, m.strategy, m.beam, pcm, max_tokens, tb);
+        // self-test with FULL_PARITY_PERTURB=eps: the reference against itself on the signal scaled by (1 + eps)
+        std::vector<float> pcm_b = pcm;
+        if (selftest && getenv("FULL_PARITY_PERTURB")) { const float e = 1.0f + (float) atof(getenv("FULL_PARITY_PERTURB")); for (auto & x : pcm_b) x *= e; }
+        const std::vector<int> b = run(argv[1], !selftest, m.strategy, m.beam, pcm_b, max_tokens, tb);
         size_t same = 0; while (same < a.size() && same < b.size() && a[same] == b[same]) same++;
         printf(",\n \"%s\": {\"n_cpu\": %zu, \"n_gpu\": %zu, \"identical_prefix\": %zu, \"cpu\": [", m.name, a.size(), b.size(), same);
         for (size_t i = 0; i < a.size(); i++) printf("%s%d", i ? ", " : "", a[i]);
