@@ -74,6 +74,8 @@ GGML_MI355X_API void ggml_backend_mi355x_host_times(double * out);
  * the same order, src/whisper.cpp:1685-1859; buffer counts and sizes are compared first).  The reference has no such call site: it
  * re-reads the model file and uploads tensor by tensor for every context (src/whisper.cpp:1934-1938).
  *   ggml_backend_mi355x_broadcast_weights_peer   one process, several devices: hipMemcpyPeerAsync over xGMI, then checksums
+ *   ggml_backend_mi355x_clone_weights            n contexts created one after the other on ONE device (a one-GPU machine standing in for
+ *                                                n GPUs in tests): copy the first context's buffers into the others', verify the same way
  *   ggml_backend_mi355x_rccl_unique_id           rank 0 of a multi-process job: 128-byte id for the host harness to hand to every rank
  *   ggml_backend_mi355x_broadcast_weights_rccl   one process per device: RCCL communicator from that id (librccl.so is dlopen()ed),
  *                                                ncclBroadcast of every buffer from rank 0, device-side checksums compared across ranks
@@ -85,6 +87,7 @@ GGML_MI355X_API void ggml_backend_mi355x_host_times(double * out);
 GGML_MI355X_API int  ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap);
 GGML_MI355X_API int  ggml_backend_mi355x_weights_checksum(int device, uint64_t * out_pairs, int cap);
 GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, double * stats4);
+GGML_MI355X_API int  ggml_backend_mi355x_clone_weights(int device, int n_replicas, double * stats4);
 GGML_MI355X_API int  ggml_backend_mi355x_rccl_unique_id(void * out128);
 GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, const void * unique_id128, double * stats4);
 GGML_MI355X_API void ggml_backend_mi355x_defer_weights(int on);

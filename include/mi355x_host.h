@@ -37,6 +37,8 @@ typedef struct mi355x_host_config {
     int32_t n_threads;             /* n_threads argument of whisper_encode / whisper_decode */
     int32_t skip_payloads;         /* 1: contexts r > 0 load through the payload-skipping loader + broadcast (GPU only) */
     int32_t flash_attn;
+    int32_t replicas_on_one_device; /* 1: every context uses gpu_device = first_device (a one-GPU machine standing in for n_devices GPUs:
+                                     *    the payload-skipping load + device copy + checksum verify path runs on real hardware) */
 } mi355x_host_config;
 
 typedef struct mi355x_host_result {

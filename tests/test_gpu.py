@@ -776,6 +776,33 @@ def test_native_harness_streams_on_the_gpu_are_bit_identical_to_a_single_stream(
     assert r4["chunks_per_s"] > 0
 
 
+def test_payload_skipping_replica_filled_by_device_copy_computes_the_same_logits():
+    """the whole replica path of SURVEY.md section 8e on real hardware, with ONE GPU standing in for two: context 1 is opened through the
+    payload-skipping loader (its set_tensor calls deferred), receives every weights buffer from context 0 by a device copy, the
+    checksums are compared, and BOTH contexts then run the bench protocol.  Their logits must be bit-identical to the same two
+    contexts each loading the whole file — i.e. a replica that never read a tensor payload computes exactly what a normal one does."""
+    from synth_model import make_model
+    from whisper_cpp_amd import host_api as h
+    m = make_model("base.en", "q5_0")
+    n_vocab = 51864
+    rows = {}
+    for skip in (True, False):
+        r = h.run(m, use_gpu=True, n_devices=2, streams=1, n_decode=12, steps=1, warmup=1, skip_payloads=skip, replicas_on_one_device=True)
+        assert r["rc"] == 0 and r["error"] == "", r
+        out = np.zeros(2 * n_vocab, dtype=np.float32)
+        assert h.lib().mi355x_host_last_logits(out.ctypes.data, out.size) == 2 * n_vocab
+        rows[skip] = out.reshape(2, n_vocab).copy()
+        if skip:
+            assert r["bcast_verified"] == 1 and r["bcast_buffers"] >= 1 and r["bcast_bytes"] > 10e6, r
+            # context 0 read the whole file, context 1 only header + filters + vocabulary
+            assert r["file_bytes"] < r["payload_bytes_read"] < 1.05 * r["file_bytes"], r
+        else:
+            assert r["bcast_bytes"] == 0 and r["payload_bytes_read"] >= 1.99 * r["file_bytes"], r
+    assert np.isfinite(rows[True]).all()
+    assert np.array_equal(rows[True], rows[False])
+    assert not np.array_equal(rows[True][0], rows[True][1])          # different mel per context: the rows are not trivially equal
+
+
 def test_gpu_log_mel_matches_the_reference_front_end_on_real_speech(gpu, oracle):
     """mi355x_log_mel on samples/jfk.wav against whisper's own log_mel_spectrogram (golden generated from the
     reference, tests/golden/mel.npz).  Floating-point kernel: tolerance max |diff| < 1e-4 in normalised mel units (values span

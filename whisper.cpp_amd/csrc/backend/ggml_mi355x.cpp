@@ -1433,21 +1433,22 @@ int ggml_backend_mi355x_weights_checksum(int device, uint64_t * out, int cap) {
 
 // in-process: copy every WEIGHTS buffer of src_device into the same-index buffer of dst_device, then verify.
 // stats[0..3] = bytes, seconds, buffers, verified (1/0).  Returns 0, or a negative code (-2 layout mismatch, -3 copy failed, -4 checksum mismatch).
-int ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, double * stats) {
-    mi_shadows_drop(dst_device, nullptr);
-    const std::vector<mi_weight_rec> S = mi_weight_list(src_device), D = mi_weight_list(dst_device);
-    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+static int mi_copy_verify(int src_device, int dst_device, const std::vector<mi_weight_rec> & S, const std::vector<mi_weight_rec> & D, double * stats) {
     if (S.empty() || S.size() != D.size()) return -2;
     for (size_t i = 0; i < S.size(); i++) if (S[i].size != D[i].size) return -2;
     for (int dev : { src_device, dst_device }) { if (hipSetDevice(dev) != hipSuccess) return -3; mi_io_drain(dev); (void) hipDeviceSynchronize(); }
-    int can = 0;
-    (void) hipDeviceCanAccessPeer(&can, dst_device, src_device);
-    if (can) { (void) hipSetDevice(dst_device); hipError_t e = hipDeviceEnablePeerAccess(src_device, 0); if (e != hipSuccess) (void) hipGetLastError(); }
+    if (src_device != dst_device) {
+        int can = 0;
+        (void) hipDeviceCanAccessPeer(&can, dst_device, src_device);
+        if (can) { (void) hipSetDevice(dst_device); hipError_t e = hipDeviceEnablePeerAccess(src_device, 0); if (e != hipSuccess) (void) hipGetLastError(); }
+    }
     const double t0 = now_ms();
     double bytes = 0;
     (void) hipSetDevice(dst_device);
     for (size_t i = 0; i < S.size(); i++) {
-        if (hipMemcpyPeerAsync(D[i].base, dst_device, S[i].base, src_device, S[i].size, nullptr) != hipSuccess) return -3;
+        const hipError_t e = src_device != dst_device ? hipMemcpyPeerAsync(D[i].base, dst_device, S[i].base, src_device, S[i].size, nullptr)
+                                                      : hipMemcpyAsync(D[i].base, S[i].base, S[i].size, hipMemcpyDeviceToDevice, nullptr);
+        if (e != hipSuccess) return -3;
         bytes += (double) S[i].size;
     }
     if (hipDeviceSynchronize() != hipSuccess) return -3;
@@ -1455,11 +1456,35 @@ int ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, d
     std::vector<uint64_t> cs, cd;
     if (mi_checksums(src_device, S, cs) != 0 || mi_checksums(dst_device, D, cd) != 0) return -4;
     const bool ok = cs == cd;
-    if (stats) { stats[0] = bytes; stats[1] = secs; stats[2] = (double) S.size(); stats[3] = ok ? 1 : 0; }
+    if (stats) { stats[0] += bytes; stats[1] += secs; stats[2] = (double) S.size(); stats[3] = ok ? 1 : 0; }
     return ok ? 0 : -4;
 }
 
-// rank 0 of a multi-process job: a fresh RCCL unique id (128 bytes) for the host harness to hand to every rank
+int ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, double * stats) {
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (src_device == dst_device) return -2;
+    mi_shadows_drop(dst_device, nullptr);
+    return mi_copy_verify(src_device, dst_device, mi_weight_list(src_device), mi_weight_list(dst_device), stats);
+}
+
+// n_replicas contexts created one after the other on ONE device (a one-GPU machine standing in for n GPUs, so that the
+// payload-skipping load -> copy -> verify -> run path can be executed on real hardware): the device's WEIGHTS buffers are
+// n_replicas groups of k in allocation order; group 0 is copied into every other group and verified like a peer broadcast.
+int ggml_backend_mi355x_clone_weights(int device, int n_replicas, double * stats) {
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    mi_shadows_drop(device, nullptr);
+    const std::vector<mi_weight_rec> all = mi_weight_list(device);
+    if (n_replicas < 2 || all.empty() || all.size() % (size_t) n_replicas) return -2;
+    const size_t k = all.size() / (size_t) n_replicas;
+    const std::vector<mi_weight_rec> S(all.begin(), all.begin() + k);
+    for (int g = 1; g < n_replicas; g++) {
+        const std::vector<mi_weight_rec> D(all.begin() + g * k, all.begin() + (g + 1) * k);
+        const int rc = mi_copy_verify(device, device, S, D, stats);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 int ggml_backend_mi355x_rccl_unique_id(void * out128) {
     mi_rccl_api * r = mi_rccl();
     if (!r) return -1;
@@ -1537,6 +1562,7 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_weight_buffers"))  return (void *) ggml_backend_mi355x_weight_buffers;
     if (!strcmp(name, "ggml_backend_mi355x_weights_checksum"))        return (void *) ggml_backend_mi355x_weights_checksum;
     if (!strcmp(name, "ggml_backend_mi355x_broadcast_weights_peer"))  return (void *) ggml_backend_mi355x_broadcast_weights_peer;
+    if (!strcmp(name, "ggml_backend_mi355x_clone_weights"))           return (void *) ggml_backend_mi355x_clone_weights;
     if (!strcmp(name, "ggml_backend_mi355x_broadcast_weights_rccl"))  return (void *) ggml_backend_mi355x_broadcast_weights_rccl;
     if (!strcmp(name, "ggml_backend_mi355x_rccl_unique_id"))          return (void *) ggml_backend_mi355x_rccl_unique_id;
     if (!strcmp(name, "ggml_backend_mi355x_defer_weights"))           return (void *) ggml_backend_mi355x_defer_weights;

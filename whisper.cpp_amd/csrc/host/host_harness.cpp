@@ -98,6 +98,7 @@ std::mutex g_last_mtx;
 
 typedef int  (*bcast_peer_fn)(int, int, double *);
 typedef void (*defer_fn)(int);
+typedef int  (*clone_fn)(int, int, double *);
 
 } // namespace
 
@@ -161,9 +162,11 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
         if (cfg->plugin_path) reg = ggml_backend_load(cfg->plugin_path);
         if (!reg) reg = ggml_backend_reg_by_name("MI355X");
         if (!reg) return fail(2, "MI355X plugin not loaded (no CPU fallback in GPU mode)");
-        if ((int) ggml_backend_reg_dev_count(reg) < cfg->first_device + cfg->n_devices) return fail(2, "fewer MI355X devices than requested");
+        if ((int) ggml_backend_reg_dev_count(reg) < cfg->first_device + (cfg->replicas_on_one_device ? 1 : cfg->n_devices)) return fail(2, "fewer MI355X devices than requested");
     }
     const int nd = cfg->n_devices, ns = cfg->streams_per_device;
+    const bool one_dev = cfg->use_gpu && cfg->replicas_on_one_device;
+    auto device_of = [&](int r) { return cfg->first_device + (one_dev ? 0 : r); };
     out->n_devices = nd; out->streams_per_device = ns;
     int64_t fsz = 0; (void) tensors_offset(cfg->model_path, &fsz); out->file_bytes = fsz;
 
@@ -176,7 +179,7 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
     defer_fn defer = reg ? (defer_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_defer_weights") : nullptr;
     for (int r = 0; r < nd; r++) {
         whisper_context_params cp = whisper_context_default_params();
-        cp.use_gpu = cfg->use_gpu != 0; cp.gpu_device = cfg->first_device + r; cp.flash_attn = cfg->flash_attn != 0;
+        cp.use_gpu = cfg->use_gpu != 0; cp.gpu_device = device_of(r); cp.flash_attn = cfg->flash_attn != 0;
         std::string err; int64_t rd = 0;
         const bool sk = skip && r > 0;
         if (sk && defer) defer(1);
@@ -185,7 +188,14 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
         out->payload_bytes_read += rd;
         if (!ctxs[r]) { cleanup(); return fail(3, err); }
     }
-    if (skip) {
+    if (skip && one_dev) {
+        clone_fn cl = (clone_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_clone_weights");
+        if (!cl) { cleanup(); return fail(4, "plugin has no ggml_backend_mi355x_clone_weights"); }
+        double st[4] = { 0, 0, 0, 0 };
+        const int rc = cl(cfg->first_device, nd, st);
+        out->bcast_bytes = st[0]; out->bcast_seconds = st[1]; out->bcast_buffers = (int) st[2]; out->bcast_verified = rc == 0 && st[3] == 1;
+        if (!out->bcast_verified) { cleanup(); return fail(4, "weight copy between the replicas of one device failed or could not be verified (rc " + std::to_string(rc) + ")"); }
+    } else if (skip) {
         bcast_peer_fn bc = (bcast_peer_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_broadcast_weights_peer");
         if (!bc) { cleanup(); return fail(4, "plugin has no ggml_backend_mi355x_broadcast_weights_peer"); }
         out->bcast_verified = 1;

@@ -12,7 +12,7 @@ HOST_SO = LIB_DIR / "libmi355x_host.so"
 class Config(C.Structure):
     _fields_ = [("model_path", C.c_char_p), ("plugin_path", C.c_char_p), ("use_gpu", C.c_int32), ("n_devices", C.c_int32), ("first_device", C.c_int32),
                 ("streams_per_device", C.c_int32), ("n_decode", C.c_int32), ("steps", C.c_int32), ("warmup", C.c_int32), ("n_threads", C.c_int32),
-                ("skip_payloads", C.c_int32), ("flash_attn", C.c_int32)]
+                ("skip_payloads", C.c_int32), ("flash_attn", C.c_int32), ("replicas_on_one_device", C.c_int32)]
 
 
 class Result(C.Structure):
@@ -42,9 +42,9 @@ def lib() -> C.CDLL:
 
 
 def run(model: Path, *, use_gpu: bool, n_devices: int = 1, streams: int = 1, n_decode: int = 256, steps: int = 1, warmup: int = 1,
-        n_threads: int = 4, skip_payloads: bool = True, first_device: int = 0, flash_attn: bool = True) -> dict:
+        n_threads: int = 4, skip_payloads: bool = True, first_device: int = 0, flash_attn: bool = True, replicas_on_one_device: bool = False) -> dict:
     cfg = Config(str(model).encode(), str(PLUGIN_SO).encode() if use_gpu else None, int(use_gpu), n_devices, first_device, streams, n_decode, steps, warmup,
-                 n_threads, int(skip_payloads), int(flash_attn))
+                 n_threads, int(skip_payloads), int(flash_attn), int(replicas_on_one_device))
     res = Result()
     rc = lib().mi355x_host_run(C.byref(cfg), C.byref(res))
     d = {f: getattr(res, f) for f, _ in Result._fields_}
