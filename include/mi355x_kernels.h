@@ -69,6 +69,11 @@ MI355X_API mi355x_ctx * mi355x_ctx_create(int device);                  /* NULL 
 MI355X_API void         mi355x_ctx_destroy(mi355x_ctx * ctx);
 MI355X_API void *       mi355x_ctx_stream(mi355x_ctx * ctx);            /* hipStream_t */
 MI355X_API int          mi355x_ctx_synchronize(mi355x_ctx * ctx);
+/* Independent neighbouring GEMMs are held back so that they can leave as ONE grouped launch (the Q / K / V projections of an encoder
+ * layer, the cross-attention K / V projections of consecutive layers: src/whisper.cpp:2119-2141, :2306-2348); every other launch,
+ * synchronize, memset, record_end and profile call flushes them first, so stream order equals program order.  A host that enqueues
+ * its OWN work on mi355x_ctx_stream() calls this before. */
+MI355X_API int          mi355x_flush(mi355x_ctx * ctx);
 MI355X_API const char * mi355x_last_error(void);
 
 /* launch recording: between begin/end no kernel is launched; launches are appended to the context's
@@ -217,6 +222,11 @@ MI355X_API int mi355x_flash_attn_ext_exact(mi355x_ctx * ctx, const mi355x_tensor
  * (the ggml_mul + ggml_add that always follow it in whisper, src/whisper.cpp:2109-2114). */
 MI355X_API int mi355x_norm(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst, float eps,
                            const float * w /* nullable [ne0] */, const float * b /* nullable [ne0] */);
+/* the same, also writing what mi355x_prep_act(dst) would write: the f16 [T][K] activation matrix (mode as in mi355x_prep_act) of the
+ * MFMA GEMM that consumes this LayerNorm (encoder: src/whisper.cpp:2107-2115 -> :2119-2141, :2214-2222 -> :2224-2228), bit-identical
+ * to the two-pass result.  x must be [K, T] with K <= 2048. */
+MI355X_API int mi355x_norm_prep(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst, float eps,
+                                const float * w, const float * b, void * prep_f16, int mode);
 
 /* ggml_add / ggml_mul with broadcasting of src1 (CPU ggml-cpu/binary-ops.cpp:140-148). op: 0 add, 1 mul */
 MI355X_API int mi355x_binary(mi355x_ctx * ctx, int op, const mi355x_tensor * a, const mi355x_tensor * b, const mi355x_tensor * dst);

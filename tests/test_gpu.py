@@ -143,6 +143,72 @@ def test_f16_weight_copy_is_bit_identical_to_fused_dequant(gpu, oracle, t):
         assert np.array_equal(got, deq.astype(np.float16))
 
 
+def test_grouped_ring_gemm_is_bit_identical_to_single_launches(gpu):
+    """independent GEMMs on the same activations that follow each other (an encoder layer's Q / K / V projections, full size:
+    1280 x 1500 x 1280) leave as ONE grouped launch of 128-wide tiles instead of three launches of 64-wide tiles; every output word
+    must equal the single-launch result (same K order per element), epilogues are per member, and a product that does not fit the
+    group (other shape) goes out on its own"""
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(77)
+    K, N, T = 1280, 1280, 1500
+    ws = [dev(torch, (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16)) for _ in range(3)]
+    w_small = dev(torch, (rng.standard_normal((256, K)) / np.sqrt(K)).astype(np.float16))
+    act = dev(torch, rng.standard_normal((T, K)).astype(np.float16))
+    bias = dev(torch, rng.standard_normal(N).astype(np.float32))
+    eps = [ka.Epilogue(), ka.Epilogue(), ka.Epilogue()]
+    eps[0].bias = bias.data_ptr()
+    eps[1].scale, eps[1].has_scale = 0.25, 1
+    eps[2].bias = bias.data_ptr()
+    dt = [torch.float32, torch.float16, torch.float32]
+
+    def outs():
+        return [torch.zeros((T, N), dtype=d, device="cuda:0") for d in dt] + [torch.zeros((T, 256), dtype=torch.float32, device="cuda:0")]
+
+    def launch(i, y):
+        tw = ka.tensor((ws[i] if i < 3 else w_small).data_ptr(), ka.F16, [K, N if i < 3 else 256])
+        n = N if i < 3 else 256
+        f16 = i < 3 and dt[i] == torch.float16
+        ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), K, T, y.data_ptr(), n * (2 if f16 else 4), ka.F16 if f16 else ka.F32,
+                                              C.byref(eps[i]) if i < 3 else None), "gemm")
+
+    single, grouped = outs(), outs()
+    torch.cuda.synchronize()
+    for i in range(4):
+        launch(i, single[i])
+        ctx.sync()                                   # one launch each
+    n0 = ka.lib().mi355x_eager_count(ctx.h)
+    for i in range(4):
+        launch(i, grouped[i])                        # 0..2 merge, 3 (other M) flushes them and is held back itself
+    ctx.sync()
+    assert ka.lib().mi355x_eager_count(ctx.h) - n0 == 2
+    for a, b in zip(single, grouped):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.isfinite(a.astype(np.float32)).all() and np.abs(a.astype(np.float32)).max() > 0.1
+        assert np.array_equal(a.view(np.uint16 if a.dtype == np.float16 else np.uint32), b.view(np.uint16 if b.dtype == np.float16 else np.uint32))
+
+
+@pytest.mark.parametrize("K,T,mode", [(1280, 1500, 1), (1280, 300, 2), (384, 77, 1), (512, 40, 0), (1024, 9, 2)])
+def test_layernorm_with_fused_activation_preparation_is_bit_identical_to_two_passes(gpu, K, T, mode):
+    """mi355x_norm_prep: the LayerNorm result AND the f16 activation matrix of the GEMM that consumes it (the reference's Q8_0 / Q8_K
+    rounding decisions, stored as f16) in one pass — both outputs word for word what mi355x_norm followed by mi355x_prep_act give"""
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(K + T + mode)
+    x = dev(torch, (rng.standard_normal((T, K)) * rng.uniform(0.1, 30.0, size=(T, 1))).astype(np.float32))
+    w = dev(torch, rng.standard_normal(K).astype(np.float32))
+    b = dev(torch, rng.standard_normal(K).astype(np.float32))
+    y1, y2 = (torch.zeros((T, K), dtype=torch.float32, device="cuda:0") for _ in range(2))
+    p1, p2 = (torch.zeros((T, K), dtype=torch.float16, device="cuda:0") for _ in range(2))
+    torch.cuda.synchronize()
+    tx = ka.tensor(x.data_ptr(), ka.F32, [K, T])
+    ctx.check(ka.lib().mi355x_norm(ctx.h, C.byref(tx), C.byref(ka.tensor(y1.data_ptr(), ka.F32, [K, T])), 1e-5, w.data_ptr(), b.data_ptr()), "norm")
+    ctx.check(ka.lib().mi355x_prep_act(ctx.h, y1.data_ptr(), K * 4, 0, p1.data_ptr(), K, T, mode), "prep_act")
+    ctx.check(ka.lib().mi355x_norm_prep(ctx.h, C.byref(tx), C.byref(ka.tensor(y2.data_ptr(), ka.F32, [K, T])), 1e-5, w.data_ptr(), b.data_ptr(), p2.data_ptr(), mode), "norm_prep")
+    ctx.sync()
+    assert np.array_equal(y1.cpu().numpy().view(np.uint32), y2.cpu().numpy().view(np.uint32))
+    a, c = p1.cpu().numpy().view(np.uint16), p2.cpu().numpy().view(np.uint16)
+    assert np.array_equal(a, c) and a.any()
+
+
 def test_mul_mat_f16_weights(gpu, oracle):
     _, ka, _ = gpu
     rng = np.random.default_rng(5)

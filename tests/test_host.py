@@ -221,7 +221,8 @@ def test_ring_gemm_loop_never_drains_the_dma_queue(tmp_path):
                         f"-I{src.parent}", str(src), "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     text = out.read_text()
-    for fn, counted in (("_Z15k_gemm_f16_ringILi64ELi4EEv8GemmArgs", "vmcnt(12)"), ("_Z15k_gemm_f16_ringILi128ELi2EEv8GemmArgs", None)):
+    for fn, counted in (("_Z15k_gemm_f16_ringILi64ELi4EEv8GemmArgs", "vmcnt(12)"), ("_Z15k_gemm_f16_ringILi128ELi2EEv8GemmArgs", None),
+                        ("_Z21k_gemm_f16_ring_groupILi64ELi4EEv13GemmGroupArgs", "vmcnt(12)"), ("_Z21k_gemm_f16_ring_groupILi128ELi2EEv13GemmGroupArgs", None)):
         body = text[text.index(fn + ":"):]
         body = body[:body.index("s_endpgm")]
         assert body.count("global_load_lds_dwordx4") >= 12, fn

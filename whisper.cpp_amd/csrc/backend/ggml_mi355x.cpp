@@ -528,6 +528,33 @@ static const void * mi_shadow_get(mi_backend_ctx * b, const ggml_tensor * w, con
     return p;
 }
 
+// room for T x K prepared f16 activations in the backend's scratch; 0 ok, < 0 recording aborted (grows on the eager re-run), > 0 error
+static int mi_act_reserve(mi_backend_ctx * b, size_t need) {
+    if (need <= b->act_size) return 0;
+    if (b->recording) { b->record_abort = true; return -1; }
+    mi355x_ctx_synchronize(b->k);
+    if (b->act) (void) hipFree(b->act);
+    b->act = nullptr; b->act_size = 0; b->act_src = nullptr;
+    const size_t sz = need + (need >> 2);
+    if (hipMalloc(&b->act, sz) != hipSuccess) return (int) hipErrorOutOfMemory;
+    b->act_size = sz;
+    return 0;
+}
+
+// does tensor x (F32 [K, T]) feed the MFMA GEMM path as the activation of mul_mat `mm`?  (the conditions of run_mm_chain)
+static bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, const ggml_tensor * x, int & mode_out) {
+    if (mm->op != GGML_OP_MUL_MAT || mm->src[1] != x || b->exact) return false;
+    const ggml_tensor * w = mm->src[0];
+    const int64_t K = w->ne[0], T = x->ne[1];
+    const bool two_d = ggml_n_dims(w) <= 2 && x->ne[2] == 1 && x->ne[3] == 1;
+    if (!(two_d && T > 8 && K % 8 == 0 && x->type == GGML_TYPE_F32 && x->nb[0] == 4 && (x->nb[1] % 16 == 0) && ((uintptr_t) x->data % 16 == 0))) return false;
+    if (!((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && w->nb[0] == 2 && w->nb[1] % 16 == 0))) return false;
+    const int mode = mode_for(w->type);
+    if ((mode == 1 && K % 32) || (mode == 2 && K % 256)) return false;
+    mode_out = mode;
+    return true;
+}
+
 static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
     const ggml_tensor * mm = c.mm, * w = mm->src[0], * x = mm->src[1];
     mi355x_tensor mw = to_mt(w), mx = to_mt(x);
@@ -565,16 +592,8 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
             const void * act; int64_t ld;
             if (x->type == GGML_TYPE_F16 && mode == 0) { act = x->data; ld = (int64_t) x->nb[1] / 2; }
             else {
-                const size_t need = (size_t) T * K * 2;
-                if (need > b->act_size) {
-                    if (b->recording) { b->record_abort = true; return 0; }     // re-run eagerly, which grows the buffer
-                    mi355x_ctx_synchronize(b->k);
-                    if (b->act) (void) hipFree(b->act);
-                    b->act = nullptr; b->act_size = 0;
-                    size_t sz = need + (need >> 2);
-                    if (hipMalloc(&b->act, sz) != hipSuccess) return (int) hipErrorOutOfMemory;
-                    b->act_size = sz; b->act_src = nullptr;
-                }
+                const int rr = mi_act_reserve(b, (size_t) T * K * 2);
+                if (rr != 0) return rr < 0 ? 0 : rr;                            // < 0: recording aborted, the range re-runs eagerly
                 if (!(b->act_src == x->data && b->act_K == K && b->act_T == T && b->act_mode == mode && b->act_nb1 == (int64_t) x->nb[1])) {
                     const int rc = mi355x_prep_act(b->k, x->data, (int64_t) x->nb[1], x->type == GGML_TYPE_F16, b->act, (int) K, T, mode);
                     if (rc) return rc;
@@ -627,9 +646,25 @@ static void parse_ln_chain(const ggml_cgraph * g, int i, bool fuse, ln_chain & c
     c.last = a; c.w = (const float *) wv->data; c.b = (const float *) bv->data; c.end = j2;
 }
 
-static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c) {
+static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c, const ggml_cgraph * g = nullptr) {
     float eps; memcpy(&eps, c.norm->op_params, sizeof(float));
     mi355x_tensor mx = to_mt(c.norm->src[0]), md = to_mt(c.last);
+    // encoder / prompt: the next node is an MFMA GEMM on this LayerNorm's result -> write its prepared f16 activations in the same
+    // pass (one launch and one read of the 7.7 MB result less per LayerNorm; bit-identical to mi355x_prep_act on the result)
+    static const bool fuse_prep = env_flag("GGML_MI355X_LN_PREP", true);
+    int mode = 0;
+    const int j = g ? next_real(g, c.end) : 0;
+    if (g && b->fuse && fuse_prep && j < g->n_nodes && mm_takes_prepared(b, g->nodes[j], c.last, mode)) {
+        const int64_t K = c.last->ne[0], T = c.last->ne[1];
+        const int rr = mi_act_reserve(b, (size_t) T * K * 2);
+        if (rr > 0) return rr;
+        if (rr == 0) {
+            const int rc = mi355x_norm_prep(b->k, &mx, &md, eps, c.w, c.b, b->act, mode);
+            if (rc == 0) { b->act_src = c.last->data; b->act_K = K; b->act_T = T; b->act_mode = mode; b->act_nb1 = (int64_t) c.last->nb[1]; return 0; }
+            if (rc != MI355X_E_UNSUPPORTED) return rc;
+        }
+    }
+    b->act_src = nullptr;
     return mi355x_norm(b->k, &mx, &md, eps, c.w, c.b);
 }
 
@@ -878,10 +913,9 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
             int end = 0, rc2 = 0;
             if (b->fuse && try_ln_gemv(b, g, c, end, rc2)) { rc = rc2; i = end; }
             else {
-                rc = run_ln_chain(b, c);
+                rc = run_ln_chain(b, c, g);                  // leaves b->act_* describing the prepared activations, if it made them
                 if (rc == MI355X_E_UNSUPPORTED && c.end != i) { parse_ln_chain(g, i, false, c); rc = run_ln_chain(b, c); }
                 else i = c.end;
-                b->act_src = nullptr;
             }
         } else if (n->op == GGML_OP_GET_ROWS && b->fuse) {
             // token embedding + positional embedding: get_rows, get_rows, add -> one launch
@@ -921,7 +955,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         }
     }
     if (i_next) *i_next = i < i_stop ? i : i_stop;
-    return 0;
+    return mi355x_flush(b->k);            // launches the kernel library held back for grouping (gemm_mfma.hip) leave with their range
 }
 static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
     b->act_src = nullptr;

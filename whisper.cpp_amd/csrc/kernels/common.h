@@ -50,7 +50,15 @@ struct mi355x_ctx {
     std::map<std::string, prof_acc>      prof_rows;
     int                                  n_cu = 256;
     void *                               dbg_stamps = nullptr;   // 16 x u64 (device), GGML_MI355X_KTIME=1 only
+    // launches held back so that independent neighbours can go out as ONE grouped launch (gemm_mfma.hip: the Q / K / V projections
+    // of an encoder layer, the cross-attention K / V projections of consecutive layers).  Anything else that is emitted, and every
+    // operation that orders against the stream, flushes them first (mi355x_flush_pending), so stream order is unchanged.
+    int      pending_n = 0;
+    bool     in_flush  = false;
+    int   (* pending_flush)(mi355x_ctx *) = nullptr;
+    alignas(16) uint8_t pending_store[2048];
 };
+static inline int mi355x_flush_pending(mi355x_ctx * ctx) { return (ctx->pending_n > 0 && !ctx->in_flush && ctx->pending_flush) ? ctx->pending_flush(ctx) : 0; }
 void * mi355x_debug_stamps(mi355x_ctx * ctx);
 
 void   mi355x_set_error(const char * fmt, ...);

@@ -72,6 +72,7 @@ extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
 extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
+    (void) mi355x_flush_pending(ctx);
     (void) hipStreamSynchronize(ctx->stream);
     for (auto & e : ctx->ev_pool) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     if (ctx->scratch)  (void) hipFree(ctx->scratch);
@@ -118,8 +119,11 @@ static void prof_drain(mi355x_ctx * ctx) {
     ctx->ev_pending.clear();
 }
 
+extern "C" int mi355x_flush(mi355x_ctx * ctx) { return mi355x_flush_pending(ctx); }
+
 extern "C" int mi355x_ctx_synchronize(mi355x_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
+    { const int rc = mi355x_flush_pending(ctx); if (rc) return rc; }
     // optional (GGML_MI355X_SYNC_SPIN_US=n): poll the stream for up to n microseconds before the blocking wait.  Measured on
     // the decode loop: no gain over hipStreamSynchronize (which already spins), so it is off by default.
     static const int spin_us = getenv("GGML_MI355X_SYNC_SPIN_US") ? atoi(getenv("GGML_MI355X_SYNC_SPIN_US")) : 0;
@@ -168,6 +172,7 @@ void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes) {
 int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 grid, dim3 block, uint32_t shmem,
                 const void * args, uint32_t arg_size, double algo_bytes, double algo_flops) {
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return 0;
+    { const int rc = mi355x_flush_pending(ctx); if (rc) return rc; }      // held-back launches go first: stream order is program order
     if (ctx->recording) {
         mi355x_launch l;
         l.func = func; l.grid[0] = grid.x; l.grid[1] = grid.y; l.grid[2] = grid.z;
@@ -229,6 +234,7 @@ extern "C" int  mi355x_record_count(mi355x_ctx * ctx) { return ctx->recording ? 
 extern "C" uint64_t mi355x_eager_count(mi355x_ctx * ctx) { return ctx->n_eager; }
 extern "C" void mi355x_record_begin(mi355x_ctx * ctx) { ctx->recording = true; ctx->record_invalid = false; ctx->plan.clear(); ctx->blob.clear(); }
 extern "C" int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size) {
+    if (mi355x_flush_pending(ctx) != 0) ctx->record_invalid = true;
     ctx->recording = false;
     if (ctx->record_invalid) { *launches = nullptr; *arg_blob = nullptr; *blob_size = 0; return -1; }
     *launches = ctx->plan.data(); *arg_blob = ctx->blob.data(); *blob_size = ctx->blob.size();
@@ -236,8 +242,9 @@ extern "C" int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launc
 }
 
 extern "C" void mi355x_prof_enable(mi355x_ctx * ctx, int on) { ctx->prof = on != 0; }
-extern "C" void mi355x_prof_reset(mi355x_ctx * ctx) { (void) hipStreamSynchronize(ctx->stream); prof_drain(ctx); ctx->prof_rows.clear(); }
+extern "C" void mi355x_prof_reset(mi355x_ctx * ctx) { (void) mi355x_flush_pending(ctx); (void) hipStreamSynchronize(ctx->stream); prof_drain(ctx); ctx->prof_rows.clear(); }
 extern "C" int  mi355x_prof_report(mi355x_ctx * ctx, mi355x_prof_row * rows, int cap) {
+    (void) mi355x_flush_pending(ctx);
     (void) hipStreamSynchronize(ctx->stream);
     prof_drain(ctx);
     int n = 0;
@@ -252,6 +259,7 @@ extern "C" int  mi355x_prof_report(mi355x_ctx * ctx, mi355x_prof_row * rows, int
 
 extern "C" int mi355x_memset(mi355x_ctx * ctx, void * dptr, int value, size_t n) {
     (void) hipSetDevice(ctx->device);
+    { const int rc = mi355x_flush_pending(ctx); if (rc) return rc; }
     HIP_OK(hipMemsetAsync(dptr, value, n, ctx->stream));
     return 0;
 }

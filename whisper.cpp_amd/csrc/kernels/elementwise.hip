@@ -100,7 +100,7 @@ extern "C" int mi355x_gelu(mi355x_ctx * ctx, const mi355x_tensor * x, const mi35
 // norm (+ optional affine): one wave per row (ggml-cpu/ops.cpp:3698-3765)
 //   mean = sum/n ; var = sum((x-mean)^2)/n ; y = (x-mean) * (1/sqrtf(var+eps)) [* w + b as separate roundings]
 // -------------------------------------------------------------------------------------------------
-struct NormArgs { dtensor x, y; float eps; const float * w; const float * b; int64_t nrows; };
+struct NormArgs { dtensor x, y; float eps; const float * w; const float * b; int64_t nrows; uint16_t * prep; int prep_mode; };
 __global__ void __launch_bounds__(256) k_norm(const NormArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -154,17 +154,65 @@ __global__ void __launch_bounds__(256) k_norm_v4(const NormArgs a) {
     #pragma unroll
     for (int i = 0; i < 8; i++) {
         const int e4 = lane + 64*i;
-        if (e4 < n4) {
-            float r[4] = { (xr[i].x - mean) * sc, (xr[i].y - mean) * sc, (xr[i].z - mean) * sc, (xr[i].w - mean) * sc };
-            if (a.w) { const float4 w = *(const float4 *) (a.w + e4*4); r[0] = r[0]*w.x; r[1] = r[1]*w.y; r[2] = r[2]*w.z; r[3] = r[3]*w.w; }
-            if (a.b) { const float4 b = *(const float4 *) (a.b + e4*4); r[0] = r[0]+b.x; r[1] = r[1]+b.y; r[2] = r[2]+b.z; r[3] = r[3]+b.w; }
-            *(float4 *) (y + (size_t) e4*4) = make_float4(r[0], r[1], r[2], r[3]);
+        if (64*i >= n4) break;                               // uniform: no lane of this wave has elements left
+        const int c4 = e4 < n4 ? e4 : n4 - 1;
+        float r[4] = { (xr[i].x - mean) * sc, (xr[i].y - mean) * sc, (xr[i].z - mean) * sc, (xr[i].w - mean) * sc };
+        if (a.w) { const float4 w = *(const float4 *) (a.w + c4*4); r[0] = r[0]*w.x; r[1] = r[1]*w.y; r[2] = r[2]*w.z; r[3] = r[3]*w.w; }
+        if (a.b) { const float4 b = *(const float4 *) (a.b + c4*4); r[0] = r[0]+b.x; r[1] = r[1]+b.y; r[2] = r[2]+b.z; r[3] = r[3]+b.w; }
+        if (e4 < n4) *(float4 *) (y + (size_t) e4*4) = make_float4(r[0], r[1], r[2], r[3]);
+        if (a.prep) {
+            // the activation preparation of the MFMA GEMM that consumes this LayerNorm (k_prep_act, gemm_mfma.hip), on the values
+            // just stored: same operations in the same order, so the f16 matrix is bit-identical to a separate pass over y.
+            // A Q8_0 block (32 elements) is 8 neighbouring lanes of this iteration, a Q8_K block (256) the whole wave.
+            float q[4];
+            if (a.prep_mode == 0) { q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = r[3]; }
+            else if (a.prep_mode == 1) {
+                float amax = fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3])));
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+                const float d  = round_f16(amax / 127.0f);
+                const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+                #pragma unroll
+                for (int j = 0; j < 4; j++) q[j] = d * rintf(r[j]*id);
+            } else {
+                float mx = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+                float mn = fminf(fminf(r[0], r[1]), fminf(r[2], r[3]));
+                #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+                const float amax = fmaxf(mx, -mn);
+                const float maxv = (mx >= -mn) ? mx : mn;
+                if (amax == 0.0f) { q[0] = q[1] = q[2] = q[3] = 0.0f; }
+                else {
+                    const float iscale = -127.0f / maxv;
+                    const float d = 1.0f / iscale;
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) q[j] = d * fminf(127.0f, rintf(iscale * r[j]));
+                }
+            }
+            if (a.prep_mode != 0) {
+                #pragma unroll
+                for (int j = 0; j < 4; j++) q[j] = fminf(fmaxf(q[j], -65504.0f), 65504.0f);
+            }
+            if (e4 < n4) *(uint2 *) (a.prep + row * n + (size_t) e4*4) = make_uint2(f2h(q[0]) | ((uint32_t) f2h(q[1]) << 16), f2h(q[2]) | ((uint32_t) f2h(q[3]) << 16));
         }
     }
 }
+// LayerNorm that also leaves the prepared f16 [T][K] activation matrix of the GEMM consuming it (mi355x_prep_act's result on dst)
+extern "C" int mi355x_norm_prep(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y, float eps, const float * w, const float * b,
+                                void * prep, int mode) {
+    const int64_t K = x->ne[0];
+    if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
+    if (!prep || mode < 0 || mode > 2 || x->ne[2] != 1 || x->ne[3] != 1 || K % 4 || K > 2048 || (mode == 1 && K % 32) || (mode == 2 && K % 256)) return MI355X_E_UNSUPPORTED;
+    if (((uintptr_t) x->data | (uintptr_t) y->data | (uintptr_t) w | (uintptr_t) b | (uintptr_t) prep) % 16 || (x->nb[1] | y->nb[1]) % 16) return MI355X_E_UNSUPPORTED;
+    NormArgs k = { to_d(x), to_d(y), eps, w, b, t_nrows(x), (uint16_t *) prep, mode };
+    if (k.nrows == 0 || K == 0) return 0;
+    return emit(ctx, "norm_prep", k_norm_v4, dim3((uint32_t) ((k.nrows + 3) / 4)), dim3(256), 0, k, (double) t_nelements(x) * 10, 0);
+}
+
 extern "C" int mi355x_norm(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y, float eps, const float * w, const float * b) {
     if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
-    NormArgs k = { to_d(x), to_d(y), eps, w, b, t_nrows(x) };
+    NormArgs k = { to_d(x), to_d(y), eps, w, b, t_nrows(x), nullptr, 0 };
     if (k.nrows == 0 || x->ne[0] == 0) return 0;
     const bool v4 = x->ne[0] % 4 == 0 && x->ne[0] <= 2048 && ((uintptr_t) x->data | (uintptr_t) y->data | (uintptr_t) w | (uintptr_t) b) % 16 == 0 &&
                     (x->nb[1] | x->nb[2] | x->nb[3] | y->nb[1] | y->nb[2] | y->nb[3]) % 16 == 0;

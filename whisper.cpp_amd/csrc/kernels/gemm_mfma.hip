@@ -410,12 +410,11 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const GemmArgs a) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 template <int BN, int NST>
-__global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
+__device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int tile, char * ring) {
     constexpr int WN = BN / 2, NT = WN / 32;
     constexpr int STAGE = (BM + BN) * 128;            // bytes per stage: A tile [128][64] f16, B tile [BN][64] f16
     constexpr int GA = BM / 32, GB = BN / 32;         // LDS-DMA instructions per wave and stage: 8 rows each
     constexpr int G = GA + GB;
-    extern __shared__ __attribute__((aligned(16))) char ring[];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -424,9 +423,6 @@ __global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
     // the 7 MB of operands of a 1280 x 1500 x 1280 product.  Here XCD x = id % 8 works through the contiguous tile range
     // [x*per, (x+1)*per) of an order in which neighbours share an operand (whole columns of tiles, or whole rows —
     // whichever moves fewer bytes, chosen on the host).
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int tile = xcd * a.per + idx;
-    if (tile >= a.mt * a.nt) return;                  // padding blocks of the last XCD range (uniform exit, before any barrier)
     const int mi = a.m_major ? tile / a.nt : tile % a.mt;
     const int ni = a.m_major ? tile % a.nt : tile / a.mt;
     const int m0 = mi * BM;
@@ -503,30 +499,156 @@ __global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
 }
 
 template <int BN, int NST>
-static int launch_ring(mi355x_ctx * ctx, const GemmArgs & k0, dim3 tiles, double bytes, double flops) {
-    constexpr uint32_t lds = (uint32_t) NST * (BM + BN) * 128;
-    GemmArgs k = k0;
-    k.mt = (int) tiles.x; k.nt = (int) tiles.y;
+__global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = xcd * a.per + idx;
+    if (tile >= a.mt * a.nt) return;                  // padding blocks of the last XCD range (uniform exit, before any barrier)
+    gemm_ring_tile<BN, NST>(a, tile, ring);
+}
+
+// Grouped form: up to GEMM_GROUP_MAX independent products with the SAME activation matrix B and the same shape (the Q / K / V
+// projections of an encoder layer; the cross-attention K / V projections of consecutive decoder layers), one launch.  The tile
+// space is the concatenation of the members' tile spaces, dealt to the XCDs in contiguous ranges like the single form, so an XCD
+// mostly stays inside one member (one A) and B is shared by all of them.  Three 1280 x 1500 x 1280 products alone are 3 x 240
+// tiles of 128 x 64 on 256 CUs with three launch / ring-fill / drain phases; together they are 360 tiles of 128 x 128 with one.
+// Every tile runs exactly the code of the single form: results are bit-identical.
+#define GEMM_GROUP_MAX 8
+struct GemmGroupArgs { GemmArgs g[GEMM_GROUP_MAX]; int n, tiles_per_member, per; };
+
+template <int BN, int NST>
+__global__ void __launch_bounds__(256) k_gemm_f16_ring_group(const GemmGroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char ring[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t = xcd * ga.per + idx;
+    if (t >= ga.n * ga.tiles_per_member) return;
+    const int gi = t / ga.tiles_per_member;
+    gemm_ring_tile<BN, NST>(ga.g[gi], t - gi * ga.tiles_per_member, ring);
+}
+
+// tile counts of one member + the XCD-aware tile order for ranges of `per` consecutive tiles
+template <int BN>
+static void ring_tiling(GemmArgs & k, int64_t per) {
+    k.mt = (int) ((k.M + BM - 1) / BM); k.nt = (int) ((k.T + BN - 1) / BN);
     const int64_t ntiles = (int64_t) k.mt * k.nt;
-    k.per = (int) ((ntiles + 7) / 8);
-    {   // bytes each XCD pulls through its L2 for its `per` consecutive tiles, column-major vs row-major tile order
-        const double a_tile = (double) BM * k.K * 2, b_tile = (double) BN * k.K * 2;
-        const double col_major = a_tile * (k.per < k.mt ? k.per : k.mt) + b_tile * ((k.per + k.mt - 1) / k.mt + (k.per % k.mt ? 1 : 0));
-        const double row_major = b_tile * (k.per < k.nt ? k.per : k.nt) + a_tile * ((k.per + k.nt - 1) / k.nt + (k.per % k.nt ? 1 : 0));
-        static const int force = getenv("GGML_MI355X_GEMM_XCD_ORDER") ? atoi(getenv("GGML_MI355X_GEMM_XCD_ORDER")) : -1;
-        k.m_major = force >= 0 ? force : (row_major < col_major ? 1 : 0);
-    }
-    const dim3 grid((uint32_t) (8 * k.per));
-    static std::atomic<bool> attr_set[64];             // > 64 KB of dynamic LDS needs the attribute once per function AND device
-    const int dev = ctx->device & 63;
+    k.per = (int) (per < ntiles ? per : ntiles);
+    // bytes each XCD pulls through its L2 for its `per` consecutive tiles, column-major vs row-major tile order
+    const double a_tile = (double) BM * k.K * 2, b_tile = (double) BN * k.K * 2;
+    const double col_major = a_tile * (k.per < k.mt ? k.per : k.mt) + b_tile * ((k.per + k.mt - 1) / k.mt + (k.per % k.mt ? 1 : 0));
+    const double row_major = b_tile * (k.per < k.nt ? k.per : k.nt) + a_tile * ((k.per + k.nt - 1) / k.nt + (k.per % k.nt ? 1 : 0));
+    static const int force = getenv("GGML_MI355X_GEMM_XCD_ORDER") ? atoi(getenv("GGML_MI355X_GEMM_XCD_ORDER")) : -1;
+    k.m_major = force >= 0 ? force : (row_major < col_major ? 1 : 0);
+}
+
+template <typename F>
+static int ring_lds_attr(mi355x_ctx * ctx, F func, uint32_t lds, std::atomic<bool> * attr_set) {
+    const int dev = ctx->device & 63;                   // > 64 KB of dynamic LDS needs the attribute once per function AND device
     if (!attr_set[dev].load()) {
-        if (hipFuncSetAttribute((const void *) k_gemm_f16_ring<BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *) func, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) {
             (void) hipGetLastError();
             return MI355X_E_UNSUPPORTED;
         }
         attr_set[dev].store(true);
     }
-    return emit(ctx, "gemm_f16_ring", k_gemm_f16_ring<BN, NST>, grid, dim3(256), lds, k, bytes, flops);
+    return 0;
+}
+
+template <int BN, int NST>
+static int launch_ring(mi355x_ctx * ctx, const GemmArgs & k0, double bytes, double flops) {
+    constexpr uint32_t lds = (uint32_t) NST * (BM + BN) * 128;
+    GemmArgs k = k0;
+    const int64_t ntiles = ((k.M + BM - 1) / BM) * ((k.T + BN - 1) / BN);
+    ring_tiling<BN>(k, (ntiles + 7) / 8);
+    k.per = (int) ((ntiles + 7) / 8);
+    static std::atomic<bool> attr_set[64];
+    if (ring_lds_attr(ctx, k_gemm_f16_ring<BN, NST>, lds, attr_set) != 0) return MI355X_E_UNSUPPORTED;
+    return emit(ctx, "gemm_f16_ring", k_gemm_f16_ring<BN, NST>, dim3((uint32_t) (8 * k.per)), dim3(256), lds, k, bytes, flops);
+}
+
+template <int BN, int NST>
+static int launch_ring_group(mi355x_ctx * ctx, const GemmArgs * members, int n, double bytes, double flops) {
+    constexpr uint32_t lds = (uint32_t) NST * (BM + BN) * 128;
+    GemmGroupArgs ga; memset(&ga, 0, sizeof(ga));
+    const int64_t tiles = ((members[0].M + BM - 1) / BM) * ((members[0].T + BN - 1) / BN);
+    const int64_t per = (n * tiles + 7) / 8;
+    for (int i = 0; i < n; i++) { ga.g[i] = members[i]; ring_tiling<BN>(ga.g[i], per); }
+    ga.n = n; ga.tiles_per_member = (int) tiles; ga.per = (int) per;
+    static std::atomic<bool> attr_set[64];
+    if (ring_lds_attr(ctx, k_gemm_f16_ring_group<BN, NST>, lds, attr_set) != 0) return MI355X_E_UNSUPPORTED;
+    return emit(ctx, "gemm_f16_ring_group", k_gemm_f16_ring_group<BN, NST>, dim3((uint32_t) (8 * per)), dim3(256), lds, ga, bytes, flops);
+}
+
+// ---- held-back ring GEMMs (mi355x_ctx::pending_*) ---------------------------------------------------------------------------
+struct PendingGemms { GemmArgs k[GEMM_GROUP_MAX]; double bytes, flops; };
+static_assert(sizeof(PendingGemms) <= sizeof(((mi355x_ctx *) nullptr)->pending_store), "pending_store too small");
+
+static bool mem_overlap(const void * a, int64_t na, const void * b, int64_t nb) {
+    return a && b && na > 0 && nb > 0 && (const char *) a < (const char *) b + nb && (const char *) b < (const char *) a + na;
+}
+static int64_t gemm_dst_bytes(const GemmArgs & k) { return (k.T - 1) * k.dst_nb1 + (int64_t) k.M * (k.dst_f16 ? 2 : 4); }
+static int64_t gemm_res_bytes(const GemmArgs & k) { return k.residual ? (k.T - 1) * k.res_nb1 + (int64_t) k.M * 4 : 0; }
+
+// may `k` join the held-back members?  Same B and shape, and no member reads or writes what another member writes.
+static bool gemm_mergeable(const PendingGemms & P, int n, const GemmArgs & k) {
+    const GemmArgs & f = P.k[0];
+    if (n >= GEMM_GROUP_MAX || k.B != f.B || k.ldb != f.ldb || k.K != f.K || k.T != f.T || k.M != f.M) return false;
+    const int64_t kd = gemm_dst_bytes(k);
+    if (mem_overlap(k.dst, kd, k.B, k.T * k.ldb * 2)) return false;
+    for (int i = 0; i < n; i++) {
+        const GemmArgs & e = P.k[i];
+        const int64_t ed = gemm_dst_bytes(e);
+        if (mem_overlap(k.dst, kd, e.dst, ed)) return false;
+        if (mem_overlap(k.residual, gemm_res_bytes(k), e.dst, ed) || mem_overlap(e.residual, gemm_res_bytes(e), k.dst, kd)) return false;
+        if (mem_overlap(k.A, (int64_t) k.M * k.a_nb1, e.dst, ed) || mem_overlap(e.A, (int64_t) e.M * e.a_nb1, k.dst, kd)) return false;
+        if (mem_overlap(k.bias, (int64_t) k.M * 4, e.dst, ed) || mem_overlap(e.bias, (int64_t) e.M * 4, k.dst, kd)) return false;
+    }
+    return true;
+}
+
+static int flush_pending_gemms(mi355x_ctx * ctx) {
+    PendingGemms P; memcpy(&P, ctx->pending_store, sizeof(P));
+    const int n = ctx->pending_n;
+    ctx->pending_n = 0;
+    ctx->in_flush = true;
+    const GemmArgs & k = P.k[0];
+    const int64_t mt = (k.M + BM - 1) / BM, nt128 = (k.T + 127) / 128;
+    int rc;
+    if (n == 1) {
+        // stages: measured on large-v3 encode — 64-wide tiles (one block per CU): 2 -> 13.0 ms, 3 -> 11.3, 4 -> 10.9, 5/6 no better;
+        // 128-wide tiles (FC1, ~2 blocks per CU): 2 stages (64 KB, two blocks co-resident) 10.6-10.8 vs 3 -> 10.9, 4 -> 11.0
+        static const int nst128 = getenv("GGML_MI355X_GEMM_RING_NST128") ? atoi(getenv("GGML_MI355X_GEMM_RING_NST128")) : 2;
+        static const int nst64  = getenv("GGML_MI355X_GEMM_RING_NST64")  ? atoi(getenv("GGML_MI355X_GEMM_RING_NST64"))  : 4;
+        if (mt * nt128 >= ctx->n_cu) rc = nst128 == 2 ? launch_ring<128, 2>(ctx, k, P.bytes, P.flops)
+                                        : nst128 == 4 ? launch_ring<128, 4>(ctx, k, P.bytes, P.flops)
+                                                      : launch_ring<128, 3>(ctx, k, P.bytes, P.flops);
+        else                         rc = nst64 == 2 ? launch_ring<64, 2>(ctx, k, P.bytes, P.flops)
+                                        : nst64 == 3 ? launch_ring<64, 3>(ctx, k, P.bytes, P.flops)
+                                        : nst64 == 5 ? launch_ring<64, 5>(ctx, k, P.bytes, P.flops)
+                                        : nst64 == 6 ? launch_ring<64, 6>(ctx, k, P.bytes, P.flops)
+                                                     : launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
+    } else {
+        // together the members cover the chip with 128-wide token tiles where one alone would not
+        if (n * mt * nt128 >= ctx->n_cu) rc = launch_ring_group<128, 2>(ctx, P.k, n, P.bytes, P.flops);
+        else                             rc = launch_ring_group<64, 4>(ctx, P.k, n, P.bytes, P.flops);
+    }
+    ctx->in_flush = false;
+    if (rc == MI355X_E_UNSUPPORTED) { mi355x_set_error("ring GEMM: dynamic LDS attribute rejected"); rc = (int) hipErrorInvalidValue; }
+    return rc;
+}
+
+// hold a ring GEMM back; it leaves with the next flush (mi355x_flush_pending: any other launch, synchronize, end of the graph range)
+static int hold_ring_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, double flops) {
+    static const bool group_on = !(getenv("GGML_MI355X_GEMM_GROUP") && !atoi(getenv("GGML_MI355X_GEMM_GROUP")));
+    PendingGemms * P = (PendingGemms *) ctx->pending_store;
+    if (ctx->pending_n > 0 && !(group_on && gemm_mergeable(*P, ctx->pending_n, k))) {
+        const int rc = flush_pending_gemms(ctx);
+        if (rc) return rc;
+    }
+    if (ctx->pending_n == 0) { P->bytes = 0; P->flops = 0; }
+    P->k[ctx->pending_n++] = k;
+    P->bytes += bytes; P->flops += flops;
+    ctx->pending_flush = flush_pending_gemms;
+    return 0;
 }
 
 template <int AT>
@@ -538,21 +660,7 @@ static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, doubl
         // both operands plain f16: the LDS-DMA ring (GGML_MI355X_GEMM_RING=0 keeps the register-staged kernel)
         static const bool ring_on = !(getenv("GGML_MI355X_GEMM_RING") && !atoi(getenv("GGML_MI355X_GEMM_RING")));
         if (ring_on && k.K % BK == 0 && k.K >= 2*BK && (k.a_nb1 % 16) == 0 && ((uintptr_t) k.A % 16) == 0 && (k.ldb % 8) == 0 && nt64 <= 65535) {
-            int rc;
-            // stages: measured on large-v3 encode — 64-wide tiles (one block per CU): 2 -> 13.0 ms, 3 -> 11.3, 4 -> 10.9, 5/6 no better;
-            // 128-wide tiles (FC1, ~2 blocks per CU): 2 stages (64 KB, two blocks co-resident) 10.6-10.8 vs 3 -> 10.9, 4 -> 11.0
-            static const int nst128 = getenv("GGML_MI355X_GEMM_RING_NST128") ? atoi(getenv("GGML_MI355X_GEMM_RING_NST128")) : 2;
-            static const int nst64  = getenv("GGML_MI355X_GEMM_RING_NST64")  ? atoi(getenv("GGML_MI355X_GEMM_RING_NST64"))  : 4;
-            const dim3 g128((uint32_t) mt, (uint32_t) nt128), g64((uint32_t) mt, (uint32_t) nt64);
-            if (mt * nt128 >= ctx->n_cu) rc = nst128 == 2 ? launch_ring<128, 2>(ctx, k, g128, bytes, flops)
-                                            : nst128 == 4 ? launch_ring<128, 4>(ctx, k, g128, bytes, flops)
-                                                          : launch_ring<128, 3>(ctx, k, g128, bytes, flops);
-            else                         rc = nst64 == 2 ? launch_ring<64, 2>(ctx, k, g64, bytes, flops)
-                                            : nst64 == 3 ? launch_ring<64, 3>(ctx, k, g64, bytes, flops)
-                                            : nst64 == 5 ? launch_ring<64, 5>(ctx, k, g64, bytes, flops)
-                                            : nst64 == 6 ? launch_ring<64, 6>(ctx, k, g64, bytes, flops)
-                                                         : launch_ring<64, 4>(ctx, k, g64, bytes, flops);
-            if (rc != MI355X_E_UNSUPPORTED) return rc;
+            return hold_ring_gemm(ctx, k, bytes, flops);
         }
     }
     if (mt * nt128 >= ctx->n_cu || k.T > 64*65535LL) {

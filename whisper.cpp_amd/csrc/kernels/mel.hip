@@ -102,6 +102,7 @@ extern "C" int mi355x_log_mel(mi355x_ctx * ctx, const float * pcm_dev, int n_sam
     const int64_t live = ((int64_t) n_samples + MEL_N_FFT / 2) / MEL_HOP + 1;            // log_mel_spectrogram_worker_thread: i < min(n_samples / frame_step + 1, n_len)
     a.n_live = (int) (live < n_len ? live : n_len);
     a.maxbits = (unsigned int *) (ctx->mel_tab + 3*MEL_N_FFT);
+    { const int rc = mi355x_flush_pending(ctx); if (rc) return rc; }
     HIP_CHECK_RET(hipMemsetAsync(a.maxbits, 0, 4, ctx->stream));
     int rc = emit(ctx, "log_mel", k_log_mel, dim3((uint32_t) n_len), dim3(256), 0, a, (double) n_samples * 4 + (double) n_mel * n_len * 4, 2.0 * 2 * MEL_BINS * MEL_N_FFT * a.n_live);
     if (rc) return rc;
