@@ -1,10 +1,15 @@
 #!/bin/bash
+# grouped encoder GEMMs + LayerNorm/prep fusion + replica path on one GPU: full GPU suite, headline bench
 cd "$(dirname "$0")/.."
 OUT=gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 date +%T
-for cfg in "1 8" "0 8" "1 4" "0 4"; do set -- $cfg
-  echo "GRAPHS=$1 HW_QUEUES=$2"
-  GGML_MI355X_GRAPHS=$1 STREAM_HW_QUEUES=$2 GPU_MAX_HW_QUEUES=$2 timeout 600 python3 scripts/stream_scaling.py large-v3 q5_0 1 2 4 8 2>&1 | tail -1 | cut -c1-700
-done | tee $OUT/stream_scaling_graphs_vs_eager.txt
+bash scripts/gpu_round.sh pytest bench > $OUT/round_call8.log 2>&1
+grep -E "passed|failed|^FAILED|^ERROR" $OUT/pytest_gpu.txt | tail -12
+cut -c1-900 $OUT/bench_large-v3_q5_0.json
+python3 - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_large-v3_q5_0.json').read().strip().splitlines()[-1])
+print(json.dumps(d.get('kernel_time_ms_per_chunk'))[:1500])
+PY
 date +%T

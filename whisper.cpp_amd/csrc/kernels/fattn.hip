@@ -66,21 +66,24 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
     // staging: thread -> (key = tid>>3 [+32], chunk = tid&7): 16 bytes = 8 d-values
     const int skey = tid >> 3, sch = tid & 7;
 
+    // this thread's share of a K/V tile, global -> registers.  Keys past n_kv are clamped to the last key (always a valid address:
+    // an unconditional load has no basic block of its own and therefore no s_waitcnt vmcnt(0) behind it); their scores are
+    // forced to -inf below, so their values never matter.
+    uint4 kr0, kr1, vr0, vr1;
+#define FA_FETCH(K0) do { \
+        const int key0_ = min((K0) + skey, a.n_kv - 1), key1_ = min((K0) + skey + 32, a.n_kv - 1); \
+        kr0 = *(const uint4 *) (kbase + (int64_t) key0_*a.k.nb[1] + sch*16); vr0 = *(const uint4 *) (vbase + (int64_t) key0_*a.v.nb[1] + sch*16); \
+        kr1 = *(const uint4 *) (kbase + (int64_t) key1_*a.k.nb[1] + sch*16); vr1 = *(const uint4 *) (vbase + (int64_t) key1_*a.v.nb[1] + sch*16); \
+    } while (0)
+    FA_FETCH(0);
     for (int k0 = 0; k0 < a.n_kv; k0 += KT) {
-        uint4 kr[2], vr[2];
-        #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int key = k0 + skey + 32*i;
-            const bool ok = key < a.n_kv;
-            kr[i] = ok ? *(const uint4 *) (kbase + (int64_t) key*a.k.nb[1] + sch*16) : make_uint4(0, 0, 0, 0);
-            vr[i] = ok ? *(const uint4 *) (vbase + (int64_t) key*a.v.nb[1] + sch*16) : make_uint4(0, 0, 0, 0);
-        }
         __syncthreads();                                      // previous tile fully consumed
         #pragma unroll
         for (int i = 0; i < 2; i++) {
             const int kl = skey + 32*i;
-            *(uint4 *) (ldsK + k_off(kl, sch)) = kr[i];
-            const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
+            const uint4 kq = i ? kr1 : kr0, vq = i ? vr1 : vr0;
+            *(uint4 *) (ldsK + k_off(kl, sch)) = kq;
+            const uint32_t w[4] = { vq.x, vq.y, vq.z, vq.w };
             #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const uint16_t hv16 = (uint16_t) ((w[e >> 1] >> (16*(e & 1))) & 0xFFFF);
@@ -88,6 +91,8 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
             }
         }
         __syncthreads();
+        // the next tile's loads are in flight while this one is computed (clamped past the end: harmless re-read of the last keys)
+        FA_FETCH(k0 + KT);
 
         // S^T[key][query] for the two 32-key blocks of the tile
         floatx16 s[2];

@@ -618,6 +618,12 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
         // 128-wide tiles (FC1, ~2 blocks per CU): 2 stages (64 KB, two blocks co-resident) 10.6-10.8 vs 3 -> 10.9, 4 -> 11.0
         static const int nst128 = getenv("GGML_MI355X_GEMM_RING_NST128") ? atoi(getenv("GGML_MI355X_GEMM_RING_NST128")) : 2;
         static const int nst64  = getenv("GGML_MI355X_GEMM_RING_NST64")  ? atoi(getenv("GGML_MI355X_GEMM_RING_NST64"))  : 4;
+        // GGML_MI355X_GEMM_RING_BIG=<BN><stages> (e.g. 642): A-B override of the tile width / depth for products that cover the chip
+        static const int big = getenv("GGML_MI355X_GEMM_RING_BIG") ? atoi(getenv("GGML_MI355X_GEMM_RING_BIG")) : 0;
+        if (mt * nt128 >= ctx->n_cu && big == 642)      rc = launch_ring<64, 2>(ctx, k, P.bytes, P.flops);
+        else if (mt * nt128 >= ctx->n_cu && big == 643) rc = launch_ring<64, 3>(ctx, k, P.bytes, P.flops);
+        else if (mt * nt128 >= ctx->n_cu && big == 644) rc = launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
+        else
         if (mt * nt128 >= ctx->n_cu) rc = nst128 == 2 ? launch_ring<128, 2>(ctx, k, P.bytes, P.flops)
                                         : nst128 == 4 ? launch_ring<128, 4>(ctx, k, P.bytes, P.flops)
                                                       : launch_ring<128, 3>(ctx, k, P.bytes, P.flops);
@@ -627,9 +633,21 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
                                         : nst64 == 6 ? launch_ring<64, 6>(ctx, k, P.bytes, P.flops)
                                                      : launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
     } else {
-        // together the members cover the chip with 128-wide token tiles where one alone would not
-        if (n * mt * nt128 >= ctx->n_cu) rc = launch_ring_group<128, 2>(ctx, P.k, n, P.bytes, P.flops);
-        else                             rc = launch_ring_group<64, 4>(ctx, P.k, n, P.bytes, P.flops);
+        // (GGML_MI355X_GEMM_GROUP_CFG=<BN><stages>, e.g. 643: A-B measurements of the tile width / ring depth of the grouped form)
+        static const int cfg = getenv("GGML_MI355X_GEMM_GROUP_CFG") ? atoi(getenv("GGML_MI355X_GEMM_GROUP_CFG")) : 0;
+        switch (cfg) {
+            case 642:  rc = launch_ring_group<64, 2>(ctx, P.k, n, P.bytes, P.flops); break;
+            case 643:  rc = launch_ring_group<64, 3>(ctx, P.k, n, P.bytes, P.flops); break;
+            case 644:  rc = launch_ring_group<64, 4>(ctx, P.k, n, P.bytes, P.flops); break;
+            case 1282: rc = launch_ring_group<128, 2>(ctx, P.k, n, P.bytes, P.flops); break;
+            case 1283: rc = launch_ring_group<128, 3>(ctx, P.k, n, P.bytes, P.flops); break;
+            default:
+                // measured on large-v3 encode (32 Q/K/V groups + 8 cross-K/V groups of 8, profiles/r02_encoder_ab.txt): 64-wide tiles
+                // with a 2-stage ring (48 KB: three workgroups co-resident per CU, each other's DMA waits hidden) 2.13 ms;
+                // 64 x 3 stages (2 per CU) 2.81; 128 x 2 stages (2 per CU) 2.63; 64 x 4 (1 per CU) 3.51; 128 x 3 (1 per CU) 3.88;
+                // the same products as single launches (64 x 4) 2.9
+                rc = launch_ring_group<64, 2>(ctx, P.k, n, P.bytes, P.flops);
+        }
     }
     ctx->in_flush = false;
     if (rc == MI355X_E_UNSUPPORTED) { mi355x_set_error("ring GEMM: dynamic LDS attribute rejected"); rc = (int) hipErrorInvalidValue; }
