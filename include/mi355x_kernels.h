@@ -145,6 +145,11 @@ MI355X_API int mi355x_mul_mat(mi355x_ctx * ctx, const mi355x_tensor * w, const m
 MI355X_API int mi355x_prep_act(mi355x_ctx * ctx, const void * x, int64_t x_nb1, int x_is_f16, void * act_f16, int K, int64_t T, int mode);
 MI355X_API int mi355x_gemm_f16act(mi355x_ctx * ctx, const mi355x_tensor * w, const void * act_f16, int64_t ld, int64_t T,
                                   void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep /* nullable */);
+/* the same product, whose epilogue ALSO leaves mi355x_prep_act(mode 1) of the F32 result in prep_out (f16 [T][M], M % 32 == 0): the result
+ * is the activation matrix of the next quantized-weight GEMM (fc1 + GELU -> fc2, src/whisper.cpp:2224-2238), bit-identical to a separate
+ * mi355x_prep_act pass over dst.  dst may be NULL when nothing else reads the F32 result (then only prep_out is written). */
+MI355X_API int mi355x_gemm_f16act_prep(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act_f16, int64_t ldb, int64_t T,
+                                       void * dst, int64_t dst_nb1, const mi355x_epilogue * ep, void * prep_out);
 
 /* One-time preparation of a quantized weight for the MFMA path: writes dst_f16[M][K] = f16(dequantized w), the
  * exact values mi355x_gemm_f16act feeds the matrix cores when given the quantized tensor.  A caller that keeps
@@ -208,6 +213,11 @@ MI355X_API int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_par
 MI355X_API int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k,
                                      const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */,
                                      const mi355x_tensor * dst, float scale);
+/* T > 8: the same, also leaving mi355x_prep_act(mode 1) of dst seen as [T][H*64] in prep_out (f16) — the activation matrix of the
+ * quantized-weight output projection that consumes it (src/whisper.cpp:2165-2167 -> :2199-2203); bit-identical to the separate pass */
+MI355X_API int mi355x_flash_attn_ext_prep(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k,
+                                          const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */,
+                                          const mi355x_tensor * dst, float scale, void * prep_out);
 
 /* ggml_flash_attn_ext with the ARITHMETIC of the reference CPU dispatcher (ggml-cpu/ops.cpp:9077-9230), opt-in: split-KV over
  * `nth` chunks for T == 1 && n_kv >= 512 (the CPU's result depends on its thread count), the F32 tiled path with ggml_v_expf for

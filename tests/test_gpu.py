@@ -209,6 +209,33 @@ def test_layernorm_with_fused_activation_preparation_is_bit_identical_to_two_pas
     assert np.array_equal(a, c) and a.any()
 
 
+@pytest.mark.parametrize("K,N,T,gelu,keep", [(1280, 5120, 1500, True, False), (1280, 5120, 1500, True, True), (512, 384, 77, False, True), (384, 1536, 40, True, False)])
+def test_gemm_epilogue_writing_the_next_gemms_activations_is_bit_identical_to_two_passes(gpu, K, N, T, gelu, keep):
+    """mi355x_gemm_f16act_prep (fc1 + bias + GELU whose result feeds fc2): the f16 activation matrix written by the epilogue equals
+    mi355x_prep_act(mode 1) of the separately stored F32 result word for word, with and without the F32 result being stored too"""
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(K + N + T)
+    w = dev(torch, (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float16))
+    act = dev(torch, rng.standard_normal((T, K)).astype(np.float16))
+    bias = dev(torch, rng.standard_normal(N).astype(np.float32))
+    ep = ka.Epilogue()
+    ep.bias, ep.gelu = bias.data_ptr(), int(gelu)
+    y1, y2 = (torch.zeros((T, N), dtype=torch.float32, device="cuda:0") for _ in range(2))
+    p1, p2 = (torch.zeros((T, N), dtype=torch.float16, device="cuda:0") for _ in range(2))
+    torch.cuda.synchronize()
+    tw = ka.tensor(w.data_ptr(), ka.F16, [K, N])
+    ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), K, T, y1.data_ptr(), N * 4, ka.F32, C.byref(ep)), "gemm")
+    ctx.check(ka.lib().mi355x_prep_act(ctx.h, y1.data_ptr(), N * 4, 0, p1.data_ptr(), N, T, 1), "prep_act")
+    ctx.check(ka.lib().mi355x_gemm_f16act_prep(ctx.h, C.byref(tw), act.data_ptr(), K, T, y2.data_ptr() if keep else None, N * 4, C.byref(ep), p2.data_ptr()), "gemm_prep")
+    ctx.sync()
+    a, b = p1.cpu().numpy().view(np.uint16), p2.cpu().numpy().view(np.uint16)
+    assert a.any() and np.array_equal(a, b)
+    if keep:
+        assert np.array_equal(y1.cpu().numpy().view(np.uint32), y2.cpu().numpy().view(np.uint32))
+    else:
+        assert not y2.cpu().numpy().any()                    # the F32 result was not stored
+
+
 def test_mul_mat_f16_weights(gpu, oracle):
     _, ka, _ = gpu
     rng = np.random.default_rng(5)
@@ -474,6 +501,38 @@ def test_flash_attn_vs_oracle(gpu, oracle, T, n_kv, H, mask):
     assert e_got < 1e-9 + e_ref, (e_got, e_ref)
     assert e_got < 1e-6, e_got
     assert nmse(ref, got) < 1e-4, nmse(ref, got)
+
+
+@pytest.mark.parametrize("T,n_kv,H,mask", [(1500, 1536, 20, False), (300, 300, 6, True), (77, 136, 8, False)])
+def test_flash_attn_writing_the_output_projections_activations_is_bit_identical_to_two_passes(gpu, T, n_kv, H, mask):
+    """mi355x_flash_attn_ext_prep: same attention result, and the f16 activation matrix of the output projection (Q8_0 rounding of every
+    32 dims, mi355x_prep_act mode 1) written by the attention kernel equals the separate pass over the result word for word"""
+    ctx, ka, torch = gpu
+    D = 64
+    rng = np.random.default_rng(T + n_kv + H)
+    q_d = dev(torch, (rng.standard_normal((T, H, D)) * 0.6).astype(np.float32))
+    k_d = dev(torch, (rng.standard_normal((n_kv, H, D)) * 0.6).astype(np.float16))
+    v_d = dev(torch, rng.standard_normal((n_kv, H, D)).astype(np.float16))
+    tm = None
+    if mask:
+        mf = np.zeros((T, n_kv), dtype=np.float32)
+        for t in range(T):
+            mf[t, max(1, n_kv - T + t + 1):] = -np.inf
+        m_d = dev(torch, mf.astype(np.float16))
+        tm = C.byref(ka.tensor(m_d.data_ptr(), ka.F16, [n_kv, T]))
+    o1, o2 = (torch.zeros((T, H, D), dtype=torch.float32, device="cuda:0") for _ in range(2))
+    p1, p2 = (torch.zeros((T, H * D), dtype=torch.float16, device="cuda:0") for _ in range(2))
+    torch.cuda.synchronize()
+    tq = ka.tensor(q_d.data_ptr(), ka.F32, [D, T, H], [4, H * D * 4, D * 4, T * H * D * 4])
+    tk = ka.tensor(k_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    tv = ka.tensor(v_d.data_ptr(), ka.F16, [D, n_kv, H], [2, H * D * 2, D * 2, n_kv * H * D * 2])
+    ctx.check(ka.lib().mi355x_flash_attn_ext(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), tm, C.byref(ka.tensor(o1.data_ptr(), ka.F32, [D, H, T])), 0.125), "flash_attn")
+    ctx.check(ka.lib().mi355x_prep_act(ctx.h, o1.data_ptr(), H * D * 4, 0, p1.data_ptr(), H * D, T, 1), "prep_act")
+    ctx.check(ka.lib().mi355x_flash_attn_ext_prep(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), tm, C.byref(ka.tensor(o2.data_ptr(), ka.F32, [D, H, T])), 0.125, p2.data_ptr()), "flash_attn_prep")
+    ctx.sync()
+    assert np.array_equal(o1.cpu().numpy().view(np.uint32), o2.cpu().numpy().view(np.uint32))
+    a, b = p1.cpu().numpy().view(np.uint16), p2.cpu().numpy().view(np.uint16)
+    assert a.any() and np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("T,n_kv,H,mask,nth", [(1, 1536, 20, False, 8), (1, 1536, 20, False, 4), (1, 1536, 6, False, 32), (1, 600, 4, True, 8), (1, 37, 8, True, 8),

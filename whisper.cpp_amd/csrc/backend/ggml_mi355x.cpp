@@ -372,6 +372,7 @@ struct mi_backend_ctx {
     int          n_threads = 4;
     // f16 activation scratch for the MFMA path, shared by consecutive mul_mats with the same src1
     void *       act = nullptr; size_t act_size = 0;
+    void *       act_alt = nullptr; size_t act_alt_size = 0;     // second scratch: a GEMM reading `act` writes the next GEMM's prepared activations here
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
     // hipGraph replay, keyed by number of launches (decoder step / encoder graphs differ in length)
     std::vector<mi_graph_cache> gcache;
@@ -529,15 +530,18 @@ static const void * mi_shadow_get(mi_backend_ctx * b, const ggml_tensor * w, con
 }
 
 // room for T x K prepared f16 activations in the backend's scratch; 0 ok, < 0 recording aborted (grows on the eager re-run), > 0 error
-static int mi_act_reserve(mi_backend_ctx * b, size_t need) {
-    if (need <= b->act_size) return 0;
+static int mi_act_reserve(mi_backend_ctx * b, size_t need, bool alt = false) {
+    void * & buf = alt ? b->act_alt : b->act;
+    size_t & size = alt ? b->act_alt_size : b->act_size;
+    if (need <= size) return 0;
     if (b->recording) { b->record_abort = true; return -1; }
-    mi355x_ctx_synchronize(b->k);
-    if (b->act) (void) hipFree(b->act);
-    b->act = nullptr; b->act_size = 0; b->act_src = nullptr;
+    mi355x_ctx_synchronize(b->k);                 // (also sends held-back launches that still name the old buffer)
+    if (buf) (void) hipFree(buf);
+    buf = nullptr; size = 0;
+    if (!alt) b->act_src = nullptr;
     const size_t sz = need + (need >> 2);
-    if (hipMalloc(&b->act, sz) != hipSuccess) return (int) hipErrorOutOfMemory;
-    b->act_size = sz;
+    if (hipMalloc(&buf, sz) != hipSuccess) return (int) hipErrorOutOfMemory;
+    size = sz;
     return 0;
 }
 
@@ -555,7 +559,7 @@ static bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, 
     return true;
 }
 
-static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
+static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgraph * g = nullptr) {
     const ggml_tensor * mm = c.mm, * w = mm->src[0], * x = mm->src[1];
     mi355x_tensor mw = to_mt(w), mx = to_mt(x);
     // destination: the chain's last tensor, seen as [N, T] with the dtype of that tensor
@@ -601,6 +605,33 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
                 }
                 act = b->act; ld = K;
             }
+            // Is the result itself the activation matrix of the next node's MFMA GEMM (fc1 + GELU -> fc2)?  Then the epilogue writes
+            // that GEMM's prepared f16 activations (second scratch; this product still reads the first), and when nothing else reads
+            // the F32 result it is not stored at all: one launch, a 30 MB write and a 30 MB read less per encoder layer of large-v3.
+            static const bool prep_out_on = env_flag("GGML_MI355X_GEMM_PREP_OUT", true);
+            void * prep_out = nullptr; bool prep_only = false;
+            const int64_t M = mm->ne[0];
+            if (g && b->fuse && prep_out_on && act == b->act && c.last->type == GGML_TYPE_F32 && M % 32 == 0 && M <= 8192 &&
+                c.last->nb[0] == 4 && (int64_t) c.last->nb[1] == M*4 && c.last->ne[1] == T && c.last->ne[2] == 1 && c.last->ne[3] == 1) {
+                const int j = next_real(g, c.end);
+                int mode2 = -1;
+                if (j < g->n_nodes && mm_takes_prepared(b, g->nodes[j], c.last, mode2) && mode2 == 1 && mi_act_reserve(b, (size_t) T * M * 2, true) == 0) {
+                    prep_out = b->act_alt;
+                    prep_only = can_elide(g, c.last, 1);
+                }
+            }
+            auto gemm = [&](const mi355x_tensor & wt) {
+                if (prep_out) {
+                    const int rc = mi355x_gemm_f16act_prep(b->k, &wt, act, ld, T, prep_only ? nullptr : md.data, md.nb[1], has_ep ? &c.ep : nullptr, prep_out);
+                    if (rc == 0) {       // the next GEMM finds its activations prepared: the scratch buffers trade places
+                        std::swap(b->act, b->act_alt); std::swap(b->act_size, b->act_alt_size);
+                        b->act_src = c.last->data; b->act_K = M; b->act_T = T; b->act_mode = 1; b->act_nb1 = M*4;
+                        return 0;
+                    }
+                    if (rc != MI355X_E_UNSUPPORTED) return rc;
+                }
+                return mi355x_gemm_f16act(b->k, &wt, act, ld, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
+            };
             // wide activations: run the GEMM on the weight's f16 copy (same values, no dequantization in the loop)
             static const int shadow_min_t = getenv("GGML_MI355X_F16_SHADOW_MIN_T") ? atoi(getenv("GGML_MI355X_F16_SHADOW_MIN_T")) : 128;
             if (mode != 0 && T >= shadow_min_t) {
@@ -608,11 +639,11 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c) {
                     mi355x_tensor ms = mw;
                     ms.data = (void *) f16; ms.type = MI355X_TYPE_F16;
                     ms.nb[0] = 2; ms.nb[1] = K*2; ms.nb[2] = ms.nb[1]*w->ne[1]; ms.nb[3] = ms.nb[2];
-                    const int rc = mi355x_gemm_f16act(b->k, &ms, act, ld, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
+                    const int rc = gemm(ms);
                     if (rc != MI355X_E_UNSUPPORTED) return rc;
                 }
             }
-            const int rc = mi355x_gemm_f16act(b->k, &mw, act, ld, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
+            const int rc = gemm(mw);
             if (rc != MI355X_E_UNSUPPORTED) return rc;
         }
     }
@@ -904,7 +935,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         if (n->op == GGML_OP_MUL_MAT) {
             mm_chain c;
             parse_mm_chain(g, i, b->fuse, c);
-            rc = run_mm_chain(b, c);
+            rc = run_mm_chain(b, c, g);
             if (rc == MI355X_E_UNSUPPORTED && c.end != i) { parse_mm_chain(g, i, false, c); rc = run_mm_chain(b, c); }
             else i = c.end;
         } else if (n->op == GGML_OP_NORM) {
@@ -940,6 +971,26 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
             rc = mi355x_flash_attn_ext_exact(b->k, &q, &kk, &v, n->src[3] ? &m : nullptr, &d, scale, b->n_threads);
             if (rc == MI355X_E_UNSUPPORTED) rc = run_node(b, n);
             b->act_src = nullptr;
+        } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->fuse && n->src[0]->ne[1] > 8) {
+            // encoder / prompt attention whose result (through a reshape) is the activation matrix of the output projection: the
+            // attention kernel leaves that GEMM's prepared f16 activations as well (one launch and one pass over the result less)
+            static const bool on = env_flag("GGML_MI355X_FATTN_PREP_OUT", true);
+            const int j = next_real(g, i);
+            const int64_t T = n->src[0]->ne[1], NS = n->ne[0] * n->ne[1];
+            int mode = -1;
+            rc = MI355X_E_UNSUPPORTED;
+            if (on && j < g->n_nodes && g->nodes[j]->op == GGML_OP_MUL_MAT) {
+                const ggml_tensor * x = g->nodes[j]->src[1];
+                if (x->data == n->data && x->ne[0] == NS && x->ne[1] == T && (int64_t) x->nb[1] == NS*4 && ggml_is_contiguous(n) &&
+                    mm_takes_prepared(b, g->nodes[j], x, mode) && mode == 1 && mi_act_reserve(b, (size_t) T * NS * 2) == 0) {
+                    mi355x_tensor q = to_mt(n->src[0]), kk = to_mt(n->src[1]), v = to_mt(n->src[2]), d = to_mt(n), m;
+                    if (n->src[3]) m = to_mt(n->src[3]);
+                    float scale; memcpy(&scale, n->op_params, 4);
+                    rc = mi355x_flash_attn_ext_prep(b->k, &q, &kk, &v, n->src[3] ? &m : nullptr, &d, scale, b->act);
+                    if (rc == 0) { b->act_src = x->data; b->act_K = NS; b->act_T = T; b->act_mode = 1; b->act_nb1 = NS*4; }
+                }
+            }
+            if (rc == MI355X_E_UNSUPPORTED) { rc = run_node(b, n); b->act_src = nullptr; }
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->fuse && n->src[0]->ne[1] <= 8) {
             int end = i, rc2 = MI355X_E_UNSUPPORTED;
             if (try_fattn_gemv(b, g, i, end, rc2)) { rc = rc2; i = end; }
@@ -1061,6 +1112,7 @@ static void mi_backend_free(ggml_backend_t backend) {
     for (auto & e : b->span_ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     for (auto & c : b->gcache) { if (c.exec) (void) hipGraphExecDestroy(c.exec); if (c.graph) (void) hipGraphDestroy(c.graph); }
     if (b->act) (void) hipFree(b->act);
+    if (b->act_alt) (void) hipFree(b->act_alt);
     {
         std::lock_guard<std::mutex> lk(g_weights_mtx);
         for (size_t i = 0; i < g_backends.size(); i++) if (g_backends[i] == b) { g_backends.erase(g_backends.begin() + i); break; }

@@ -138,6 +138,16 @@ __global__ void __launch_bounds__(256) k_norm_v4(const NormArgs a) {
     float4 xr[8];
     #pragma unroll
     for (int i = 0; i < 8; i++) { const int e4 = lane + 64*i; xr[i] = *(const float4 *) (x + (size_t) (e4 < n4 ? e4 : n4 - 1)*4); }
+    // the affine parameters are requested together with the row (clamped, always-valid addresses: x itself stands in when a vector
+    // is absent), not after the two reductions: one memory round trip per row instead of two
+    const float * wp = a.w ? a.w : x, * bp = a.b ? a.b : x;
+    float4 wr[8], br[8];
+    #pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int e4 = lane + 64*i, c4 = e4 < n4 ? e4 : n4 - 1;
+        wr[i] = *(const float4 *) (wp + (size_t) c4*4);
+        br[i] = *(const float4 *) (bp + (size_t) c4*4);
+    }
     float s = 0.0f;
     #pragma unroll
     for (int i = 0; i < 8; i++) if (lane + 64*i < n4) s += (xr[i].x + xr[i].y) + (xr[i].z + xr[i].w);
@@ -155,10 +165,9 @@ __global__ void __launch_bounds__(256) k_norm_v4(const NormArgs a) {
     for (int i = 0; i < 8; i++) {
         const int e4 = lane + 64*i;
         if (64*i >= n4) break;                               // uniform: no lane of this wave has elements left
-        const int c4 = e4 < n4 ? e4 : n4 - 1;
         float r[4] = { (xr[i].x - mean) * sc, (xr[i].y - mean) * sc, (xr[i].z - mean) * sc, (xr[i].w - mean) * sc };
-        if (a.w) { const float4 w = *(const float4 *) (a.w + c4*4); r[0] = r[0]*w.x; r[1] = r[1]*w.y; r[2] = r[2]*w.z; r[3] = r[3]*w.w; }
-        if (a.b) { const float4 b = *(const float4 *) (a.b + c4*4); r[0] = r[0]+b.x; r[1] = r[1]+b.y; r[2] = r[2]+b.z; r[3] = r[3]+b.w; }
+        if (a.w) { const float4 w = wr[i]; r[0] = r[0]*w.x; r[1] = r[1]*w.y; r[2] = r[2]*w.z; r[3] = r[3]*w.w; }
+        if (a.b) { const float4 b = br[i]; r[0] = r[0]+b.x; r[1] = r[1]+b.y; r[2] = r[2]+b.z; r[3] = r[3]+b.w; }
         if (e4 < n4) *(float4 *) (y + (size_t) e4*4) = make_float4(r[0], r[1], r[2], r[3]);
         if (a.prep) {
             // the activation preparation of the MFMA GEMM that consumes this LayerNorm (k_prep_act, gemm_mfma.hip), on the values

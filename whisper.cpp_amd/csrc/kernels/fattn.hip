@@ -19,6 +19,7 @@ struct FattnArgs {
     dtensor q, k, v, m, d;
     int has_mask; float scale;
     int T, n_kv, H, rk2, rv2;
+    uint16_t * prep; int prep_ld;      // also write k_prep_act(mode 1) of the result seen as [T][H*64]: the O-projection's activations
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -179,10 +180,51 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
                 *(float4 *) (dp + d0) = make_float4(o[i][4*g]*inv, o[i][4*g+1]*inv, o[i][4*g+2]*inv, o[i][4*g+3]*inv);
             }
     }
+    if (a.prep) {
+        // The result, seen as [T][H*64], is the activation matrix of the output projection (src/whisper.cpp:2165-2167 -> :2199-2203):
+        // leave what k_prep_act (mode 1) would make of it.  A Q8_0 block = 32 consecutive dims of one head = the 16 registers
+        // o[i][*] of this lane and of lane^32 (same query).
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float v[16], amax = 0.0f;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) { v[r] = o[i][r]*inv; amax = fmaxf(amax, fabsf(v[r])); }
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            const float d  = round_f16(amax / 127.0f);
+            const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+            if (q_ok) {
+                uint16_t * pp = a.prep + (int64_t) qi*a.prep_ld + hq*FA_D;
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float q[4];
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) q[e] = fminf(fmaxf(d * rintf(v[4*g + e]*id), -65504.0f), 65504.0f);
+                    *(uint2 *) (pp + 32*i + 8*g + 4*hf) = make_uint2(f2h(q[0]) | ((uint32_t) f2h(q[1]) << 16), f2h(q[2]) | ((uint32_t) f2h(q[3]) << 16));
+                }
+            }
+        }
+    }
 }
+
+static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
+                           const mi355x_tensor * mask, const mi355x_tensor * dst, float scale, void * prep_out);
 
 extern "C" int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                                      const mi355x_tensor * mask, const mi355x_tensor * dst, float scale) {
+    return flash_attn_impl(ctx, q, k, v, mask, dst, scale, nullptr);
+}
+
+// T > 8 only: the same, also leaving mi355x_prep_act(mode 1) of dst viewed as [T][H*64] in prep_out (f16): the activations of the
+// quantized-weight output projection that follows.  dst must be contiguous in that view.
+extern "C" int mi355x_flash_attn_ext_prep(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
+                                          const mi355x_tensor * mask, const mi355x_tensor * dst, float scale, void * prep_out) {
+    if (!prep_out || ((uintptr_t) prep_out % 16) || q->ne[1] <= 8 || k->ne[1] == 0) return MI355X_E_UNSUPPORTED;
+    if (dst->nb[1] != FA_D*4 || dst->nb[2] != dst->ne[1]*FA_D*4) return MI355X_E_UNSUPPORTED;
+    return flash_attn_impl(ctx, q, k, v, mask, dst, scale, prep_out);
+}
+
+static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
+                           const mi355x_tensor * mask, const mi355x_tensor * dst, float scale, void * prep_out) {
     if (q->type != MI355X_TYPE_F32 || k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16 || dst->type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
     if (q->ne[0] != FA_D || k->ne[0] != FA_D || v->ne[0] != FA_D || dst->ne[0] != FA_D) return MI355X_E_UNSUPPORTED;
     if (q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return MI355X_E_UNSUPPORTED;
@@ -201,6 +243,7 @@ extern "C" int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, 
     if (mask) a.m = to_d(mask);
     a.has_mask = mask != nullptr; a.scale = scale; a.T = T; a.n_kv = n_kv; a.H = H;
     a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
+    a.prep = (uint16_t *) prep_out; a.prep_ld = H * FA_D;
     const double kv_bytes = 2.0 * n_kv * FA_D * 2 * H;
     const double flops = 4.0 * T * (double) n_kv * FA_D * H;
     if (n_kv == 0) return mi355x_memset(ctx, dst->data, 0, (size_t) dst->nb[3]*dst->ne[3]);

@@ -100,6 +100,7 @@ struct GemmArgs {
     const char * residual; int64_t res_nb1;
     const uint16_t * gelu_tab;
     int mt, nt, per, m_major;                           // k_gemm_f16_ring: tile counts and the XCD-aware tile order (launch_ring)
+    uint16_t * prep; int prep_only;                     // epilogue also writes k_prep_act(mode 1) of the result, f16 [T][M]; prep_only: no dst store
 };
 
 #define BM 128
@@ -287,6 +288,47 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc
     // epilogue: C[i = A row][j = B row]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) && !a.dst_f16 &&
                         (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || ((uintptr_t) a.bias % 16 == 0));
+    if (a.prep) {
+        // The result is the activation matrix of the NEXT GEMM (fc1 + GELU -> fc2, src/whisper.cpp:2224-2238): write what k_prep_act
+        // (mode 1) would make of it — the reference's Q8_0 rounding of every 32 consecutive features of a token, stored as f16(d*q) —
+        // straight from the accumulators.  A 32-row block of one token is the 16 registers of this lane and of lane^32.
+        // Host guarantees M % 32 == 0 and the 16-byte alignments of the vector path.
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            #pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int64_t t = n0 + wn*WN + j*32 + (lane & 31);
+                const int mb = m0 + wm*64 + i*32;
+                if (t >= a.T || mb >= a.M) continue;            // the same for both lanes of a pair
+                float v[16];
+                float amax = 0.0f;
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int m = mb + 8*g + 4*(lane >> 5);
+                    float x[4] = { acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3] };
+                    if (a.bias) { const float4 b = *(const float4 *) (a.bias + m); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+                    if (a.has_scale) { x[0] *= a.scale; x[1] *= a.scale; x[2] *= a.scale; x[3] *= a.scale; }
+                    if (a.gelu) { x[0] = gelu_lut(x[0], a.gelu_tab); x[1] = gelu_lut(x[1], a.gelu_tab); x[2] = gelu_lut(x[2], a.gelu_tab); x[3] = gelu_lut(x[3], a.gelu_tab); }
+                    if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w; }
+                    if (!a.prep_only) *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(x[0], x[1], x[2], x[3]);
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) { v[4*g + e] = x[e]; amax = fmaxf(amax, fabsf(x[e])); }
+                }
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const float d  = round_f16(amax / 127.0f);
+                const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int m = mb + 8*g + 4*(lane >> 5);
+                    float q[4];
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) q[e] = fminf(fmaxf(d * rintf(v[4*g + e]*id), -65504.0f), 65504.0f);
+                    *(uint2 *) (a.prep + t*a.M + m) = make_uint2(f2h(q[0]) | ((uint32_t) f2h(q[1]) << 16), f2h(q[2]) | ((uint32_t) f2h(q[3]) << 16));
+                }
+            }
+        }
+        return;
+    }
     #pragma unroll
     for (int i = 0; i < 2; i++) {
         #pragma unroll
@@ -591,6 +633,7 @@ static int64_t gemm_res_bytes(const GemmArgs & k) { return k.residual ? (k.T - 1
 // may `k` join the held-back members?  Same B and shape, and no member reads or writes what another member writes.
 static bool gemm_mergeable(const PendingGemms & P, int n, const GemmArgs & k) {
     const GemmArgs & f = P.k[0];
+    if (k.prep || f.prep) return false;                                   // a product that also writes prepared activations goes alone
     if (n >= GEMM_GROUP_MAX || k.B != f.B || k.ldb != f.ldb || k.K != f.K || k.T != f.T || k.M != f.M) return false;
     const int64_t kd = gemm_dst_bytes(k);
     if (mem_overlap(k.dst, kd, k.B, k.T * k.ldb * 2)) return false;
@@ -689,11 +732,31 @@ static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, doubl
 }
 
 // A: [K, M] ggml src0; Bf16: prepared [T][K]; dst column stride dst_nb1
+static int gemm_f16act_impl(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act, int64_t ldb, int64_t T,
+                            void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep, void * prep_out, int prep_only);
+
 extern "C" int mi355x_gemm_f16act(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act, int64_t ldb, int64_t T,
                                   void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep) {
+    return gemm_f16act_impl(ctx, A, act, ldb, T, dst, dst_nb1, dst_type, ep, nullptr, 0);
+}
+
+// the same product, whose epilogue ALSO leaves mi355x_prep_act(mode 1) of the F32 result in prep_out (f16 [T][M]): the result is the
+// activation matrix of the next GEMM.  dst may be NULL when nothing else reads the F32 result (then only prep_out is written).
+extern "C" int mi355x_gemm_f16act_prep(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act, int64_t ldb, int64_t T,
+                                       void * dst, int64_t dst_nb1, const mi355x_epilogue * ep, void * prep_out) {
+    const int64_t M = A->ne[1];
+    if (!prep_out || ((uintptr_t) prep_out % 16) || M % 32) return MI355X_E_UNSUPPORTED;
+    if (dst && (((uintptr_t) dst % 16) || (dst_nb1 % 16))) return MI355X_E_UNSUPPORTED;
+    if (ep && ((ep->bias && ((uintptr_t) ep->bias % 16)) || (ep->residual && (((uintptr_t) ep->residual % 16) || (ep->residual_nb1 % 16))))) return MI355X_E_UNSUPPORTED;
+    return gemm_f16act_impl(ctx, A, act, ldb, T, dst ? dst : prep_out, dst ? dst_nb1 : M*4, MI355X_TYPE_F32, ep, prep_out, dst ? 0 : 1);
+}
+
+static int gemm_f16act_impl(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act, int64_t ldb, int64_t T,
+                            void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep, void * prep_out, int prep_only) {
     if (dst_type != MI355X_TYPE_F32 && dst_type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
     const uint16_t * Bf16 = (const uint16_t *) act; const int dst_f16 = dst_type == MI355X_TYPE_F16;
     GemmArgs k; memset(&k, 0, sizeof(k));
+    k.prep = (uint16_t *) prep_out; k.prep_only = prep_only;
     const int K = (int) A->ne[0], M = (int) A->ne[1];
     k.A = (const char *) A->data; k.a_nb1 = A->nb[1]; k.B = Bf16; k.ldb = ldb; k.M = M; k.K = K; k.T = T;
     k.dst = (char *) dst; k.dst_nb1 = dst_nb1; k.dst_f16 = dst_f16; k.gelu_tab = ctx->gelu_tab;

@@ -18,7 +18,7 @@ _BLOCK = {F32: (1, 4), F16: (1, 2), I32: (1, 4), Q4_0: (32, 18), Q5_0: (32, 22),
 
 # every symbol declared in include/mi355x_kernels.h (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
-    "mi355x_device_count", "mi355x_ctx_create", "mi355x_ctx_destroy", "mi355x_ctx_stream", "mi355x_ctx_synchronize", "mi355x_flush", "mi355x_norm_prep",
+    "mi355x_device_count", "mi355x_ctx_create", "mi355x_ctx_destroy", "mi355x_ctx_stream", "mi355x_ctx_synchronize", "mi355x_flush", "mi355x_norm_prep", "mi355x_flash_attn_ext_prep", "mi355x_gemm_f16act_prep",
     "mi355x_last_error", "mi355x_record_begin", "mi355x_record_count", "mi355x_eager_count", "mi355x_record_end", "mi355x_prof_enable", "mi355x_prof_report",
     "mi355x_prof_reset", "mi355x_type_is_quantized", "mi355x_type_row_bytes", "mi355x_repack_to_planar",
     "mi355x_repack_from_planar", "mi355x_mul_mat", "mi355x_prep_act", "mi355x_gemm_f16act", "mi355x_dequant_f16", "mi355x_gemv_fused",
@@ -88,9 +88,11 @@ def lib() -> C.CDLL:
         L.mi355x_mul_mat.argtypes = [C.c_void_p, TP, TP, TP, C.POINTER(Epilogue)]
         L.mi355x_prep_act.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int64, C.c_int]
         L.mi355x_gemm_f16act.argtypes = [C.c_void_p, TP, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.POINTER(Epilogue)]
+        L.mi355x_gemm_f16act_prep.argtypes = [C.c_void_p, TP, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(Epilogue), C.c_void_p]
         L.mi355x_dequant_f16.argtypes = [C.c_void_p, TP, C.c_void_p]
         L.mi355x_gemv_fused.argtypes = [C.c_void_p, C.POINTER(GemvDesc)]
         L.mi355x_flash_attn_ext.argtypes = [C.c_void_p, TP, TP, TP, TP, TP, C.c_float]
+        L.mi355x_flash_attn_ext_prep.argtypes = [C.c_void_p, TP, TP, TP, TP, TP, C.c_float, C.c_void_p]
         L.mi355x_flash_attn_ext_exact.argtypes = [C.c_void_p, TP, TP, TP, TP, TP, C.c_float, C.c_int]
         L.mi355x_flash_attn_partial.argtypes = [C.c_void_p, TP, TP, TP, TP, C.c_float, C.POINTER(AttnPartials)]
         L.mi355x_flash_attn_combine.argtypes = [C.c_void_p, C.POINTER(AttnPartials), TP]
