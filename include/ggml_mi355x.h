@@ -101,6 +101,8 @@ GGML_MI355X_API void ggml_backend_mi355x_defer_weights(int on);
  *   GGML_MI355X_STRICT=1     abort instead of letting the scheduler fall back to the CPU backend for an unsupported op
  *   GGML_MI355X_EXACT=1      reference-exact arithmetic (test mode, slow): flash attention as the CPU dispatcher computes it
  *                            (F16 accumulation / split over n_threads / F32 tiles), integer block dots for every column count
+ *   GGML_MI355X_GEMM_GROUP=0, GGML_MI355X_LN_PREP=0, GGML_MI355X_GEMM_PREP_OUT=0, GGML_MI355X_FATTN_PREP_OUT=0
+ *                            encoder / prompt fusions off one by one (A-B measurements; results are bit-identical either way)
  */
 
 #ifdef __cplusplus
