@@ -92,6 +92,10 @@ typedef struct mi355x_launch {
 
 MI355X_API void mi355x_record_begin(mi355x_ctx * ctx);
 MI355X_API int  mi355x_record_count(mi355x_ctx * ctx);    /* launches recorded since record_begin (0 when not recording) */
+/* n small host-to-device copies in ONE launch on `stream`: src_dev[i] are DEVICE addresses of pinned, device-mapped host memory
+ * (hipHostGetDevicePointer).  Used by the plugin for the per-step graph inputs (ggml-backend.cpp:1625-1632: token ids, positions, mask). */
+#define MI355X_SCATTER_MAX 8
+MI355X_API int mi355x_scatter_upload(void * hip_stream, int n, void * const * dst, const void * const * src_dev, const uint32_t * sizes);
 MI355X_API uint64_t mi355x_eager_count(mi355x_ctx * ctx); /* launches issued directly on the stream since the context was created */
 /* returns the number of recorded launches, or -1 if the record is unusable (scratch arena had to grow) */
 MI355X_API int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size);

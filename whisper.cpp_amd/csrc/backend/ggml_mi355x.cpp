@@ -108,19 +108,27 @@ struct io_timer {
 // upload stream instead: set_tensor returns as soon as the copy is enqueued (the source has been copied into the ring, so
 // the caller may reuse it), compute streams wait on the upload event, every other reader drains the upload stream first.
 // ---------------------------------------------------------------------------------------------------
+struct mi_io_rec { void * dst; uint32_t off, size; };
 struct mi_io_ctx {
     std::mutex  mtx;
     hipStream_t stream = nullptr;
-    hipEvent_t  ev = nullptr;
+    hipEvent_t  ev = nullptr;              // last async COPY on `stream` (uploads too large for the deferred path)
+    hipEvent_t  ev_flush = nullptr;        // last scatter launch of deferred uploads (on whichever stream flushed them)
+    hipStream_t flush_stream = nullptr;    // the stream ev_flush was recorded on
     char *      pinned = nullptr;
+    char *      pinned_dev = nullptr;      // the same memory as the device sees it
     size_t      cap = 0, off = 0;
-    std::atomic<uint64_t> seq{0};          // number of uploads enqueued so far
+    std::vector<mi_io_rec> pending;        // deferred small uploads: bytes are in the ring, one scatter launch moves them
+    std::atomic<uint64_t> seq{0};          // number of uploads accepted so far (both paths)
+    std::atomic<uint64_t> copy_seq{0};     // ... of which went through async copies on `stream`
     std::atomic<uint64_t> drained{0};      // uploads known to be complete
     uint64_t    wake_seq = 0;              // value of seq when the last graph_compute picked the uploads up
-    bool        ok = false, tried = false;
+    uint64_t    flush_count = 0;           // scatter flushes so far
+    bool        ok = false, tried = false, flushed_since_drain = false;
 };
 static mi_io_ctx g_io[MI_MAX_DEVICES];
 #define MI_IO_SMALL (256u << 10)
+#define MI_IO_DEFER (32u << 10)            // uploads up to this size wait in the ring for the next flush (graph inputs of a decode step)
 
 static mi_io_ctx * mi_io(int device) {          // caller holds no lock; device already current
     mi_io_ctx & io = g_io[device];
@@ -131,17 +139,43 @@ static mi_io_ctx * mi_io(int device) {          // caller holds no lock; device 
         io.cap = (size_t) 4 << 20;
         if (enabled && hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&io.ev, hipEventDisableTiming) == hipSuccess &&
-            hipHostMalloc((void **) &io.pinned, io.cap, hipHostMallocDefault) == hipSuccess) io.ok = true;
+            hipEventCreateWithFlags(&io.ev_flush, hipEventDisableTiming) == hipSuccess &&
+            hipHostMalloc((void **) &io.pinned, io.cap, hipHostMallocDefault) == hipSuccess) {
+            io.ok = true;
+            void * dp = nullptr;
+            static const bool defer = env_flag("GGML_MI355X_DEFER_IO", true);
+            if (defer && hipHostGetDevicePointer(&dp, io.pinned, 0) == hipSuccess) io.pinned_dev = (char *) dp;
+            else (void) hipGetLastError();
+        }
     }
     return io.ok ? &io : nullptr;
 }
-// wait until every enqueued upload has landed (readers other than the compute streams)
+// one scatter launch on `stream` for everything that waits in the ring (io.mtx held)
+static void mi_io_flush_locked(mi_io_ctx & io, hipStream_t stream) {
+    if (io.pending.empty()) return;
+    // flushes form a chain: ev_flush only remembers the LAST one, so a flush on another stream is ordered behind its predecessor
+    // and whoever waits for the last one has waited for all of them (several whisper_states on one device)
+    if (io.flush_stream && io.flush_stream != stream) (void) hipStreamWaitEvent(stream, io.ev_flush, 0);
+    void * dst[64]; const void * src[64]; uint32_t sz[64];
+    size_t i = 0;
+    while (i < io.pending.size()) {
+        int n = 0;
+        for (; n < 64 && i < io.pending.size(); n++, i++) { dst[n] = io.pending[i].dst; src[n] = io.pinned_dev + io.pending[i].off; sz[n] = io.pending[i].size; }
+        if (mi355x_scatter_upload((void *) stream, n, dst, src, sz) != 0) GGML_ABORT("ggml-mi355x: upload of graph inputs failed: %s", mi355x_last_error());
+    }
+    io.pending.clear();
+    (void) hipEventRecord(io.ev_flush, stream);
+    io.flush_stream = stream; io.flushed_since_drain = true; io.flush_count++;
+}
+// wait until every accepted upload has landed (readers other than the compute streams)
 static void mi_io_drain(int device) {
     mi_io_ctx & io = g_io[device];
     if (!io.ok || io.drained.load() == io.seq.load()) return;
     std::lock_guard<std::mutex> lk(io.mtx);
     const uint64_t s = io.seq.load();
+    mi_io_flush_locked(io, io.stream);
     (void) hipStreamSynchronize(io.stream);
+    if (io.flushed_since_drain) { (void) hipEventSynchronize(io.ev_flush); io.flushed_since_drain = false; }
     io.drained.store(s); io.off = 0;
 }
 static bool mi_io_upload(int device, void * dst, const void * src, size_t size) {
@@ -149,8 +183,20 @@ static bool mi_io_upload(int device, void * dst, const void * src, size_t size) 
     if (!io) return false;
     std::lock_guard<std::mutex> lk(io->mtx);
     const size_t need = (size + 255) & ~(size_t) 255;
-    if (io->off + need > io->cap) { (void) hipStreamSynchronize(io->stream); io->drained.store(io->seq.load()); io->off = 0; }
+    if (io->off + need > io->cap / 2) {            // ring full: everything that still reads from it must finish first
+        mi_io_flush_locked(*io, io->stream);
+        (void) hipStreamSynchronize(io->stream);
+        if (io->flushed_since_drain) { (void) hipEventSynchronize(io->ev_flush); io->flushed_since_drain = false; }
+        io->drained.store(io->seq.load()); io->off = 0;
+    }
     memcpy(io->pinned + io->off, src, size);
+    if (io->pinned_dev && size <= MI_IO_DEFER) {
+        // deferred: the next graph_compute (or any other reader) moves it with one scatter launch
+        io->pending.push_back({ dst, (uint32_t) io->off, (uint32_t) size });
+        io->off += need;
+        io->seq++;
+        return true;
+    }
     if (hipMemcpyAsync(dst, io->pinned + io->off, size, hipMemcpyHostToDevice, io->stream) != hipSuccess) return false;
     // first upload since the last compute: wake the chip now, while the host still has its per-step work ahead
     // (measured: no effect on the ~30 us stall before the first chip-wide dispatch of a step; off unless GGML_MI355X_WAKE=n)
@@ -158,7 +204,7 @@ static bool mi_io_upload(int device, void * dst, const void * src, size_t size) 
     if (wake > 0 && io->seq.load() == io->wake_seq) (void) mi355x_wake((void *) io->stream, wake);
     io->off += need;
     (void) hipEventRecord(io->ev, io->stream);
-    io->seq++;
+    io->seq++; io->copy_seq++;
     return true;
 }
 static bool mi_io_download(int device, void * dst, const void * src, size_t size) {
@@ -166,7 +212,9 @@ static bool mi_io_download(int device, void * dst, const void * src, size_t size
     if (!io || size > io->cap / 2) return false;
     std::lock_guard<std::mutex> lk(io->mtx);
     // the ring is used from its upper half for downloads after draining the stream (uploads in flight keep the lower part)
+    mi_io_flush_locked(*io, io->stream);
     (void) hipStreamSynchronize(io->stream);
+    if (io->flushed_since_drain) { (void) hipEventSynchronize(io->ev_flush); io->flushed_since_drain = false; }
     io->drained.store(io->seq.load()); io->off = 0;
     char * stage = io->pinned + io->cap / 2;
     if (hipMemcpyAsync(stage, src, size, hipMemcpyDeviceToHost, io->stream) != hipSuccess) return false;
@@ -376,7 +424,7 @@ struct mi_backend_ctx {
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
     // hipGraph replay, keyed by number of launches (decoder step / encoder graphs differ in length)
     std::vector<mi_graph_cache> gcache;
-    uint64_t io_seen = 0;                                       // uploads (mi_io_ctx::seq) this stream already waits behind
+    uint64_t io_seen = 0, io_copy_seen = 0, io_flush_seen = 0;                     // uploads (mi_io_ctx::seq / copy_seq) this stream already waits behind
     uint64_t n_graph_compute = 0, n_replay = 0, n_update = 0, n_rebuild = 0;
     bool     recording = false, record_abort = false;
     uint64_t eager_base = 0;                                    // mi355x_eager_count at the start of an eager head segment
@@ -1142,7 +1190,13 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
         const uint64_t seq = io.ok ? io.seq.load() : 0;
         if (seq != b->io_seen) {
             std::lock_guard<std::mutex> lk(io.mtx);
-            (void) hipStreamWaitEvent((hipStream_t) mi355x_ctx_stream(b->k), io.ev, 0);
+            hipStream_t cs = (hipStream_t) mi355x_ctx_stream(b->k);
+            // deferred uploads (this step's graph inputs) leave with one scatter launch at the head of this stream; uploads that
+            // another stream flushed, or that went through async copies, are ordered in front of us by their events
+            if (io.flush_count != b->io_flush_seen && io.flush_stream && io.flush_stream != cs) (void) hipStreamWaitEvent(cs, io.ev_flush, 0);
+            mi_io_flush_locked(io, cs);
+            b->io_flush_seen = io.flush_count;
+            if (io.copy_seq.load() != b->io_copy_seen) { (void) hipStreamWaitEvent(cs, io.ev, 0); b->io_copy_seen = io.copy_seq.load(); }
             b->io_seen = io.seq.load();
             io.wake_seq = b->io_seen;
         }

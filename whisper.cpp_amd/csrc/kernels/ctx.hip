@@ -337,3 +337,36 @@ extern "C" int mi355x_checksum(void * stream, const void * dptr, size_t nbytes, 
     k_checksum<<<dim3((uint32_t) nb), dim3(256), 0, (hipStream_t) stream>>>((const uint64_t *) dptr, nwords, (const uint8_t *) dptr + nwords*8, ntail, (unsigned long long *) dev_out16);
     return (int) hipGetLastError();
 }
+
+// ---- batched small uploads ------------------------------------------------------------------------------------------
+// The scheduler writes the graph inputs of a decode step (token ids, positions, mask: 4 B .. a few KB each) into device tensors
+// right before graph_compute.  As three H2D copies they are three serialized blit kernels plus a cross-stream event in front of
+// the step's first kernel; here the host only memcpy()s them into pinned, device-mapped memory and ONE launch on the compute
+// stream moves all of them (each workgroup reads its record over PCIe and writes the device tensor).
+struct ScatterArgs { void * dst[MI355X_SCATTER_MAX]; const void * src[MI355X_SCATTER_MAX]; uint32_t size[MI355X_SCATTER_MAX]; int n; };
+__global__ void __launch_bounds__(256) k_scatter_upload(const ScatterArgs a) {
+    const int r = blockIdx.x;
+    if (r >= a.n) return;
+    char * d = (char *) a.dst[r]; const char * s = (const char *) a.src[r];
+    const uint32_t n = a.size[r];
+    if ((((uintptr_t) d | (uintptr_t) s) & 15) == 0) {
+        const uint32_t n16 = n >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += 256) ((uint4 *) d)[i] = ((const uint4 *) s)[i];
+        for (uint32_t i = (n16 << 4) + threadIdx.x; i < n; i += 256) d[i] = s[i];
+    } else if ((((uintptr_t) d | (uintptr_t) s | n) & 3) == 0) {
+        for (uint32_t i = threadIdx.x; i < (n >> 2); i += 256) ((uint32_t *) d)[i] = ((const uint32_t *) s)[i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+    }
+}
+extern "C" int mi355x_scatter_upload(void * stream, int n, void * const * dst, const void * const * src_dev, const uint32_t * sizes) {
+    for (int i0 = 0; i0 < n; i0 += MI355X_SCATTER_MAX) {
+        ScatterArgs a; memset(&a, 0, sizeof(a));
+        a.n = n - i0 < MI355X_SCATTER_MAX ? n - i0 : MI355X_SCATTER_MAX;
+        for (int i = 0; i < a.n; i++) { a.dst[i] = dst[i0 + i]; a.src[i] = src_dev[i0 + i]; a.size[i] = sizes[i0 + i]; }
+        k_scatter_upload<<<dim3((uint32_t) a.n), dim3(256), 0, (hipStream_t) stream>>>(a);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { mi355x_set_error("scatter upload launch failed: %s", hipGetErrorString(e)); return (int) e; }
+    }
+    return 0;
+}
