@@ -9,8 +9,8 @@ run() {
   python3 - "$r" "$*" <<'PY'
 import json,sys
 d=json.loads(sys.argv[1])
-print(f"{sys.argv[2]:28s} value {d['value']:.2f} encode {d['encode_ms']:.3f} decode {d['decode_ms_per_token']:.4f} batchd {d['batchd_ms_per_token']:.4f} 4-stream {d['multi_stream']['chunks_per_s']:.3f} chunks/s  gpu_span/chunk {d['hip_graph']['host_ms_in_timed_region']['gpu_span']/3:.1f} set_tensor {d['hip_graph']['host_ms_in_timed_region']['set_tensor']/3:.2f}")
+print(f"{sys.argv[2]:28s} value {d['value']:.2f} encode {d['encode_ms']:.3f} decode {d['decode_ms_per_token']:.4f} batchd {d['batchd_ms_per_token']:.4f} 4-stream {d['multi_stream']['chunks_per_s']:.3f} chunks/s  gpu_span/chunk {d['hip_graph']['host_ms_in_timed_region']['gpu_span']/3:.1f} set {d['hip_graph']['host_ms_in_timed_region']['set_tensor']/3:.2f} get {d['hip_graph']['host_ms_in_timed_region']['get_tensor']/3:.2f} sync {d['hip_graph']['host_ms_in_timed_region']['synchronize']/3:.1f}")
 PY
 }
-for i in 1 2; do for cfg in GGML_MI355X_DEFER_IO=1 GGML_MI355X_DEFER_IO=0; do run $cfg; done; done | tee $OUT/defer_io_ab.txt
+for i in 1 2 3; do for cfg in GGML_MI355X_PREFETCH_OUT=1 GGML_MI355X_PREFETCH_OUT=0; do run $cfg; done; done | tee $OUT/prefetch_ab.txt
 date +%T
