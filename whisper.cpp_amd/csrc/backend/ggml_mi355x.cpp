@@ -424,6 +424,7 @@ struct mi_backend_ctx {
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
     // hipGraph replay, keyed by number of launches (decoder step / encoder graphs differ in length)
     std::vector<mi_graph_cache> gcache;
+    std::vector<int> warm_sizes;                                // graph sizes (n_nodes) that have run once as plain launches
     uint64_t io_seen = 0, io_copy_seen = 0, io_flush_seen = 0;                     // uploads (mi_io_ctx::seq / copy_seq) this stream already waits behind
     uint64_t n_graph_compute = 0, n_replay = 0, n_update = 0, n_rebuild = 0;
     bool     recording = false, record_abort = false;
@@ -1215,7 +1216,13 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
     }
     struct span_end { mi_backend_ctx * b; int idx; ~span_end() { if (idx >= 0) (void) hipEventRecord(b->span_ev[idx].second, (hipStream_t) mi355x_ctx_stream(b->k)); } } span_guard{ b, span_idx };
     // graphs pay off when the launch sequence is long and launch-bound (decoder step); profiling needs eager launches
-    const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32;
+    // The FIRST call for a graph of a given size always runs as plain launches: it is the one that grows the scratch buffers, creates
+    // the f16 weight copies and fills the planner's caches — side effects that must not happen inside a recording that may be
+    // aborted and re-run (a weight copy whose dequantization was only RECORDED would be published before it exists).
+    bool warm = false;
+    for (int n : b->warm_sizes) if (n == cgraph->n_nodes) { warm = true; break; }
+    if (!warm) b->warm_sizes.push_back(cgraph->n_nodes);
+    const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32 && warm;
     if (use_graph) {
         // The launch sequence is replayed as hipGraphs of ~seg launches each: the first segment starts executing while the
         // host is still planning / patching / launching the following ones, so only 1/n-th of the per-step host work sits in
@@ -1257,7 +1264,9 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
             const int n = mi355x_record_end(b->k, &L, &blob, &bsz);
             if (rc != 0) return GGML_STATUS_FAILED;
             if (n < 0 || b->record_abort) {
-                // a scratch buffer had to grow while recording: this segment runs eagerly (the next call records again)
+                // a scratch buffer had to grow while recording: this segment runs eagerly (the next call records again).  The aborted
+                // pass moved the planner's prepared-activation cache without running a kernel: forget it.
+                b->act_src = nullptr;
                 const double t1 = now_ms();
                 rc = mi_emit_range(b, cgraph, i, i_next, 0, nullptr);
                 b->t_eager_ms += now_ms() - t1;
