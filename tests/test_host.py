@@ -399,3 +399,52 @@ def test_native_harness_refuses_gpu_mode_without_the_plugin(tmp_path):
     cfg = h.Config(str(m).encode(), b"/nonexistent/libggml-mi355x.so", 1, 1, 0, 1, 2, 1, 0, 2, 1, 1)
     res = h.Result()
     assert h.lib().mi355x_host_run(C.byref(cfg), C.byref(res)) != 0 and b"plugin" in res.error
+
+
+def _latest(pattern):
+    files = sorted((ROOT / "profiles").glob(pattern))
+    assert files, f"profiles/{pattern} is missing"
+    return files[-1]
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """the bench line committed under profiles/ (copied from the GPU box's bench.py output) carries every field the driver's contract
+    names, the metric of BASELINE.json, a roofline object whose fraction is achieved / peak, and a reference-kind CPU baseline"""
+    d = json.loads(_latest("r*_bench_large-v3_q5_0.json").read_text().strip().splitlines()[-1])
+    base = json.loads((ROOT / "BASELINE.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["higher_is_better"] is False and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    if isinstance(base.get("metric"), str):
+        assert d["unit"].startswith("ms")
+    assert abs(d["value"] - (d["encode_ms"] + 256 * d["decode_ms_per_token"])) < 0.03 * d["value"]      # wall = encode + 256 decodes (+ host)
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] is not None and r["traffic"] > 0
+    assert abs(r["achieved"] - r["algorithmic_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 0.02 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 5 * d["value"] and "whisper-bench" in c["sample"]
+
+
+def test_committed_parity_summary_is_within_the_documented_tolerances():
+    """profiles/rNN_parity_summary.json (made by scripts/make_parity_summary.py from the GPU tests' own output) against the tolerances
+    DESIGN.md section 4 states: quantized models 5e-4 single-token / 2e-3 batch rows (exact mode: 5e-4 for both), F16 model 5e-6,
+    every argmax disagreement on a near-tie step, every BASELINE configuration present"""
+    d = json.loads(_latest("r*_parity_summary.json").read_text())
+    m = d["models"]
+    for need in ("large-v3_q5_0", "large-v3_q4_k", "large-v3-turbo_q8_0", "tiny.en_f16", "base.en_q4_0"):
+        assert need in m and need + "_exact" in m, need
+    assert "base.en_q5_0_nfa" in m and m["base.en_q5_0_nfa"]["flash_attn"] == 0
+    for name, v in m.items():
+        f16 = "f16" in name
+        exact = name.endswith("_exact")
+        assert v["single_worst_nmse"] < (5e-6 if f16 else 5e-4), (name, v["single_worst_nmse"])
+        assert max(v["batch5_nmse"], v["batch48_nmse"]) < (5e-4 if exact else 2e-3), name
+        agree, total = (int(x) for x in v["argmax_agree"].split("/"))
+        assert agree >= total - 3, (name, v["argmax_agree"])
+        if agree < total:
+            assert v["max_margin_over_maxdiff_on_mismatch"] < 1.0, name      # the CPU's own top-2 margin was below the logit difference there
+    assert all(x["greedy"]["n_cpu"] == x["greedy"]["n_gpu"] for x in d["whisper_full_pipeline"].values())
+    for v in d["language_detection"].values():
+        assert v["id_cpu"] == v["id_gpu"] and v["max_abs_prob_diff"] < 5e-3
