@@ -53,20 +53,19 @@ GGML_MI355X_API struct ggml_mi355x_feature * ggml_backend_mi355x_get_features(vo
 GGML_MI355X_API void ggml_backend_mi355x_set_n_threads(void * backend, int n_threads);
 
 /* Per-kernel profile of one backend (ggml_backend_t): enables hipEvent bracketing of every launch on the
- * backend's stream (graph replay is disabled while profiling).  Rows as in mi355x_prof_row. */
+ * backend's stream.  Rows as in mi355x_prof_row. */
 struct ggml_mi355x_prof_row { const char * name; uint64_t calls; double total_ms; double algo_bytes; double algo_flops; };
 GGML_MI355X_API void ggml_backend_mi355x_prof_enable(void * backend, int on);
 GGML_MI355X_API void ggml_backend_mi355x_prof_reset(void * backend);
 GGML_MI355X_API int  ggml_backend_mi355x_prof_report(void * backend, struct ggml_mi355x_prof_row * rows, int cap);
 
 /* process-wide variants over every live MI355X backend (whisper.h does not expose its ggml_backend_t handles);
- * ggml_backend_mi355x_stats fills out[4] = {graph_compute calls, hipGraph replays, patched kernel nodes, graph builds} */
+ * ggml_backend_mi355x_stats fills out[4] = {graph_compute calls, 0, 0, 0} (slots 1..3 belonged to the removed hipGraph replay path) */
 GGML_MI355X_API void ggml_backend_mi355x_prof_enable_all(int on);
 GGML_MI355X_API void ggml_backend_mi355x_prof_reset_all(void);
 GGML_MI355X_API int  ggml_backend_mi355x_prof_report_all(struct ggml_mi355x_prof_row * rows, int cap);
 GGML_MI355X_API void ggml_backend_mi355x_stats(uint64_t * out);
-/* out[13]: [12] GPU-side span of all completed graph_computes (ms, hipEvent pairs on the compute stream); [0..3] host milliseconds inside graph_compute {planning + launch recording, hipGraph node patching, hipGraphLaunch,
- * eager launches}; [4..7] milliseconds inside {set_tensor, get_tensor, cpy_tensor, synchronize}; [8..11] their call counts */
+/* out[13]: [12] GPU-side span of all completed graph_computes (ms, hipEvent pairs on the compute stream); [3] host milliseconds inside graph_compute (graph walk + launches; [0..2] always 0, kept for layout); [4..7] milliseconds inside {set_tensor, get_tensor, cpy_tensor, synchronize}; [8..11] their call counts */
 GGML_MI355X_API void ggml_backend_mi355x_host_times(double * out);
 
 /* Multi-GPU weight distribution.  Replicas are independent streams: the only exchange is the ONE-TIME copy of
@@ -80,7 +79,8 @@ GGML_MI355X_API void ggml_backend_mi355x_host_times(double * out);
  *   ggml_backend_mi355x_broadcast_weights_rccl   one process per device: RCCL communicator from that id (librccl.so is dlopen()ed),
  *                                                ncclBroadcast of every buffer from rank 0, device-side checksums compared across ranks
  *   ggml_backend_mi355x_weights_checksum         {sum, index-weighted sum} mod 2^64 of every WEIGHTS buffer (mi355x_checksum)
- *   ggml_backend_mi355x_defer_weights            while on, set_tensor of weight tensors is skipped (they arrive by broadcast)
+ *   ggml_backend_mi355x_defer_weights            while on, set_tensor of weight tensors issued BY THE CALLING THREAD is skipped (they arrive by
+ *                                                broadcast); ggml_backend_mi355x_deferred_bytes = bytes skipped so far, process-wide
  *   ggml_backend_mi355x_weight_buffers           base pointers + sizes in allocation order (for harnesses with their own transport)
  * stats[0..3] = bytes moved, seconds, buffers, verified (1: every destination buffer's checksum equals the source's).  Return 0 on
  * success; -1 transport unavailable / failed, -2 layout differs between replicas, -3 copy failed, -4 checksum mismatch. */
@@ -91,12 +91,10 @@ GGML_MI355X_API int  ggml_backend_mi355x_clone_weights(int device, int n_replica
 GGML_MI355X_API int  ggml_backend_mi355x_rccl_unique_id(void * out128);
 GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, const void * unique_id128, double * stats4);
 GGML_MI355X_API void ggml_backend_mi355x_defer_weights(int on);
+GGML_MI355X_API uint64_t ggml_backend_mi355x_deferred_bytes(void);
 
 /* Runtime switches (environment):
  *   GGML_MI355X_FUSE=0       run every ggml node as its own kernel (debug / parity bisect)
- *   GGML_MI355X_GRAPHS=1     record each graph's launch sequence and replay it as segmented hipGraphs (patched where arguments changed).
- *                            Off by default: measured 3 % slower per decode step than plain launches on ROCm 7.2; saves host CPU time
- *   GGML_MI355X_EAGER_HEAD=n with GRAPHS=1: the first n launches of a graph go out directly, the rest is replayed
  *   GGML_MI355X_DEBUG=1      log unsupported ops and kernel-library errors to stderr
  *   GGML_MI355X_STRICT=1     abort instead of letting the scheduler fall back to the CPU backend for an unsupported op
  *   GGML_MI355X_EXACT=1      reference-exact arithmetic (test mode, slow): flash attention as the CPU dispatcher computes it

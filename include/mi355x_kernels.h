@@ -71,34 +71,16 @@ MI355X_API void *       mi355x_ctx_stream(mi355x_ctx * ctx);            /* hipSt
 MI355X_API int          mi355x_ctx_synchronize(mi355x_ctx * ctx);
 /* Independent neighbouring GEMMs are held back so that they can leave as ONE grouped launch (the Q / K / V projections of an encoder
  * layer, the cross-attention K / V projections of consecutive layers: src/whisper.cpp:2119-2141, :2306-2348); every other launch,
- * synchronize, memset, record_end and profile call flushes them first, so stream order equals program order.  A host that enqueues
+ * synchronize, memset and profile call flushes them first, so stream order equals program order.  A host that enqueues
  * its OWN work on mi355x_ctx_stream() calls this before. */
 MI355X_API int          mi355x_flush(mi355x_ctx * ctx);
 MI355X_API const char * mi355x_last_error(void);
 
-/* launch recording: between begin/end no kernel is launched; launches are appended to the context's
- * plan instead (used by the backend to build / patch a hipGraph).  See ggml_mi355x.h. */
-typedef struct mi355x_launch {
-    const void * func;          /* device function handle for hipLaunchKernel / hipGraphAddKernelNode */
-    uint32_t     grid[3];
-    uint32_t     block[3];
-    uint32_t     shmem;
-    uint32_t     arg_size;
-    uint64_t     arg_offset;    /* byte offset of this launch's single by-value argument struct in the blob */
-    const char * name;          /* static string: kernel family, for profiling */
-    double       algo_bytes;    /* algorithmic HBM bytes of this launch (roofline numerator) */
-    double       algo_flops;
-} mi355x_launch;
-
-MI355X_API void mi355x_record_begin(mi355x_ctx * ctx);
-MI355X_API int  mi355x_record_count(mi355x_ctx * ctx);    /* launches recorded since record_begin (0 when not recording) */
 /* n small host-to-device copies in ONE launch on `stream`: src_dev[i] are DEVICE addresses of pinned, device-mapped host memory
  * (hipHostGetDevicePointer).  Used by the plugin for the per-step graph inputs (ggml-backend.cpp:1625-1632: token ids, positions, mask). */
 #define MI355X_SCATTER_MAX 8
 MI355X_API int mi355x_scatter_upload(void * hip_stream, int n, void * const * dst, const void * const * src_dev, const uint32_t * sizes);
-MI355X_API uint64_t mi355x_eager_count(mi355x_ctx * ctx); /* launches issued directly on the stream since the context was created */
-/* returns the number of recorded launches, or -1 if the record is unusable (scratch arena had to grow) */
-MI355X_API int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size);
+MI355X_API uint64_t mi355x_eager_count(mi355x_ctx * ctx); /* launches issued on the stream since the context was created */
 
 /* profiling: when enabled every eager launch is bracketed by hipEvents on the context's stream and
  * accumulated per kernel name.  mi355x_prof_report fills up to `cap` rows; returns the row count. */
@@ -159,7 +141,7 @@ MI355X_API int mi355x_gemm_f16act_prep(mi355x_ctx * ctx, const mi355x_tensor * A
  * exact values mi355x_gemm_f16act feeds the matrix cores when given the quantized tensor.  A caller that keeps
  * this copy (HBM is plentiful) passes it to mi355x_gemm_f16act as an F16 tensor and still prepares the
  * activation with the ORIGINAL weight type's mode: results are bit-identical to the quantized call, the GEMM
- * inner loop just carries no dequantization.  Launched immediately even while a plan is being recorded. */
+ * inner loop just carries no dequantization.  */
 MI355X_API int mi355x_dequant_f16(mi355x_ctx * ctx, const mi355x_tensor * w, void * dst_f16);
 
 /* Decoder-step fusion (T <= 8 columns): [optional LayerNorm(x)*ln_w+ln_b] -> quantize -> up to 3

@@ -34,14 +34,13 @@ model)
     for spec in "micro q5_0" "tiny.en f16" "base.en q5_0" "base.en q4_k" "base.en q8_0" "base.en q4_0" "large-v3-2l q5_0"; do
         set -- $spec
         m=$(python3 scripts/synth_model.py --arch "$1" --qtype "$2") || continue
-        for mode in "1 1" "0 0"; do
-            set -- $mode
-            echo "--- $spec fuse=$1 graphs=$2"
-            GGML_MI355X_FUSE=$1 GGML_MI355X_GRAPHS=$2 GGML_MI355X_DEBUG=1 timeout 600 tests/native/bin/model_parity "$m" 24 \
-                > "$OUT/model_parity_$(basename "$m" .bin)_f$1g$2.json" 2> "$OUT/model_parity_$(basename "$m" .bin)_f$1g$2.err"
+        for fuse in 1 0; do
+            echo "--- $spec fuse=$fuse"
+            GGML_MI355X_FUSE=$fuse GGML_MI355X_DEBUG=1 timeout 600 tests/native/bin/model_parity "$m" 24 \
+                > "$OUT/model_parity_$(basename "$m" .bin)_f$fuse.json" 2> "$OUT/model_parity_$(basename "$m" .bin)_f$fuse.err"
             echo "exit=$?"
-            grep -E '"single"|"batch|"greedy"|encode_ms' "$OUT/model_parity_$(basename "$m" .bin)_f$1g$2.json" | cut -c1-300
-            grep -E "unsupported|failed|error" "$OUT/model_parity_$(basename "$m" .bin)_f$1g$2.err" | sort | uniq -c | head -8
+            grep -E '"single"|"batch|"greedy"|encode_ms' "$OUT/model_parity_$(basename "$m" .bin)_f$fuse.json" | cut -c1-300
+            grep -E "unsupported|failed|error" "$OUT/model_parity_$(basename "$m" .bin)_f$fuse.err" | sort | uniq -c | head -8
         done
     done
     ;;

@@ -1,5 +1,5 @@
 // ggml backend plugin for AMD Instinct MI355X (gfx950).  Host side only: registration, buffers, graph walk +
-// fusion planner, hipGraph replay.  All device work goes through the C ABI of libmi355x_kernels.so
+// fusion planner.  All device work goes through the C ABI of libmi355x_kernels.so
 // (include/mi355x_kernels.h).  Boundary documentation: include/ggml_mi355x.h.
 //
 // Reference interface being implemented: ggml/src/ggml-backend-impl.h (vtables), loader
@@ -64,7 +64,11 @@ static mi_device_ctx              g_device_ctx[MI_MAX_DEVICES];
 static int                        g_n_devices = -1;
 
 static bool is_quant_type(ggml_type t) { return mi355x_type_is_quantized((int) t) != 0; }
-static std::atomic<int> g_defer_weights{0};        // ggml_backend_mi355x_defer_weights: weight uploads are skipped (they arrive by broadcast)
+// ggml_backend_mi355x_defer_weights: weight uploads issued BY THE CALLING THREAD are skipped (they arrive by broadcast).  Scoped to
+// the thread that creates the replica's context — whisper_init_* runs its set_tensor loop on the caller's thread (src/whisper.cpp:1934-
+// 1938) — so another context loading concurrently on another thread, or on another device, is never affected.
+static thread_local int       t_defer_weights = 0;
+static std::atomic<uint64_t>  g_deferred_bytes{0};    // bytes skipped so far (visible through GGML_MI355X_DEBUG and ggml_backend_mi355x_deferred_bytes)
 
 // f16 copies of quantized WEIGHTS tensors that meet wide activations (encoder, cross-attention K/V, prompt): made once by
 // mi355x_dequant_f16 the first time such a tensor reaches the MFMA path, kept until its buffer is written or freed.
@@ -258,7 +262,12 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     MI_REQUIRE_WHOLE_QUANT(tensor, "set_tensor");
-    if (g_defer_weights.load() != 0 && buffer->usage != GGML_BACKEND_BUFFER_USAGE_COMPUTE && ggml_nbytes(tensor) >= (1u << 16)) return;   // arrives by broadcast
+    // (the buffer is not yet marked WEIGHTS while the loader fills it: ggml_backend_buffer_set_usage comes after the loop, W:1956)
+    if (t_defer_weights != 0 && buffer->usage != GGML_BACKEND_BUFFER_USAGE_COMPUTE && ggml_nbytes(tensor) >= (1u << 16)) {
+        g_deferred_bytes += size;
+        MI_LOG("set_tensor of '%s' (%zu bytes) deferred: arrives by broadcast", tensor->name, size);
+        return;
+    }
     if (is_quant_type(tensor->type)) {
         mi_shadows_drop(ctx->device, ctx->base);
         mi_io_drain(ctx->device);
@@ -397,22 +406,11 @@ static const ggml_backend_buffer_type_i mi_buft_iface = {
 // ---------------------------------------------------------------------------------------------------
 // backend (stream)
 // ---------------------------------------------------------------------------------------------------
-struct mi_graph_cache {
-    uint64_t                   key = 0;           // (cgraph node count, segment index)
-    hipGraph_t                 graph = nullptr;
-    hipGraphExec_t             exec  = nullptr;
-    std::vector<hipGraphNode_t> nodes;
-    std::vector<mi355x_launch>  launches;
-    std::vector<uint8_t>        blob;
-    uint64_t                    hits = 0;
-    uint64_t                    last_call = 0;     // n_graph_compute of the most recent launch (never evicted within that call)
-};
-
 struct mi_backend_ctx {
     int          device;
     mi355x_ctx * k;
     std::string  name;
-    bool         fuse, graphs, prof;
+    bool         fuse, prof;
     // GGML_MI355X_EXACT=1: walk the reference CPU path's arithmetic where it differs observably from ours — flash attention in
     // the CPU dispatcher's three forms (F16 accumulation, split over n_threads, F32 tiles; fattn_exact.hip) and integer block dots
     // for every column count (no f16-rounded d*q products) — so that free-running decodes can be compared token for token
@@ -422,14 +420,9 @@ struct mi_backend_ctx {
     void *       act = nullptr; size_t act_size = 0;
     void *       act_alt = nullptr; size_t act_alt_size = 0;     // second scratch: a GEMM reading `act` writes the next GEMM's prepared activations here
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
-    // hipGraph replay, keyed by number of launches (decoder step / encoder graphs differ in length)
-    std::vector<mi_graph_cache> gcache;
-    std::vector<int> warm_sizes;                                // graph sizes (n_nodes) that have run once as plain launches
     uint64_t io_seen = 0, io_copy_seen = 0, io_flush_seen = 0;                     // uploads (mi_io_ctx::seq / copy_seq) this stream already waits behind
-    uint64_t n_graph_compute = 0, n_replay = 0, n_update = 0, n_rebuild = 0;
-    bool     recording = false, record_abort = false;
-    uint64_t eager_base = 0;                                    // mi355x_eager_count at the start of an eager head segment
-    double   t_plan_ms = 0, t_patch_ms = 0, t_launch_ms = 0, t_eager_ms = 0;    // host time inside graph_compute
+    uint64_t n_graph_compute = 0;
+    double   t_eager_ms = 0;                                    // host time inside graph_compute
     // GPU-side span of every graph_compute (first launch .. last kernel done), from a ring of hipEvent pairs on the stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_ev;
     int      span_next = 0, span_pending = 0;
@@ -578,12 +571,11 @@ static const void * mi_shadow_get(mi_backend_ctx * b, const ggml_tensor * w, con
     return p;
 }
 
-// room for T x K prepared f16 activations in the backend's scratch; 0 ok, < 0 recording aborted (grows on the eager re-run), > 0 error
+// room for T x K prepared f16 activations in the backend's scratch; 0 ok, > 0 error
 static int mi_act_reserve(mi_backend_ctx * b, size_t need, bool alt = false) {
     void * & buf = alt ? b->act_alt : b->act;
     size_t & size = alt ? b->act_alt_size : b->act_size;
     if (need <= size) return 0;
-    if (b->recording) { b->record_abort = true; return -1; }
     mi355x_ctx_synchronize(b->k);                 // (also sends held-back launches that still name the old buffer)
     if (buf) (void) hipFree(buf);
     buf = nullptr; size = 0;
@@ -646,7 +638,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             if (x->type == GGML_TYPE_F16 && mode == 0) { act = x->data; ld = (int64_t) x->nb[1] / 2; }
             else {
                 const int rr = mi_act_reserve(b, (size_t) T * K * 2);
-                if (rr != 0) return rr < 0 ? 0 : rr;                            // < 0: recording aborted, the range re-runs eagerly
+                if (rr != 0) return rr;
                 if (!(b->act_src == x->data && b->act_K == K && b->act_T == T && b->act_mode == mode && b->act_nb1 == (int64_t) x->nb[1])) {
                     const int rc = mi355x_prep_act(b->k, x->data, (int64_t) x->nb[1], x->type == GGML_TYPE_F16, b->act, (int) K, T, mode);
                     if (rc) return rc;
@@ -970,14 +962,10 @@ static int run_node(mi_backend_ctx * b, const ggml_tensor * n) {
     }
 }
 
-// walk nodes [i0, i_stop) and emit kernels (eagerly, or into the context's launch record).  While recording with
-// max_launches > 0 the walk also stops, at a node boundary, once that many launches have been recorded; *i_next receives the
-// index of the first node not processed.
-static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop, int max_launches, int * i_next) {
+// walk nodes [i0, i_stop) and emit kernels on the backend's stream
+static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop) {
     int i = i0;
     for (; i < i_stop; i++) {
-        if (max_launches > 0 && (b->recording ? mi355x_record_count(b->k) >= max_launches
-                                              : (int) (mi355x_eager_count(b->k) - b->eager_base) >= max_launches)) break;
         const ggml_tensor * n = g->nodes[i];
         if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
         int rc = MI355X_E_UNSUPPORTED;
@@ -1054,99 +1042,11 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
             return rc;
         }
     }
-    if (i_next) *i_next = i < i_stop ? i : i_stop;
     return mi355x_flush(b->k);            // launches the kernel library held back for grouping (gemm_mfma.hip) leave with their range
 }
 static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
     b->act_src = nullptr;
-    return mi_emit_range(b, g, 0, g->n_nodes, 0, nullptr);
-}
-
-// ---- hipGraph replay ----------------------------------------------------------------------------------
-static bool same_shape(const mi355x_launch & a, const mi355x_launch & b) {
-    return a.func == b.func && a.arg_size == b.arg_size && a.shmem == b.shmem &&
-           !memcmp(a.block, b.block, sizeof(a.block));
-}
-
-static int mi_run_recorded(mi_backend_ctx * b, uint64_t key, const mi355x_launch * L, int n, const uint8_t * blob, size_t blob_size) {
-    hipStream_t stream = (hipStream_t) mi355x_ctx_stream(b->k);
-    mi_graph_cache * gc = nullptr;
-    for (auto & c : b->gcache) if (c.key == key && (int) c.launches.size() == n) { gc = &c; break; }
-    bool rebuild = gc == nullptr;
-    if (gc) {
-        for (int i = 0; i < n && !rebuild; i++) if (!same_shape(gc->launches[i], L[i])) rebuild = true;
-    }
-    if (rebuild) {
-        if (!gc) {
-            if (b->gcache.size() >= 48) {           // bounded cache: drop the least used entry that was not launched by this graph_compute
-                size_t worst = b->gcache.size();
-                for (size_t i = 0; i < b->gcache.size(); i++) {
-                    if (b->gcache[i].last_call == b->n_graph_compute) continue;
-                    if (worst == b->gcache.size() || b->gcache[i].hits < b->gcache[worst].hits) worst = i;
-                }
-                if (worst < b->gcache.size()) {
-                    // graph launches are asynchronous: the entry may still be executing (or queued) on the compute stream
-                    (void) hipStreamSynchronize(stream);
-                    if (b->gcache[worst].exec)  (void) hipGraphExecDestroy(b->gcache[worst].exec);
-                    if (b->gcache[worst].graph) (void) hipGraphDestroy(b->gcache[worst].graph);
-                    b->gcache.erase(b->gcache.begin() + worst);
-                }
-            }
-            b->gcache.emplace_back();
-            gc = &b->gcache.back();
-            gc->key = key;
-        } else {
-            (void) hipStreamSynchronize(stream);        // the previous instance of this entry may still be executing
-            if (gc->exec)  (void) hipGraphExecDestroy(gc->exec);
-            if (gc->graph) (void) hipGraphDestroy(gc->graph);
-            gc->exec = nullptr; gc->graph = nullptr;
-        }
-        gc->launches.assign(L, L + n);
-        gc->blob.assign(blob, blob + blob_size);
-        gc->nodes.resize(n);
-        if (hipGraphCreate(&gc->graph, 0) != hipSuccess) return -2;
-        for (int i = 0; i < n; i++) {
-            hipKernelNodeParams p = {};
-            void * args[1] = { (void *) (gc->blob.data() + L[i].arg_offset) };
-            p.func = (void *) L[i].func;
-            p.gridDim = dim3(L[i].grid[0], L[i].grid[1], L[i].grid[2]);
-            p.blockDim = dim3(L[i].block[0], L[i].block[1], L[i].block[2]);
-            p.sharedMemBytes = L[i].shmem; p.kernelParams = args; p.extra = nullptr;
-            hipError_t e = hipGraphAddKernelNode(&gc->nodes[i], gc->graph, i ? &gc->nodes[i - 1] : nullptr, i ? 1 : 0, &p);
-            if (e != hipSuccess) { MI_LOG("hipGraphAddKernelNode failed: %s", hipGetErrorString(e)); return -2; }
-        }
-        hipError_t e = hipGraphInstantiate(&gc->exec, gc->graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) { MI_LOG("hipGraphInstantiate failed: %s", hipGetErrorString(e)); return -2; }
-        b->n_rebuild++;
-    } else {
-        // patch the kernel nodes whose arguments or grid changed since the last replay
-        const double tp0 = now_ms();
-        for (int i = 0; i < n; i++) {
-            const mi355x_launch & o = gc->launches[i];
-            const bool same = !memcmp(o.grid, L[i].grid, sizeof(o.grid)) &&
-                              !memcmp(gc->blob.data() + o.arg_offset, blob + L[i].arg_offset, L[i].arg_size);
-            if (same) continue;
-            memcpy(gc->blob.data() + o.arg_offset, blob + L[i].arg_offset, L[i].arg_size);
-            memcpy(gc->launches[i].grid, L[i].grid, sizeof(o.grid));
-            hipKernelNodeParams p = {};
-            void * args[1] = { (void *) (gc->blob.data() + o.arg_offset) };
-            p.func = (void *) o.func;
-            p.gridDim = dim3(L[i].grid[0], L[i].grid[1], L[i].grid[2]);
-            p.blockDim = dim3(o.block[0], o.block[1], o.block[2]);
-            p.sharedMemBytes = o.shmem; p.kernelParams = args; p.extra = nullptr;
-            hipError_t e = hipGraphExecKernelNodeSetParams(gc->exec, gc->nodes[i], &p);
-            if (e != hipSuccess) { MI_LOG("hipGraphExecKernelNodeSetParams failed: %s", hipGetErrorString(e)); return -2; }
-            b->n_update++;
-        }
-        b->n_replay++;
-        b->t_patch_ms += now_ms() - tp0;
-    }
-    gc->hits++; gc->last_call = b->n_graph_compute;
-    const double tl0 = now_ms();
-    hipError_t e = hipGraphLaunch(gc->exec, stream);
-    b->t_launch_ms += now_ms() - tl0;
-    if (e != hipSuccess) { MI_LOG("hipGraphLaunch failed: %s", hipGetErrorString(e)); return -2; }
-    return 0;
+    return mi_emit_range(b, g, 0, g->n_nodes);
 }
 
 static const char * mi_backend_get_name(ggml_backend_t backend) { return ((mi_backend_ctx *) backend->context)->name.c_str(); }
@@ -1155,18 +1055,16 @@ static void mi_backend_free(ggml_backend_t backend) {
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     (void) hipSetDevice(b->device);
     mi355x_ctx_synchronize(b->k);
-    if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 " replays=%" PRIu64 " node-updates=%" PRIu64 " rebuilds=%" PRIu64 "\n",
-                           b->name.c_str(), b->n_graph_compute, b->n_replay, b->n_update, b->n_rebuild);
+    if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 "\n", b->name.c_str(), b->n_graph_compute);
     if (b->span_pending) mi_span_drain(b);
     for (auto & e : b->span_ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
-    for (auto & c : b->gcache) { if (c.exec) (void) hipGraphExecDestroy(c.exec); if (c.graph) (void) hipGraphDestroy(c.graph); }
     if (b->act) (void) hipFree(b->act);
     if (b->act_alt) (void) hipFree(b->act_alt);
     {
         std::lock_guard<std::mutex> lk(g_weights_mtx);
         for (size_t i = 0; i < g_backends.size(); i++) if (g_backends[i] == b) { g_backends.erase(g_backends.begin() + i); break; }
-        g_total_stats[0] += b->n_graph_compute; g_total_stats[1] += b->n_replay; g_total_stats[2] += b->n_update; g_total_stats[3] += b->n_rebuild;
-        g_total_host_ms[0] += b->t_plan_ms; g_total_host_ms[1] += b->t_patch_ms; g_total_host_ms[2] += b->t_launch_ms; g_total_host_ms[3] += b->t_eager_ms;
+        g_total_stats[0] += b->n_graph_compute;
+        g_total_host_ms[3] += b->t_eager_ms;
         g_total_gpu_span_ms += b->t_gpu_span_ms;
     }
     mi355x_ctx_destroy(b->k);
@@ -1215,77 +1113,6 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
         (void) hipEventRecord(b->span_ev[span_idx].first, (hipStream_t) mi355x_ctx_stream(b->k));
     }
     struct span_end { mi_backend_ctx * b; int idx; ~span_end() { if (idx >= 0) (void) hipEventRecord(b->span_ev[idx].second, (hipStream_t) mi355x_ctx_stream(b->k)); } } span_guard{ b, span_idx };
-    // graphs pay off when the launch sequence is long and launch-bound (decoder step); profiling needs eager launches
-    // The FIRST call for a graph of a given size always runs as plain launches: it is the one that grows the scratch buffers, creates
-    // the f16 weight copies and fills the planner's caches — side effects that must not happen inside a recording that may be
-    // aborted and re-run (a weight copy whose dequantization was only RECORDED would be published before it exists).
-    bool warm = false;
-    for (int n : b->warm_sizes) if (n == cgraph->n_nodes) { warm = true; break; }
-    if (!warm) b->warm_sizes.push_back(cgraph->n_nodes);
-    const bool use_graph = b->graphs && !b->prof && cgraph->n_nodes >= 32 && warm;
-    if (use_graph) {
-        // The launch sequence is replayed as hipGraphs of ~seg launches each: the first segment starts executing while the
-        // host is still planning / patching / launching the following ones, so only 1/n-th of the per-step host work sits in
-        // front of the GPU (a decode step of large-v3 is 264 launches and ~145 us of host work in here).
-        static const int seg = getenv("GGML_MI355X_GRAPH_SEG") ? atoi(getenv("GGML_MI355X_GRAPH_SEG")) : 64;
-        // the first segment is short: it is the only one whose planning / patching / hipGraphLaunch the GPU has to wait for
-        static const int seg0 = getenv("GGML_MI355X_GRAPH_SEG0") ? atoi(getenv("GGML_MI355X_GRAPH_SEG0")) : 12;
-        b->act_src = nullptr;
-        int i = 0, iseg = 0;
-        bool ok = true;
-        // The head of the sequence goes out as plain launches: the GPU starts on the first kernel ~5 us after graph_compute is entered
-        // instead of after planning + comparing + hipGraphLaunch of a first graph segment (~25 us), and the host stays ahead of it
-        // (3.5 us per launch against ~5 us per dependent kernel) while it records the first real segment.
-        static const int head = getenv("GGML_MI355X_EAGER_HEAD") ? atoi(getenv("GGML_MI355X_EAGER_HEAD")) : 0;
-        if (head > 0) {
-            const double t1 = now_ms();
-            b->eager_base = mi355x_eager_count(b->k);
-            int i_next = cgraph->n_nodes;
-            if (mi_emit_range(b, cgraph, 0, cgraph->n_nodes, head, &i_next) != 0) return GGML_STATUS_FAILED;
-            b->t_eager_ms += now_ms() - t1;
-            i = i_next; iseg = 1;
-        }
-        while (i < cgraph->n_nodes && ok) {
-            const double t0 = now_ms();
-            mi355x_record_begin(b->k);
-            b->recording = true; b->record_abort = false;
-            int i_next = cgraph->n_nodes;
-            // GGML_MI355X_GRAPH_SEGS=a,b,c overrides the schedule: segment i holds the i-th entry's launches (last entry repeats)
-            static const std::vector<int> segs = [] {
-                std::vector<int> v;
-                if (const char * e = getenv("GGML_MI355X_GRAPH_SEGS")) for (const char * p = e; *p; ) { v.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p) p++; }
-                return v;
-            }();
-            const int seg_len = !segs.empty() ? segs[std::min((size_t) iseg, segs.size() - 1)] : (iseg == 0 && seg > 0 && seg0 > 0) ? seg0 : seg;
-            int rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, seg_len, &i_next);
-            b->recording = false;
-            b->t_plan_ms += now_ms() - t0;
-            const mi355x_launch * L; const uint8_t * blob; size_t bsz;
-            const int n = mi355x_record_end(b->k, &L, &blob, &bsz);
-            if (rc != 0) return GGML_STATUS_FAILED;
-            if (n < 0 || b->record_abort) {
-                // a scratch buffer had to grow while recording: this segment runs eagerly (the next call records again).  The aborted
-                // pass moved the planner's prepared-activation cache without running a kernel: forget it.
-                b->act_src = nullptr;
-                const double t1 = now_ms();
-                rc = mi_emit_range(b, cgraph, i, i_next, 0, nullptr);
-                b->t_eager_ms += now_ms() - t1;
-                if (rc != 0) return GGML_STATUS_FAILED;
-            } else if (n > 0) {
-                rc = mi_run_recorded(b, ((uint64_t) cgraph->n_nodes << 16) | (uint64_t) iseg, L, n, blob, bsz);
-                if (rc != 0) {
-                    MI_LOG("graph replay unavailable (rc=%d); falling back to eager launches", rc);
-                    b->graphs = false;
-                    const double t1 = now_ms();
-                    rc = mi_emit_range(b, cgraph, i, cgraph->n_nodes, 0, nullptr);
-                    b->t_eager_ms += now_ms() - t1;
-                    return rc == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
-                }
-            }
-            i = i_next; iseg++;
-        }
-        return GGML_STATUS_SUCCESS;
-    }
     const double t0 = now_ms();
     const int rc = mi_emit_graph(b, cgraph);
     b->t_eager_ms += now_ms() - t0;
@@ -1339,15 +1166,10 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
     if (!k) { GGML_LOG_ERROR("ggml-mi355x: failed to create kernel context on device %d: %s\n", d->index, mi355x_last_error()); return nullptr; }
     mi_backend_ctx * b = new mi_backend_ctx();
     b->device = d->index; b->k = k; b->name = d->name;
-    // hipGraph replay of the recorded launch sequence is OPT-IN (GGML_MI355X_GRAPHS=1).  Measured on large-v3 Q5_0, ROCm 7.2
-    // (profiles/r02_decode_launch_mode_sweep.txt, r02_stream_scaling_graphs_vs_eager.txt): plain launches 1.473 ms/token and 2.59
-    // chunks/s against 1.515 ms/token and 2.40-2.50 chunks/s with segmented graph replay, and no worse at 2-8 concurrent streams —
-    // the replayed (packet-captured) nodes cost ~0.2 us more each on the GPU than the same kernels launched directly, and at ~5 us
-    // per dependent kernel the host's 3.5 us per launch never becomes the bottleneck.  Replay still buys host CPU time (0.8 ms ->
-    // 0.1 ms per decode step): worth it only where host threads are scarcer than here.
-    b->fuse = env_flag("GGML_MI355X_FUSE", true); b->graphs = env_flag("GGML_MI355X_GRAPHS", false); b->prof = env_flag("GGML_MI355X_PROF", false);
+    // Plain launches on the backend's stream.  (Rounds 1-2 carried a record / patch / replay path over hipGraphs; on ROCm 7.2 it lost to
+    //  the plain launch loop on the same kernels — 1.515 vs 1.473 ms/token, profiles/r02_decode_launch_mode_sweep.txt — and was removed.)
+    b->fuse = env_flag("GGML_MI355X_FUSE", true); b->prof = env_flag("GGML_MI355X_PROF", false);
     b->exact = env_flag("GGML_MI355X_EXACT", false);
-    if (b->exact) b->graphs = false;          // a test mode: thousands of small launches per graph, replay buys nothing
     if (b->prof) mi355x_prof_enable(k, 1);
     { std::lock_guard<std::mutex> lk(g_weights_mtx); g_backends.push_back(b); }
     return new ggml_backend{ mi_guid(), mi_backend_iface, dev, b };
@@ -1415,7 +1237,7 @@ static ggml_backend_dev_t mi_reg_get_device(ggml_backend_reg_t, size_t index) {
 }
 
 static ggml_mi355x_feature g_features[] = {
-    { "ARCH", "gfx950" }, { "MFMA_F16", "1" }, { "DOT4_I8", "1" }, { "PLANAR_QUANT", "1" }, { "HIP_GRAPHS", "1" }, { nullptr, nullptr },
+    { "ARCH", "gfx950" }, { "MFMA_F16", "1" }, { "DOT4_I8", "1" }, { "PLANAR_QUANT", "1" }, { nullptr, nullptr },
 };
 
 static mi_backend_ctx * as_ctx(void * backend) {
@@ -1471,11 +1293,11 @@ int ggml_backend_mi355x_prof_report_all(ggml_mi355x_prof_row * rows, int cap) {
     }
     return n;
 }
-// out[0..3] = graph_compute calls, hipGraph replays, patched kernel nodes, graph (re)builds — over all backends so far
+// out[0] = graph_compute calls over all backends so far (out[1..3]: always 0 — the counters of the removed hipGraph replay path, kept for ABI)
 void ggml_backend_mi355x_stats(uint64_t * out) {
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     for (int i = 0; i < 4; i++) out[i] = g_total_stats[i];
-    for (auto * b : g_backends) { out[0] += b->n_graph_compute; out[1] += b->n_replay; out[2] += b->n_update; out[3] += b->n_rebuild; }
+    for (auto * b : g_backends) out[0] += b->n_graph_compute;
 }
 
 // out[0..3] = host milliseconds spent inside graph_compute: planning (graph walk + launch recording), hipGraph node
@@ -1485,7 +1307,7 @@ void ggml_backend_mi355x_stats(uint64_t * out) {
 void ggml_backend_mi355x_host_times(double * out) {
     std::lock_guard<std::mutex> lk(g_weights_mtx);
     for (int i = 0; i < 4; i++) out[i] = g_total_host_ms[i];
-    for (auto * b : g_backends) { out[0] += b->t_plan_ms; out[1] += b->t_patch_ms; out[2] += b->t_launch_ms; out[3] += b->t_eager_ms; }
+    for (auto * b : g_backends) out[3] += b->t_eager_ms;
     for (int i = 0; i < 4; i++) { out[4 + i] = g_io_ns[i].load() * 1e-6; out[8 + i] = (double) g_io_calls[i].load(); }
     out[12] = g_total_gpu_span_ms;
     for (auto * b : g_backends) out[12] += b->t_gpu_span_ms;       // completed (drained) graph_computes only
@@ -1535,7 +1357,17 @@ static int mi_checksums(int device, const std::vector<mi_weight_rec> & bufs, std
 }
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>      // types only: the entry points are resolved with dlsym
+// RCCL is dlopen()ed; only a handful of its types are needed here.  With the RCCL headers installed they come from there, on a ROCm
+// install without them the same (ABI-stable, nccl.h) declarations are made locally so that the plugin still builds.
+#if defined(__has_include) && __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm * ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+#endif
 
 struct mi_rccl_api {
     void * h = nullptr;
@@ -1567,7 +1399,8 @@ extern "C" {
 
 // uploads of weight tensors are skipped while the flag is set (replicas whose weights will arrive by broadcast: the skipping
 // model loader of the host harness never reads tensor payloads, this covers callers that do)
-void ggml_backend_mi355x_defer_weights(int on) { g_defer_weights.store(on ? 1 : 0); }
+void ggml_backend_mi355x_defer_weights(int on) { t_defer_weights = on ? 1 : 0; }
+uint64_t ggml_backend_mi355x_deferred_bytes(void) { return g_deferred_bytes.load(); }
 
 // out[0..2n): {sum, weighted sum} of every WEIGHTS buffer of `device` in allocation order; returns n (or -1)
 int ggml_backend_mi355x_weights_checksum(int device, uint64_t * out, int cap) {
@@ -1655,13 +1488,22 @@ int ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, 
     mi_io_drain(device); (void) hipDeviceSynchronize();
     const std::vector<mi_weight_rec> B = mi_weight_list(device);
     ncclUniqueId id; memcpy(&id, unique_id128, sizeof(id));
-    ncclComm_t comm = nullptr;
-    if (r->CommInitRank(&comm, world, id, rank) != ncclSuccess) return -1;
+    // Local resources FIRST: a rank that cannot get them still joins the communicator and the agreement round below, so that no other
+    // rank is left waiting inside a collective for it.  (A rank whose ncclCommInitRank itself fails cannot be helped from here: the
+    // others block in their own init until RCCL's bootstrap times out — the host harness's all_ranks_ok round then reports it.)
     hipStream_t st = nullptr;
-    (void) hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-    int rc = 0;
     uint64_t * d64 = nullptr;          // device scratch: layout words, then checksums
     const size_t nw = 1 + B.size();
+    const size_t cap_words = 3 * std::max(nw, 2 * B.size() + 2) + 8;
+    bool local_ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+    if (hipMalloc((void **) &d64, cap_words * 8) != hipSuccess) { d64 = nullptr; local_ok = false; (void) hipGetLastError(); }
+    ncclComm_t comm = nullptr;
+    if (r->CommInitRank(&comm, world, id, rank) != ncclSuccess) {
+        if (d64) (void) hipFree(d64);
+        if (st) (void) hipStreamDestroy(st);
+        return -1;
+    }
+    int rc = 0;
     std::vector<uint64_t> lay(nw), lo(nw), hi(nw);
     lay[0] = B.size(); for (size_t i = 0; i < B.size(); i++) lay[1 + i] = B[i].size;
     auto all_equal = [&](std::vector<uint64_t> & v) -> bool {      // every rank holds the same words?  (min == max over ranks)
@@ -1674,8 +1516,14 @@ int ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, 
         if (hipMemcpy(a.data(), d64 + n, n*8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(b.data(), d64 + 2*n, n*8, hipMemcpyDeviceToHost) != hipSuccess) return false;
         return a == b;
     };
-    const size_t cap_words = 3 * std::max(nw, 2 * B.size() + 2);
-    if (hipMalloc((void **) &d64, cap_words * 8) != hipSuccess) rc = -1;
+    if (!local_ok) {
+        // this rank cannot run the data collectives: it cannot take part in the agreement either (no device word), so it leaves;
+        // the communicator is destroyed, which makes the peers' next collective fail instead of hang
+        if (d64) (void) hipFree(d64);
+        if (st) (void) hipStreamDestroy(st);
+        (void) r->CommDestroy(comm);
+        return -1;
+    }
     if (rc == 0 && !all_equal(lay)) rc = -2;                        // same number of buffers, same sizes, on every rank
     double bytes = 0, secs = 0;
     if (rc == 0) {
@@ -1688,10 +1536,15 @@ int ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, 
         secs = (now_ms() - t0) * 1e-3;
     }
     bool verified = false;
-    if (rc == 0) {
+    if (rc != -2) {
+        // every rank that agreed on the layout takes part in this round, also one whose broadcast or checksum failed locally: it
+        // contributes words that cannot match (its rank in the high bits), so ALL ranks see "not verified" and nobody waits forever
         std::vector<uint64_t> cs;
-        if (mi_checksums(device, B, cs) != 0) rc = -4;
-        else { cs.push_back(0xC0FFEEull); cs.push_back((uint64_t) B.size()); verified = all_equal(cs); if (!verified) rc = -4; }
+        const bool local = rc == 0 && mi_checksums(device, B, cs) == 0;
+        if (!local) cs.assign(2 * B.size(), 0xBAD0000000000000ull | (uint64_t) rank);
+        cs.push_back(0xC0FFEEull); cs.push_back((uint64_t) B.size());
+        verified = all_equal(cs) && local;
+        if (!verified && rc == 0) rc = -4;
     }
     if (d64) (void) hipFree(d64);
     if (st) (void) hipStreamDestroy(st);
@@ -1715,6 +1568,7 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_broadcast_weights_rccl"))  return (void *) ggml_backend_mi355x_broadcast_weights_rccl;
     if (!strcmp(name, "ggml_backend_mi355x_rccl_unique_id"))          return (void *) ggml_backend_mi355x_rccl_unique_id;
     if (!strcmp(name, "ggml_backend_mi355x_defer_weights"))           return (void *) ggml_backend_mi355x_defer_weights;
+    if (!strcmp(name, "ggml_backend_mi355x_deferred_bytes"))          return (void *) ggml_backend_mi355x_deferred_bytes;
     if (!strcmp(name, "ggml_backend_mi355x_prof_enable_all")) return (void *) ggml_backend_mi355x_prof_enable_all;
     if (!strcmp(name, "ggml_backend_mi355x_prof_reset_all"))  return (void *) ggml_backend_mi355x_prof_reset_all;
     if (!strcmp(name, "ggml_backend_mi355x_prof_report_all")) return (void *) ggml_backend_mi355x_prof_report_all;

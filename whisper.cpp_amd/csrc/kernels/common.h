@@ -37,11 +37,6 @@ struct mi355x_ctx {
     std::vector<void *> scratch_retired; // outgrown arenas that may still back pointers of the current op group
     float *     mel_tab = nullptr;       // sin / cos / Hann tables + the running maximum of mi355x_log_mel (device)
     uint64_t    n_eager = 0;             // launches issued directly on the stream so far (mi355x_eager_count)
-    // recording
-    bool                        recording = false;
-    bool                        record_invalid = false;
-    std::vector<mi355x_launch>  plan;
-    std::vector<uint8_t>        blob;
     // profiling
     bool                                 prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -67,7 +62,7 @@ void   mi355x_set_error(const char * fmt, ...);
 void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes);
 void   mi355x_scratch_reset(mi355x_ctx * ctx);
 
-// emit one kernel launch (eager: hipLaunchKernel on ctx->stream; recording: append to plan)
+// emit one kernel launch (hipLaunchKernel on ctx->stream)
 int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 grid, dim3 block, uint32_t shmem,
                 const void * args, uint32_t arg_size, double algo_bytes, double algo_flops);
 

@@ -161,7 +161,6 @@ void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes) {
         ctx->scratch_retired.clear();
         if (ctx->scratch) { if (ctx->scratch_used > 0) ctx->scratch_retired.push_back(ctx->scratch); else (void) hipFree(ctx->scratch); }
         ctx->scratch = nptr; ctx->scratch_size = nsz; ctx->scratch_used = 0;
-        if (ctx->recording) { mi355x_set_error("scratch grew while recording; plan invalid"); ctx->record_invalid = true; }
     }
     void * p = (char *) ctx->scratch + ctx->scratch_used;
     ctx->scratch_used += bytes;
@@ -173,18 +172,6 @@ int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 gri
                 const void * args, uint32_t arg_size, double algo_bytes, double algo_flops) {
     if (grid.x == 0 || grid.y == 0 || grid.z == 0) return 0;
     { const int rc = mi355x_flush_pending(ctx); if (rc) return rc; }      // held-back launches go first: stream order is program order
-    if (ctx->recording) {
-        mi355x_launch l;
-        l.func = func; l.grid[0] = grid.x; l.grid[1] = grid.y; l.grid[2] = grid.z;
-        l.block[0] = block.x; l.block[1] = block.y; l.block[2] = block.z;
-        l.shmem = shmem; l.arg_size = arg_size;
-        size_t off = (ctx->blob.size() + 15) & ~(size_t) 15;
-        ctx->blob.resize(off + arg_size);
-        memcpy(ctx->blob.data() + off, args, arg_size);
-        l.arg_offset = off; l.name = name; l.algo_bytes = algo_bytes; l.algo_flops = algo_flops;
-        ctx->plan.push_back(l);
-        return 0;
-    }
     int ev = -1;
     void * kargs[1] = { (void *) args };
     hipError_t e;
@@ -230,16 +217,7 @@ int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 gri
     return 0;
 }
 
-extern "C" int  mi355x_record_count(mi355x_ctx * ctx) { return ctx->recording ? (int) ctx->plan.size() : 0; }
 extern "C" uint64_t mi355x_eager_count(mi355x_ctx * ctx) { return ctx->n_eager; }
-extern "C" void mi355x_record_begin(mi355x_ctx * ctx) { ctx->recording = true; ctx->record_invalid = false; ctx->plan.clear(); ctx->blob.clear(); }
-extern "C" int  mi355x_record_end(mi355x_ctx * ctx, const mi355x_launch ** launches, const uint8_t ** arg_blob, size_t * blob_size) {
-    if (mi355x_flush_pending(ctx) != 0) ctx->record_invalid = true;
-    ctx->recording = false;
-    if (ctx->record_invalid) { *launches = nullptr; *arg_blob = nullptr; *blob_size = 0; return -1; }
-    *launches = ctx->plan.data(); *arg_blob = ctx->blob.data(); *blob_size = ctx->blob.size();
-    return (int) ctx->plan.size();
-}
 
 extern "C" void mi355x_prof_enable(mi355x_ctx * ctx, int on) { ctx->prof = on != 0; }
 extern "C" void mi355x_prof_reset(mi355x_ctx * ctx) { (void) mi355x_flush_pending(ctx); (void) hipStreamSynchronize(ctx->stream); prof_drain(ctx); ctx->prof_rows.clear(); }

@@ -268,8 +268,6 @@ extern "C" int mi355x_dequant_f16(mi355x_ctx * ctx, const mi355x_tensor * A, voi
     const int64_t ngroups = (int64_t) M * (K / 32);
     const dim3 g((uint32_t) ((ngroups + 255) / 256)), b(256);
     const double bytes = (double) mi355x_type_row_bytes(A->type, K) * M + (double) M * K * 2;
-    // preparation, not part of a step: always launched now, never appended to a plan that is being recorded
-    const bool rec = ctx->recording; ctx->recording = false;
     int rc;
     switch (A->type) {
         case MI355X_TYPE_Q4_0: rc = emit(ctx, "dequant_f16", k_dequant_f16<MI355X_TYPE_Q4_0>, g, b, 0, k, bytes, 0); break;
@@ -278,7 +276,6 @@ extern "C" int mi355x_dequant_f16(mi355x_ctx * ctx, const mi355x_tensor * A, voi
         case MI355X_TYPE_Q4_K: rc = emit(ctx, "dequant_f16", k_dequant_f16<MI355X_TYPE_Q4_K>, g, b, 0, k, bytes, 0); break;
         default: rc = MI355X_E_UNSUPPORTED;
     }
-    ctx->recording = rec;
     return rc;
 }
 
@@ -648,6 +645,16 @@ static bool gemm_mergeable(const PendingGemms & P, int n, const GemmArgs & k) {
     return true;
 }
 
+// register-staged MFMA kernel for plain f16 operands (no LDS-DMA ring, static LDS only)
+static int launch_staged_f16(mi355x_ctx * ctx, const GemmArgs & k, double bytes, double flops) {
+    const int64_t mt = (k.M + BM - 1) / BM, nt128 = (k.T + 127) / 128, nt64 = (k.T + 63) / 64;
+    if (mt * nt128 >= ctx->n_cu || k.T > 64*65535LL) {
+        if (nt128 > 65535) return MI355X_E_UNSUPPORTED;
+        return emit(ctx, "gemm_mfma", k_gemm_mfma<MI355X_TYPE_F16, 128>, dim3((uint32_t) mt, (uint32_t) nt128), dim3(256), 0, k, bytes, flops);
+    }
+    return emit(ctx, "gemm_mfma", k_gemm_mfma<MI355X_TYPE_F16, 64>, dim3((uint32_t) mt, (uint32_t) nt64), dim3(256), 0, k, bytes, flops);
+}
+
 static int flush_pending_gemms(mi355x_ctx * ctx) {
     PendingGemms P; memcpy(&P, ctx->pending_store, sizeof(P));
     const int n = ctx->pending_n;
@@ -692,8 +699,13 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
                 rc = launch_ring_group<64, 2>(ctx, P.k, n, P.bytes, P.flops);
         }
     }
+    if (rc == MI355X_E_UNSUPPORTED) {
+        // the runtime rejected the ring kernel's dynamic LDS size: every member leaves as the register-staged kernel instead (the
+        // path launch_gemm takes when the ring is switched off) — same tiles, same results, nothing surfaces on a later op
+        rc = 0;
+        for (int i = 0; i < n && rc == 0; i++) rc = launch_staged_f16(ctx, P.k[i], P.bytes / n, P.flops / n);
+    }
     ctx->in_flush = false;
-    if (rc == MI355X_E_UNSUPPORTED) { mi355x_set_error("ring GEMM: dynamic LDS attribute rejected"); rc = (int) hipErrorInvalidValue; }
     return rc;
 }
 

@@ -19,7 +19,7 @@ _BLOCK = {F32: (1, 4), F16: (1, 2), I32: (1, 4), Q4_0: (32, 18), Q5_0: (32, 22),
 # every symbol declared in include/mi355x_kernels.h (tests/test_abi.py checks header <-> library <-> this list)
 SYMBOLS = [
     "mi355x_device_count", "mi355x_ctx_create", "mi355x_ctx_destroy", "mi355x_ctx_stream", "mi355x_ctx_synchronize", "mi355x_flush", "mi355x_norm_prep", "mi355x_flash_attn_ext_prep", "mi355x_gemm_f16act_prep",
-    "mi355x_last_error", "mi355x_record_begin", "mi355x_record_count", "mi355x_eager_count", "mi355x_record_end", "mi355x_prof_enable", "mi355x_prof_report",
+    "mi355x_last_error", "mi355x_eager_count", "mi355x_prof_enable", "mi355x_prof_report",
     "mi355x_prof_reset", "mi355x_type_is_quantized", "mi355x_type_row_bytes", "mi355x_repack_to_planar",
     "mi355x_repack_from_planar", "mi355x_mul_mat", "mi355x_prep_act", "mi355x_gemm_f16act", "mi355x_dequant_f16", "mi355x_gemv_fused",
     "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_combine", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
