@@ -117,7 +117,7 @@ def algorithmic_figures(arch: str, qtype: str):
     kv_cross = n_tl * 2 * n_ctx_pad * n_ts * 2
     enc_flop = 2.0 * n_actx * n_al * 12 * n_as * n_as + 4.0 * n_actx * n_ctx_pad * n_as * n_al \
         + 2.0 * (2 * n_actx) * n_as * 3 * n_mels + 2.0 * n_actx * n_as * 3 * n_as + 2.0 * n_actx * n_tl * 2 * n_ts * n_ts
-    return {"decode_bytes_per_token": dec_w * bpw + kv_cross, "encode_flop": enc_flop}
+    return {"decode_bytes_per_token": dec_w * bpw + kv_cross, "encode_flop": enc_flop, "decode_weight_bytes": dec_w * bpw, "decode_kv_bytes_per_stream": kv_cross}
 
 
 def main():
@@ -129,7 +129,7 @@ def main():
     ap.add_argument("--qtype", default="q5_0")
     ap.add_argument("--n-decode", type=int, default=256)
     ap.add_argument("--streams", type=int, default=1, help="concurrent streams per GPU in the timed region (headline config: 1)")
-    ap.add_argument("--multi-stream", type=int, default=4, help="also measure S concurrent streams on one GPU after the headline (0 = skip)")
+    ap.add_argument("--multi-stream", type=int, default=8, help="also measure S concurrent streams on one GPU after the headline, with and without cross-state batching (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default="whisper-bench", choices=["whisper-bench", "bounded"],
                     help="whisper-bench: the metric's own tool, the reference build's `whisper-bench -ng -t N` (all four columns, after its own two "
@@ -277,22 +277,34 @@ def main():
     tm = w.whisper_get_timings(ctx).contents
     batchd_ms, prompt_ms = float(tm.batchd_ms), float(tm.prompt_ms)
 
-    # SURVEY.md §8f rank 2, reported beside the headline: S concurrent streams sharing this GPU and one copy of the weights
+    # SURVEY.md §8f rank 2, reported beside the headline: S concurrent streams sharing this GPU and one copy of the weights, through the
+    # native C++ harness (include/mi355x_host.h: one thread per whisper_state).  "batched": the plugin runs the states' single-token
+    # steps as the columns of ONE launch chain (weights read once per step for all streams); "unbatched": one launch chain per state.
     multi_stream = None
     if a.multi_stream > 1 and multi is None and world == 1:
         try:
-            ms = make_streams(a.multi_stream)
-            ms.chunk_all(a.n_decode)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(2):
-                ms.chunk_all(a.n_decode)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            ms.close()
-            multi_stream = {"streams": a.multi_stream, "chunks_per_s": round(2 * a.multi_stream / el, 4),
-                            "ms_per_chunk_aggregate": round(el * 1e3 / (2 * a.multi_stream), 3), "ms_per_chunk_per_stream": round(el * 1e3 / 2, 3),
-                            "note": "one whisper_state (own HIP stream, KV caches, compute buffers) per stream on one whisper_context; weights shared"}
+            from whisper_cpp_amd import host_api
+            figs_ms = algorithmic_figures(a.arch, a.qtype)
+            multi_stream = {"streams": a.multi_stream, "harness": "mi355x_host_run (C++ threads, one whisper_state each, one whisper_context, weights shared)"}
+            for label, batching, ns in (("batched", 1, a.multi_stream), ("unbatched", 0, min(a.multi_stream, 4))):
+                r = host_api.run(model, use_gpu=True, n_devices=1, streams=ns, n_decode=a.n_decode, steps=2, warmup=1, n_threads=2, batching=batching)
+                if r["rc"] != 0:
+                    multi_stream[label] = {"streams": ns, "error": r["error"]}
+                    continue
+                e = {"streams": ns, "chunks_per_s": round(r["chunks_per_s"], 4), "ms_per_chunk_aggregate": round(1e3 / r["chunks_per_s"], 3),
+                     "ms_per_chunk_per_stream": round(r["ms_per_chunk_per_stream"], 3), "batch_stats": r["batch_stats"]}
+                if batching:
+                    # algorithmic HBM bytes of one merged step: the decoder weights ONCE + every stream's cross-KV; streams * n_decode tokens per chunk round
+                    st = r["batch_stats"]
+                    cols = st["columns"] / max(st["chains"], 1)
+                    step_bytes = figs_ms["decode_weight_bytes"] + cols * figs_ms["decode_kv_bytes_per_stream"]
+                    steps_per_s = r["chunks_per_s"] * a.n_decode / max(cols, 1)
+                    e["mean_columns_per_chain"] = round(cols, 2)
+                    e["decode_algorithmic_GBps"] = round(step_bytes * steps_per_s / 1e9, 1)
+                    e["decode_frac_of_hbm_peak"] = round(step_bytes * steps_per_s / 1e9 / HBM_PEAK_GBS, 4)
+                multi_stream[label] = e
+            p.ggml_backend_mi355x_set_batching.argtypes = [C.c_int]
+            p.ggml_backend_mi355x_set_batching(0)
         except Exception as e:  # noqa: BLE001
             multi_stream = {"streams": a.multi_stream, "error": str(e)}
 

@@ -67,6 +67,23 @@ GGML_MI355X_API int  ggml_backend_mi355x_prof_report_all(struct ggml_mi355x_prof
 GGML_MI355X_API void ggml_backend_mi355x_stats(uint64_t * out);
 /* out[13]: [12] GPU-side span of all completed graph_computes (ms, hipEvent pairs on the compute stream); [3] host milliseconds inside graph_compute (graph walk + launches; [0..2] always 0, kept for layout); [4..7] milliseconds inside {set_tensor, get_tensor, cpy_tensor, synchronize}; [8..11] their call counts */
 GGML_MI355X_API void ggml_backend_mi355x_host_times(double * out);
+/* GGML_MI355X_TRACE=1 (off: returns 0, zeros): out[2i] = nanoseconds, out[2i+1] = calls of slot i — 0 supports_op, 1 supports_buft,
+ * 2 graph_compute entry -> first kernel launched, 3 graph_compute entry -> return, 4 graph_compute entry -> synchronize return,
+ * 5 get_proc_address.  The plugin-owned side of the per-step host timeline (tests/native/step_trace.cpp measures the reference's side). */
+GGML_MI355X_API int  ggml_backend_mi355x_trace(uint64_t * out16);
+
+/* Cross-state batching: whisper_states of one device whose next graph is a single-token decoder step are
+ * executed as the COLUMNS of one launch chain — every weight byte is read once for all of them instead of once per state — by whichever
+ * of their host threads completes the set (up to 8 columns; a state alone runs the ordinary path; a state whose next graph is anything
+ * else leaves the group at once).  Per state the results are bit-identical to running alone.  Off by default: GGML_MI355X_BATCH=1 or
+ * ggml_backend_mi355x_set_batching(1) at any time.  ggml_backend_mi355x_batch_stats: out[0..4] = merged chains, columns carried, steps
+ * run alone, groups that fell back to one chain per state, windows that closed on an absent state. */
+GGML_MI355X_API void ggml_backend_mi355x_set_batching(int on);
+GGML_MI355X_API void ggml_backend_mi355x_batch_stats(int device, uint64_t * out5);
+/* test hook, needs no device (nothing is launched): does `cgraph` (struct ggml_cgraph *) fit the cross-state walker as S >= 2 columns
+ * (out[0] == 0), resp. for S == 1 how many of its stages the T >= 3 plane pipeline takes (out[1..3] LayerNorm / attention / plain
+ * mat-vec stages, out[4] compute nodes left to the other paths) */
+GGML_MI355X_API int  ggml_backend_mi355x_debug_walk(void * cgraph, int S, int64_t * out6);
 
 /* Multi-GPU weight distribution.  Replicas are independent streams: the only exchange is the ONE-TIME copy of
  * rank 0's WEIGHTS buffers into the identically laid out buffers of the other replicas (every context allocates the same tensors in

@@ -39,6 +39,8 @@ typedef struct mi355x_host_config {
     int32_t flash_attn;
     int32_t replicas_on_one_device; /* 1: every context uses gpu_device = first_device (a one-GPU machine standing in for n_devices GPUs:
                                      *    the payload-skipping load + device copy + checksum verify path runs on real hardware) */
+    int32_t batching;              /* cross-state batching in the plugin (ggml_backend_mi355x_set_batching): 1 on, 0 off, -1 leave as it is.  With
+                                    * it the states of one device that decode at the same time run as the columns of ONE launch chain */
 } mi355x_host_config;
 
 typedef struct mi355x_host_result {
@@ -52,6 +54,8 @@ typedef struct mi355x_host_result {
     int64_t file_bytes;
     int32_t n_devices, streams_per_device;
     char    error[256];            /* empty on success */
+    uint64_t batch_stats[5];       /* device first_device, over the whole run: merged launch chains, columns they carried, steps a state ran alone,
+                                    * groups that fell back to one chain per state, windows closed on an absent state (ggml_backend_mi355x_batch_stats) */
 } mi355x_host_result;
 
 /* returns 0 on success; on failure a non-zero code and out->error */

@@ -177,8 +177,55 @@ typedef struct mi355x_gemv_desc {
     const float * attn_part_ml;
     int32_t       attn_nparts;
     int32_t       reserved2;
+    /* third activation source (x == NULL, no partials): activations ALREADY rounded to the weight type's vec_dot_type by
+     * mi355x_act_prepare or by a producer's epilogue (planes_out below) — the T >= 3 / cross-state pipeline, see below */
+    const void *  x_planes;
+    /* optional: segment 0 (nseg == 1, N % 32 == 0, Q4_0/Q5_0/Q8_0 consumer) also leaves the Q8_0 planes of its result — the
+     * activations of the mat-vec that consumes it (fc1 + GELU -> fc2, src/whisper.cpp:2797-2827) — laid out for K' = N and the same T;
+     * planes_out_only: the F32 result itself is not stored (nothing else reads it) */
+    void *        planes_out;
+    int32_t       planes_out_only;
+    int32_t       reserved3;
+    /* optional per-column destinations / residuals (cross-state batches: column t belongs to another whisper_state); NULL: the
+     * strided form dst + t*dst_nb1, residual + t*residual_nb1.  Honoured by the x_planes path only. */
+    const struct mi355x_gemv_cols * cols;
 } mi355x_gemv_desc;
 MI355X_API int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
+
+/* ---- decoder steps with T = 3..8 columns (beam search: src/whisper.cpp:6486-6543 decodes n_tokens = beam size per step) and
+ * cross-state batches (several whisper_states' single-token steps as the columns of ONE launch chain, weights read once) --------
+ * The activation vector of a stage is rounded to the weight type's vec_dot_type ONCE (arch/x86/quants.c:302-398 Q8_0,
+ * ggml-quants.c:2768-2805 Q8_K) into "planes" in HBM — byte for byte the image of the LDS planes the fused T <= 2 kernels build
+ * in every workgroup — and every mat-vec workgroup only copies that image (Q8_0 family: lo[T][K/32] uint4 | hi[T][K/32] uint4 |
+ * d[T][K/32] f32 | sum[T][K/32] i32; Q8_K: q[4][T][K/64] uint4 | d[T][K/256] f32 | sums[T][K/32] i32).  Same arithmetic, same
+ * summation order per column as the fused kernels: a column's result does not depend on T or on which path computed it. */
+#define MI355X_MAX_COLS 8
+typedef struct mi355x_gemv_cols {
+    void *        dst[3][MI355X_MAX_COLS];     /* [segment][column] */
+    const float * res[3][MI355X_MAX_COLS];     /* NULL entries where the segment has no residual */
+} mi355x_gemv_cols;
+
+typedef struct mi355x_act_desc {
+    const float * x;               /* f32 [K, T], column stride x_nb1 bytes — or NULL with xcol / attention partials */
+    int64_t       x_nb1;
+    const float * xcol[MI355X_MAX_COLS];   /* xcol[0] != NULL: per-column vectors instead of x + t*x_nb1 */
+    int32_t       K, T;
+    int32_t       wtype;           /* weight type of the consumer: Q4_0/Q5_0/Q8_0 -> Q8_0 planes, Q4_K -> Q8_K planes */
+    int32_t       has_norm;        /* ggml_norm + affine first (K <= 2048), as in mi355x_gemv_desc */
+    float         eps;
+    int32_t       reserved;
+    const float * ln_w;
+    const float * ln_b;
+    const float * attn_part_o;     /* x == NULL && xcol[0] == NULL: combine of decode-attention partial records (K = H*64 <= 2048) */
+    const float * attn_part_ml;
+    int32_t       attn_nparts;
+    int32_t       reserved2;
+} mi355x_act_desc;
+MI355X_API size_t mi355x_act_planes_bytes(int wtype, int K, int T);
+MI355X_API int    mi355x_act_prepare(mi355x_ctx * ctx, const mi355x_act_desc * d, void * planes);
+/* two plane buffers owned by the context (each holds any K <= 8192, T <= 8): a stage reads one while its epilogue fills the other */
+MI355X_API void * mi355x_act_scratch(mi355x_ctx * ctx, int which);
+
 
 /* Decode attention in two halves (T <= 8 queries, head_dim 64): mi355x_flash_attn_partial computes, per head, query and
  * 128-key chunk, the un-normalised partial (max score m, sum l, sum_k exp(s_k - m) v_k) of ggml_flash_attn_ext
@@ -193,6 +240,16 @@ typedef struct mi355x_attn_partials {
 MI355X_API int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                                          const mi355x_tensor * mask /* nullable */, float scale, mi355x_attn_partials * out);
 MI355X_API int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_partials * p, const mi355x_tensor * dst);
+/* decode attention for S single-query states in ONE launch (cross-state batch): state s has its own q [64, 1, H], K / V caches
+ * (shapes and strides of k0 / v0, n_kv[s] keys) and mask row; records land as column s of a T = S partial set with
+ * nparts = max_s ceil(n_kv[s] / 128) (chunks beyond a state's keys are empty records: weight 0 in the combine). */
+typedef struct mi355x_attn_state { const void * q; const void * k; const void * v; const void * mask /* f16 row or NULL */; int32_t n_kv; int32_t reserved; } mi355x_attn_state;
+MI355X_API int mi355x_flash_attn_partial_multi(mi355x_ctx * ctx, int S, const mi355x_attn_state * st, const mi355x_tensor * q0, const mi355x_tensor * k0,
+                                               const mi355x_tensor * v0, float scale, mi355x_attn_partials * out);
+/* head of S single-token decoder steps in ONE launch: dst[s] = te[tok[s]] + pe[pos[s]] (src/whisper.cpp:2524-2526) and the
+ * F32 -> F16 cast of every state's mask row (ggml_cast, :2520); a state with tok == NULL / mask_f32 == NULL skips that half */
+typedef struct mi355x_head_state { const int32_t * tok; const int32_t * pos; float * dst; const float * mask_f32; void * mask_f16; int32_t n_mask; int32_t reserved; } mi355x_head_state;
+MI355X_API int mi355x_decode_head_multi(mi355x_ctx * ctx, int S, const mi355x_head_state * st, const mi355x_tensor * te, const mi355x_tensor * pe);
 /* ggml_flash_attn_ext (ggml/src/ggml.c:5418-5460; CPU ggml-cpu/ops.cpp:8479-8715).
  * q: F32 [D, T, H] (any nb1/nb2), k/v: F16 [D, n_kv, H] views, mask: F16 [n_kv, >=T] or NULL,
  * dst: F32 [D, H, T].  D must be 64 (all Whisper models).  softmax(scale*q.k + mask) . v */

@@ -448,3 +448,32 @@ def test_committed_parity_summary_is_within_the_documented_tolerances():
     assert all(x["greedy"]["n_cpu"] == x["greedy"]["n_gpu"] for x in d["whisper_full_pipeline"].values())
     for v in d["language_detection"].values():
         assert v["id_cpu"] == v["id_gpu"] and v["max_abs_prob_diff"] < 5e-3
+
+
+@pytest.mark.parametrize("arch,qtype,fits", [("base.en", "q5_0", True), ("base.en", "q4_k", True), ("tiny.en", "f16", False)])
+def test_reference_decoder_graphs_fit_the_plane_pipeline_and_the_cross_state_walker(arch, qtype, fits):
+    """tests/native/walk_check.cpp: whisper decodes on the reference CPU backend; every decoder graph it builds is shown to the plugin's
+    planner in its dry mode (no device needed).  Single-token steps of a quantized model must fit the cross-state walker completely
+    (verdict 0 for 2 and for 8 columns), every LayerNorm / attention / fc2 stage must be taken by the plane pipeline and nothing but the
+    step head (2 x get_rows + add + mask cast) may be left over; an F16 model must be refused (it runs through the other paths)."""
+    from synth_model import make_model
+    exe = ROOT / "tests" / "native" / "bin" / "walk_check"
+    plugin = ROOT / "whisper.cpp_amd" / "lib" / "libggml-mi355x.so"
+    if not exe.exists() or not plugin.exists():
+        pytest.skip("native test drivers / plugin not built (needs the reference tree)")
+    m = make_model(arch, qtype)
+    env = dict(os.environ, LD_LIBRARY_PATH=f"{ROOT / 'whisper.cpp_amd' / 'lib'}:{ROOT / 'oracle' / '_ref'}")
+    r = subprocess.run([str(exe), str(m), str(plugin)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rows = json.loads(r.stdout)
+    from whisper_cpp_amd.archs import ARCHS
+    n_layer = ARCHS[arch][8]
+    assert len(rows) == 5
+    for row in rows:
+        single = "1 token" in row["what"]
+        if fits:
+            assert row["ln_stages"] == 3 * n_layer + 1 and row["attn_stages"] == 2 * n_layer and row["mm_stages"] == n_layer and row["other_nodes"] == 4, row
+            assert (row["batch2"], row["batch8"]) == ((0, 0) if single else (-2, -2)), row
+        else:
+            assert row["ln_stages"] == 0 and row["attn_stages"] == 0 and row["mm_stages"] == 0, row
+            assert row["batch2"] != 0 and row["batch8"] != 0, row

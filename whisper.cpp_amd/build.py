@@ -22,7 +22,7 @@ BUILD = ROOT / "build"
 REF = Path(os.environ.get("WHISPER_REF", "/root/reference"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-KERNEL_SRCS = ["ctx.hip", "elementwise.hip", "gemv.hip", "decode.hip", "gemm_mfma.hip", "fattn.hip", "fattn_exact.hip", "mel.hip", "mul_mat.hip"]
+KERNEL_SRCS = ["ctx.hip", "elementwise.hip", "gemv.hip", "decode.hip", "decode_q.hip", "gemm_mfma.hip", "fattn.hip", "fattn_exact.hip", "mel.hip", "mul_mat.hip"]
 BACKEND_SRCS = ["ggml_mi355x.cpp"]
 
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
@@ -49,7 +49,7 @@ def _stale(out: Path, deps):
 def build_kernels(verbose=False):
     LIB.mkdir(exist_ok=True)
     (BUILD / "kernels").mkdir(parents=True, exist_ok=True)
-    hdrs = [CSRC / "kernels" / "common.h", ROOT / "include" / "mi355x_kernels.h"]
+    hdrs = [CSRC / "kernels" / "common.h", CSRC / "kernels" / "decode_common.h", ROOT / "include" / "mi355x_kernels.h"]
     objs, jobs = [], []
     for s in KERNEL_SRCS:
         src = CSRC / "kernels" / s

@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -103,6 +104,20 @@ struct io_timer {
     int slot; std::chrono::steady_clock::time_point t0;
     explicit io_timer(int s) : slot(s), t0(std::chrono::steady_clock::now()) {}
     ~io_timer() { g_io_ns[slot] += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_io_calls[slot]++; }
+};
+
+// GGML_MI355X_TRACE=1: where the host-side time of a step goes INSIDE the plugin (tests/native/step_trace.cpp reads it through
+// ggml_backend_mi355x_trace and sets it beside the reference-side timeline it measures by interposing the scheduler's entry points).
+// Slots (ns, calls): 0 supports_op, 1 supports_buft, 2 graph_compute entry -> first kernel launched, 3 graph_compute entry -> return,
+// 4 graph_compute entry -> synchronize return (one step's whole device phase as the host sees it), 5 get_proc_address
+static const bool g_trace = env_flag("GGML_MI355X_TRACE", false);
+static std::atomic<uint64_t> g_trace_ns[8] = {};
+static std::atomic<uint64_t> g_trace_calls[8] = {};
+static inline uint64_t trace_now() { return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct trace_scope {
+    int slot; uint64_t t0;
+    explicit trace_scope(int s) : slot(s), t0(g_trace ? trace_now() : 0) {}
+    ~trace_scope() { if (g_trace) { g_trace_ns[slot] += trace_now() - t0; g_trace_calls[slot]++; } }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -226,6 +241,11 @@ static bool mi_io_download(int device, void * dst, const void * src, size_t size
     memcpy(dst, stage, size);
     return true;
 }
+
+// order `cs` behind every input upload accepted so far: deferred uploads (a step's graph inputs) leave with one scatter launch at the
+// head of this stream; uploads that another stream flushed, or that went through async copies, are ordered in front of it by their events
+struct mi_io_marks;
+static void mi_io_order_stream(int device, mi_io_marks & mk, hipStream_t cs);
 
 // ---------------------------------------------------------------------------------------------------
 // buffer
@@ -406,6 +426,25 @@ static const ggml_backend_buffer_type_i mi_buft_iface = {
 // ---------------------------------------------------------------------------------------------------
 // backend (stream)
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// decoder steps with 3..8 columns, and cross-state batches: the pre-quantized-activation pipeline (csrc/kernels/decode_q.hip).
+// A stage's activation vector is rounded to the weights' vec_dot_type ONCE (mi355x_act_prepare, or the epilogue of the producing
+// mat-vec) and every mat-vec workgroup only copies the planes, so a step costs the same for 1 and for 8 columns.  The columns are
+// either the T tokens of ONE graph (beam search: src/whisper.cpp:6486-6543 decodes one token per beam per step) or ONE token of
+// each of S graphs — S whisper_states on one device whose single-token steps arrived together (mi_batch_group below): the reference
+// batches sequences inside one graph (whisper_batch, src/whisper.cpp:472-523, mask :2928-2945); independent audio streams have no
+// common graph, so the batch is formed here, behind the backend boundary.  Per column the arithmetic is that of the fused T <= 2
+// kernels, bit for bit (tests/test_gpu_batch.py).
+// ---------------------------------------------------------------------------------------------------
+struct mi_colset {
+    int S = 1;                                       // 1: the T token columns of one graph (strided); > 1: S graphs, one single-token column each
+    int T = 1;                                       // columns in total
+    const ggml_cgraph * g[MI355X_MAX_COLS] = {};
+};
+struct mi_qstate { const void * src = nullptr; int64_t K = 0; int T = 0; int which = 0; };      // planes a producer's epilogue left for its consumer
+
+struct mi_io_marks { uint64_t seen = 0, copy_seen = 0, flush_seen = 0; };     // uploads (mi_io_ctx::seq / copy_seq / flush_count) a stream already waits behind
+
 struct mi_backend_ctx {
     int          device;
     mi355x_ctx * k;
@@ -420,9 +459,17 @@ struct mi_backend_ctx {
     void *       act = nullptr; size_t act_size = 0;
     void *       act_alt = nullptr; size_t act_alt_size = 0;     // second scratch: a GEMM reading `act` writes the next GEMM's prepared activations here
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
-    uint64_t io_seen = 0, io_copy_seen = 0, io_flush_seen = 0;                     // uploads (mi_io_ctx::seq / copy_seq) this stream already waits behind
+    mi_io_marks io;                                             // uploads this stream already waits behind
+    mi_qstate   qs;                                             // planes a producer's epilogue left for the next mat-vec (T >= 3 pipeline)
+    // cross-state batches (mi_batch_group)
+    bool        in_group = false;                               // counted among the device's decoding states (guarded by the group's mutex)
+    bool        own_dirty = false;                              // work was launched on the own stream since the group's stream last waited for it
+    hipEvent_t  own_ev = nullptr;
+    hipEvent_t  batch_wait_sync = nullptr, batch_wait_stream = nullptr;   // completion of the last batch this state was a column of: synchronize() / the own stream still have to wait for it
+    int         no_batch_nodes = 0;                             // graph size (n_nodes) that was found not to fit the batch walker
     uint64_t n_graph_compute = 0;
     double   t_eager_ms = 0;                                    // host time inside graph_compute
+    uint64_t trace_gc_enter = 0;                                // GGML_MI355X_TRACE: entry time of the graph_compute still waiting for its synchronize
     // GPU-side span of every graph_compute (first launch .. last kernel done), from a ring of hipEvent pairs on the stream
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_ev;
     int      span_next = 0, span_pending = 0;
@@ -437,6 +484,19 @@ static void mi_span_drain(mi_backend_ctx * b) {          // all pending pairs mu
         if (hipEventElapsedTime(&ms, b->span_ev[idx].first, b->span_ev[idx].second) == hipSuccess) b->t_gpu_span_ms += ms;
     }
     b->span_pending = 0;
+}
+
+static void mi_io_order_stream(int device, mi_io_marks & mk, hipStream_t cs) {
+    mi_io_ctx & io = g_io[device];
+    const uint64_t seq = io.ok ? io.seq.load() : 0;
+    if (seq == mk.seen) return;
+    std::lock_guard<std::mutex> lk(io.mtx);
+    if (io.flush_count != mk.flush_seen && io.flush_stream && io.flush_stream != cs) (void) hipStreamWaitEvent(cs, io.ev_flush, 0);
+    mi_io_flush_locked(io, cs);
+    mk.flush_seen = io.flush_count;
+    if (io.copy_seq.load() != mk.copy_seen) { (void) hipStreamWaitEvent(cs, io.ev, 0); mk.copy_seen = io.copy_seq.load(); }
+    mk.seen = io.seq.load();
+    io.wake_seq = mk.seen;
 }
 
 static inline double now_ms() {
@@ -492,6 +552,7 @@ struct mm_chain {
     const ggml_tensor * last = nullptr;     // tensor whose memory receives the result
     mi355x_epilogue ep{};
     int end = 0;                            // index of the last fused node
+    int res_node = -1, res_slot = 0;        // the residual operand is src[res_slot] of node res_node (cross-state batches look it up per graph)
 };
 
 static bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c) {
@@ -514,6 +575,7 @@ static bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c
             if (stage <= 0 && is_vec_f32(o, N) && o != cur) { c.ep.bias = (const float *) o->data; stage = 1; took = true; }
             else if (stage <= 3 && o->type == GGML_TYPE_F32 && ggml_are_same_shape(o, cur) && o->nb[0] == 4 && o != cur) {
                 c.ep.residual = (const float *) o->data; c.ep.residual_nb1 = (int64_t) o->nb[1]; stage = 4; took = true;
+                c.res_node = j; c.res_slot = n->src[0] == cur ? 1 : 0;
             }
         } else if (n->op == GGML_OP_SCALE && n->src[0] == cur && stage <= 1 && ggml_get_op_params_f32(n, 1) == 0.0f) {
             c.ep.scale = ggml_get_op_params_f32(n, 0); c.ep.has_scale = 1; stage = 2; took = true;
@@ -962,13 +1024,294 @@ static int run_node(mi_backend_ctx * b, const ggml_tensor * n) {
     }
 }
 
+// ---- the plane pipeline's stages (structures: mi_colset / mi_qstate above) -------------------------------------------
+static const ggml_tensor * cs_tensor(const mi_colset & cs, int c, int node, int slot) {
+    const ggml_tensor * n = (cs.S > 1 ? cs.g[c] : cs.g[0])->nodes[node];
+    return slot < 0 ? n : n->src[slot];
+}
+// address of column c of the tensor at (node, src slot or -1); nb1 < 0: the tensor's own column stride
+static char * cs_col(const mi_colset & cs, int c, int node, int slot, int64_t nb1 = -1) {
+    const ggml_tensor * t = cs_tensor(cs, c, node, slot);
+    if (cs.S > 1) return (char *) t->data;
+    return (char *) t->data + (int64_t) c * (nb1 >= 0 ? nb1 : (int64_t) t->nb[1]);
+}
+static bool q_weight_ok(const ggml_tensor * w, int64_t K) {
+    return is_quant_type(w->type) && ggml_is_contiguous(w) && ggml_n_dims(w) <= 2 && w->ne[0] == K && K % 32 == 0 && (w->type != GGML_TYPE_Q4_K || K % 256 == 0);
+}
+// segment s of a plane mat-vec from mul_mat chain `ch` (graph 0 describes the shapes, every column's graph its own addresses)
+static void q_fill_seg(const mi_colset & cs, const mm_chain & ch, int s, mi355x_gemv_desc & d, mi355x_gemv_cols & cols) {
+    const ggml_tensor * w = ch.mm->src[0];
+    mi355x_gemv_seg & sg = d.seg[s];
+    sg.w = w->data; sg.wtype = (int32_t) w->type; sg.N = (int32_t) w->ne[1]; sg.ep = ch.ep;
+    sg.ep.residual = nullptr; sg.ep.residual_nb1 = 0;                      // per column, below
+    sg.dst = nullptr; sg.dst_type = (int32_t) ch.last->type; sg.dst_nb1 = 0;
+    const int64_t dst_nb1 = ch.last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch.last == ch.mm ? (int64_t) ch.mm->nb[1] : (int64_t) ch.last->nb[1]);
+    for (int c = 0; c < cs.T; c++) {
+        cols.dst[s][c] = cs_col(cs, c, ch.end, -1, dst_nb1);
+        cols.res[s][c] = ch.res_node >= 0 ? (const float *) cs_col(cs, c, ch.res_node, ch.res_slot) : nullptr;
+    }
+}
+
+static bool q_mm(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int i, int & end_out, int & rc_out);
+
+// norm -> mul -> add -> 1..3 mul_mat chains on the result (Q/K/V, cross-Q, fc1, logits).  k == nullptr: pattern check only.
+static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int i, const ln_chain & ln, int & end_out, int & rc_out) {
+    const ggml_cgraph * g = cs.g[0];
+    if (!ln.w || !ln.b) return false;
+    const ggml_tensor * x = ln.norm->src[0], * lnout = ln.last;
+    const int64_t K = x->ne[0];
+    if (ggml_nrows(x) != (cs.S > 1 ? 1 : cs.T) || K > 2048 || K % 32 || x->ne[2] != 1 || x->ne[3] != 1 || x->nb[0] != 4 || (x->nb[1] % 16) || ((uintptr_t) x->data % 16)) return false;
+    if (((uintptr_t) ln.w % 16) || ((uintptr_t) ln.b % 16)) return false;
+    const int nuse = use_count(g, lnout);
+    if (nuse < 1 || nuse > 3 || lnout->view_src || (lnout->flags & GGML_TENSOR_FLAG_OUTPUT)) return false;
+    mm_chain ch[3];
+    int j = next_real(g, ln.end), n = 0;
+    while (n < nuse && j < g->n_nodes) {
+        const ggml_tensor * t = g->nodes[j];
+        if (t->op != GGML_OP_MUL_MAT || t->src[1] != lnout) return false;
+        if (!parse_mm_chain(g, j, true, ch[n])) return false;
+        j = next_real(g, ch[n].end);
+        n++;
+    }
+    if (n != nuse) return false;
+    for (int s = 0; s < n; s++) {
+        const ggml_tensor * w = ch[s].mm->src[0];
+        if (w->type != ch[0].mm->src[0]->type || !q_weight_ok(w, K)) return false;
+        if (t_overlap(ch[s].last, x)) return false;
+        for (int s2 = 0; s2 < s; s2++) if (t_overlap(ch[s].last, ch[s2].last)) return false;
+    }
+    // fc1 + GELU whose only reader is the next mat-vec: the epilogue writes that mat-vec's planes (and skips the F32 store if it can)
+    bool pout = false, only = false;
+    const ggml_tensor * w0 = ch[0].mm->src[0];
+    if (n == 1 && w0->ne[1] % 32 == 0 && w0->ne[1] <= 8192 && w0->type != GGML_TYPE_Q4_K && ch[0].last->type == GGML_TYPE_F32 && ch[0].res_node < 0) {
+        const int jn = next_real(g, ch[0].end);
+        if (jn < g->n_nodes && g->nodes[jn]->op == GGML_OP_MUL_MAT && g->nodes[jn]->src[1] == ch[0].last) {
+            // only if the consumer WILL take the planes (q_mm's own conditions): an elided F32 result exists nowhere else
+            const ggml_tensor * w2 = g->nodes[jn]->src[0];
+            mi_qstate dummy; int e2 = 0, r2 = 0;
+            if (w2->type != GGML_TYPE_Q4_K && q_mm(nullptr, cs, dummy, jn, e2, r2)) { pout = true; only = can_elide(g, ch[0].last, 1); }
+        }
+    }
+    end_out = ch[n - 1].end; rc_out = 0;
+    if (!k) return true;
+    mi355x_act_desc a; memset(&a, 0, sizeof(a));
+    a.K = (int) K; a.T = cs.T; a.wtype = (int32_t) w0->type; a.has_norm = 1; memcpy(&a.eps, ln.norm->op_params, sizeof(float)); a.ln_w = ln.w; a.ln_b = ln.b;
+    for (int c = 0; c < cs.T; c++) a.xcol[c] = (const float *) cs_col(cs, c, i, 0);
+    void * p0 = mi355x_act_scratch(k, 0), * p1 = mi355x_act_scratch(k, 1);
+    if (!p0 || !p1) { rc_out = (int) hipErrorOutOfMemory; return true; }
+    int rc = mi355x_act_prepare(k, &a, p0);
+    if (rc == MI355X_E_UNSUPPORTED) return false;
+    if (rc) { rc_out = rc; return true; }
+    mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
+    mi355x_gemv_cols cols; memset(&cols, 0, sizeof(cols));
+    d.K = (int) K; d.T = cs.T; d.nseg = n; d.x_planes = p0; d.cols = &cols;
+    for (int s = 0; s < n; s++) q_fill_seg(cs, ch[s], s, d, cols);
+    if (pout) { d.planes_out = p1; d.planes_out_only = only ? 1 : 0; }
+    rc = mi355x_gemv_fused(k, &d);
+    if (rc == MI355X_E_UNSUPPORTED && pout) { d.planes_out = nullptr; d.planes_out_only = 0; pout = false; rc = mi355x_gemv_fused(k, &d); }
+    if (rc == MI355X_E_UNSUPPORTED) { rc_out = (int) hipErrorInvalidValue; GGML_LOG_ERROR("ggml-mi355x: plane mat-vec rejected a shape its planes were already prepared for\n"); return true; }
+    rc_out = rc;
+    qs = mi_qstate();
+    if (pout && rc == 0) { qs.src = ch[0].last->data; qs.K = w0->ne[1]; qs.T = cs.T; qs.which = 1; }
+    return true;
+}
+
+// flash_attn_ext -> reshape -> mul_mat chain (output projection)
+static bool q_attn_proj(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int i, int & end_out, int & rc_out) {
+    const ggml_cgraph * g = cs.g[0];
+    const ggml_tensor * fa = g->nodes[i];
+    const ggml_tensor * q = fa->src[0], * kk = fa->src[1], * v = fa->src[2], * m = fa->src[3];
+    const int64_t Tq = q->ne[1], H = q->ne[2];
+    if (Tq != (cs.S > 1 ? 1 : cs.T) || q->ne[3] != 1 || fa->type != GGML_TYPE_F32 || !ggml_is_contiguous(fa) || H*64 > 2048) return false;
+    const int j = next_real(g, i);
+    if (!(j < g->n_nodes && g->nodes[j]->op == GGML_OP_MUL_MAT && can_elide(g, fa, 1))) return false;
+    const ggml_tensor * mm = g->nodes[j], * x = mm->src[1], * w = mm->src[0];
+    const bool x_is_fa = x->view_src == fa && x->view_offs == 0 && x->type == GGML_TYPE_F32 && ggml_is_contiguous(x) &&
+                         x->ne[0] == H*64 && x->ne[1] == Tq && x->ne[2] == 1 && x->ne[3] == 1 && use_count(g, x) == 1 && !(x->flags & GGML_TENSOR_FLAG_OUTPUT);
+    mm_chain ch;
+    if (!x_is_fa || !q_weight_ok(w, H*64) || !parse_mm_chain(g, j, true, ch)) return false;
+    end_out = ch.end; rc_out = 0;
+    if (!k) return true;
+    float scale; memcpy(&scale, fa->op_params, 4);
+    mi355x_attn_partials parts;
+    mi355x_tensor mq = to_mt(q), mk = to_mt(kk), mv = to_mt(v), mm_;
+    int rc;
+    if (cs.S > 1) {
+        mi355x_attn_state st[MI355X_MAX_COLS]; memset(st, 0, sizeof(st));
+        for (int c = 0; c < cs.T; c++) {
+            const ggml_tensor * qc = cs_tensor(cs, c, i, 0), * kc = cs_tensor(cs, c, i, 1), * vc = cs_tensor(cs, c, i, 2), * mc = cs_tensor(cs, c, i, 3);
+            if (kc->nb[1] != kk->nb[1] || kc->nb[2] != kk->nb[2] || vc->nb[1] != v->nb[1] || vc->nb[2] != v->nb[2] || qc->nb[2] != q->nb[2] || (mc != nullptr) != (m != nullptr) || vc->ne[1] != kc->ne[1]) {
+                rc_out = (int) hipErrorInvalidValue; GGML_LOG_ERROR("ggml-mi355x: cross-state batch: attention operands of the states are laid out differently\n"); return true;
+            }
+            st[c].q = qc->data; st[c].k = kc->data; st[c].v = vc->data; st[c].mask = mc ? mc->data : nullptr; st[c].n_kv = (int32_t) kc->ne[1];
+        }
+        rc = mi355x_flash_attn_partial_multi(k, cs.T, st, &mq, &mk, &mv, scale, &parts);
+    } else {
+        if (m) mm_ = to_mt(m);
+        rc = mi355x_flash_attn_partial(k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
+    }
+    if (rc == MI355X_E_UNSUPPORTED) return false;
+    if (rc) { rc_out = rc; return true; }
+    void * p0 = mi355x_act_scratch(k, 0);
+    if (!p0) { rc_out = (int) hipErrorOutOfMemory; return true; }
+    mi355x_act_desc a; memset(&a, 0, sizeof(a));
+    a.K = (int) (H*64); a.T = cs.T; a.wtype = (int32_t) w->type;
+    a.attn_part_o = parts.part_o; a.attn_part_ml = parts.part_ml; a.attn_nparts = parts.nparts;
+    rc = mi355x_act_prepare(k, &a, p0);
+    mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
+    mi355x_gemv_cols cols; memset(&cols, 0, sizeof(cols));
+    d.K = (int) (H*64); d.T = cs.T; d.nseg = 1; d.x_planes = p0; d.cols = &cols;
+    q_fill_seg(cs, ch, 0, d, cols);
+    if (rc == 0) rc = mi355x_gemv_fused(k, &d);
+    if (rc == MI355X_E_UNSUPPORTED) { rc = (int) hipErrorInvalidValue; GGML_LOG_ERROR("ggml-mi355x: plane pipeline rejected the attention output projection\n"); }
+    rc_out = rc;
+    qs = mi_qstate();
+    return true;
+}
+
+// mul_mat chain on an F32 activation (fc2; any projection the patterns above did not take)
+static bool q_mm(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int i, int & end_out, int & rc_out) {
+    const ggml_cgraph * g = cs.g[0];
+    mm_chain ch;
+    if (!parse_mm_chain(g, i, true, ch)) return false;
+    const ggml_tensor * w = ch.mm->src[0], * x = ch.mm->src[1];
+    const int64_t K = w->ne[0];
+    if (!q_weight_ok(w, K) || K > 8192 || x->type != GGML_TYPE_F32 || x->ne[1] != (cs.S > 1 ? 1 : cs.T) || x->ne[2] != 1 || x->ne[3] != 1 || x->nb[0] != 4 ||
+        (x->nb[1] % 16) || ((uintptr_t) x->data % 16) || ch.mm->type != GGML_TYPE_F32) return false;
+    end_out = ch.end; rc_out = 0;
+    if (!k) return true;
+    void * planes;
+    int rc = 0;
+    if (qs.src == x->data && qs.K == K && qs.T == cs.T) planes = mi355x_act_scratch(k, qs.which);
+    else {
+        planes = mi355x_act_scratch(k, 0);
+        mi355x_act_desc a; memset(&a, 0, sizeof(a));
+        a.K = (int) K; a.T = cs.T; a.wtype = (int32_t) w->type;
+        for (int c = 0; c < cs.T; c++) a.xcol[c] = (const float *) cs_col(cs, c, i, 1);
+        rc = planes ? mi355x_act_prepare(k, &a, planes) : (int) hipErrorOutOfMemory;
+        if (rc == MI355X_E_UNSUPPORTED) return false;
+    }
+    qs = mi_qstate();
+    if (rc) { rc_out = rc; return true; }
+    mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
+    mi355x_gemv_cols cols; memset(&cols, 0, sizeof(cols));
+    d.K = (int) K; d.T = cs.T; d.nseg = 1; d.x_planes = planes; d.cols = &cols;
+    q_fill_seg(cs, ch, 0, d, cols);
+    rc = mi355x_gemv_fused(k, &d);
+    if (rc == MI355X_E_UNSUPPORTED) { rc = (int) hipErrorInvalidValue; GGML_LOG_ERROR("ggml-mi355x: plane mat-vec rejected a shape its planes were already prepared for\n"); }
+    rc_out = rc;
+    return true;
+}
+
+// One launch chain for S single-token decoder graphs (the columns).  k == nullptr: does every node fit?  (nothing is launched)
+static int mi_walk_batch(mi355x_ctx * k, const mi_colset & cs) {
+    const ggml_cgraph * g = cs.g[0];
+    mi_qstate qs;
+    for (int i = 0; i < g->n_nodes; i++) {
+        const ggml_tensor * n = g->nodes[i];
+        if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
+        int end = i, rc = 0;
+        bool took = false;
+        if (n->op == GGML_OP_GET_ROWS) {
+            // token embedding + positional embedding of every state in one launch
+            const int j1 = next_real(g, i), j2 = j1 < g->n_nodes ? next_real(g, j1) : g->n_nodes;
+            if (j2 < g->n_nodes && g->nodes[j1]->op == GGML_OP_GET_ROWS && g->nodes[j2]->op == GGML_OP_ADD) {
+                const ggml_tensor * ga = n, * gb = g->nodes[j1], * ad = g->nodes[j2];
+                const bool pair = (ad->src[0] == ga && ad->src[1] == gb) || (ad->src[0] == gb && ad->src[1] == ga);
+                if (pair && can_elide(g, ga, 1) && can_elide(g, gb, 1) && ggml_are_same_shape(ga, gb) && ggml_are_same_shape(ad, ga) && ad->type == GGML_TYPE_F32 &&
+                    ggml_is_contiguous(ad) && gb->src[0]->type == GGML_TYPE_F32 && ga->src[1]->type == GGML_TYPE_I32 && gb->src[1]->type == GGML_TYPE_I32 &&
+                    ggml_nelements(ga->src[1]) == 1 && ggml_nelements(gb->src[1]) == 1 && whole_quant_ok(ga->src[0])) {
+                    took = true; end = j2;
+                    if (k) {
+                        mi355x_head_state st[MI355X_MAX_COLS]; memset(st, 0, sizeof(st));
+                        for (int c = 0; c < cs.T; c++) {
+                            st[c].tok = (const int32_t *) cs_tensor(cs, c, i, 1)->data; st[c].pos = (const int32_t *) cs_tensor(cs, c, j1, 1)->data;
+                            st[c].dst = (float *) cs_tensor(cs, c, j2, -1)->data;
+                        }
+                        mi355x_tensor te = to_mt(ga->src[0]), pe = to_mt(gb->src[0]);
+                        rc = mi355x_decode_head_multi(k, cs.T, st, &te, &pe);
+                    }
+                }
+            }
+        } else if (n->op == GGML_OP_CPY || n->op == GGML_OP_CONT || n->op == GGML_OP_DUP) {
+            // the mask row's F32 -> F16 cast (src/whisper.cpp:2520), every state's in one launch
+            const ggml_tensor * s0 = n->src[0];
+            if (s0->type == GGML_TYPE_F32 && n->type == GGML_TYPE_F16 && ggml_is_contiguous(s0) && ggml_is_contiguous(n) && ggml_nelements(s0) == ggml_nelements(n) &&
+                ggml_nelements(n) < (1 << 20)) {
+                took = true;
+                if (k) {
+                    mi355x_head_state st[MI355X_MAX_COLS]; memset(st, 0, sizeof(st));
+                    for (int c = 0; c < cs.T; c++) {
+                        const ggml_tensor * nc = cs_tensor(cs, c, i, -1);
+                        st[c].mask_f32 = (const float *) nc->src[0]->data; st[c].mask_f16 = nc->data; st[c].n_mask = (int32_t) ggml_nelements(nc);
+                    }
+                    rc = mi355x_decode_head_multi(k, cs.T, st, nullptr, nullptr);          // no state embeds: the tables are not needed
+                }
+            }
+        } else if (n->op == GGML_OP_NORM) {
+            ln_chain c;
+            parse_ln_chain(g, i, true, c);
+            took = q_ln_gemv(k, cs, qs, i, c, end, rc);
+        } else if (n->op == GGML_OP_FLASH_ATTN_EXT) {
+            took = q_attn_proj(k, cs, qs, i, end, rc);
+        } else if (n->op == GGML_OP_MUL_MAT) {
+            took = q_mm(k, cs, qs, i, end, rc);
+        }
+        if (!took) return MI355X_E_UNSUPPORTED;
+        if (rc != 0) { GGML_LOG_ERROR("ggml-mi355x: cross-state batch: op %s (%s) failed: rc=%d %s\n", ggml_op_name(n->op), n->name, rc, mi355x_last_error()); return rc; }
+        i = end;
+    }
+    return k ? mi355x_flush(k) : 0;
+}
+
+// may graph `b` run as another column next to graph `a`?  Same node sequence, shapes (up to the key counts) and weights.
+static bool mi_graphs_congruent(const ggml_cgraph * a, const ggml_cgraph * b) {
+    if (a->n_nodes != b->n_nodes) return false;
+    for (int i = 0; i < a->n_nodes; i++) {
+        const ggml_tensor * x = a->nodes[i], * y = b->nodes[i];
+        if (x->op != y->op || x->type != y->type || x->ne[0] != y->ne[0] || (x->flags & GGML_TENSOR_FLAG_COMPUTE) != (y->flags & GGML_TENSOR_FLAG_COMPUTE)) return false;
+        for (int s = 0; s < 4; s++) {
+            const ggml_tensor * xs = x->src[s], * ys = y->src[s];
+            if ((xs == nullptr) != (ys == nullptr)) return false;
+            if (!xs) continue;
+            if (xs->type != ys->type || xs->ne[0] != ys->ne[0]) return false;
+            ggml_backend_buffer_t xb = xs->view_src ? xs->view_src->buffer : xs->buffer;
+            if (xb && xb->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS && xs->data != ys->data) return false;     // the same weights
+        }
+    }
+    return true;
+}
+
 // walk nodes [i0, i_stop) and emit kernels on the backend's stream
 static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop) {
     int i = i0;
+    const uint64_t trace_n0 = g_trace ? mi355x_eager_count(b->k) : 0;
+    bool trace_first = g_trace && b->trace_gc_enter != 0;
     for (; i < i_stop; i++) {
+        if (trace_first && mi355x_eager_count(b->k) != trace_n0) { g_trace_ns[2] += trace_now() - b->trace_gc_enter; g_trace_calls[2]++; trace_first = false; }
         const ggml_tensor * n = g->nodes[i];
         if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
         int rc = MI355X_E_UNSUPPORTED;
+        // decoder steps with planes_min_t .. 8 columns (beam search): the pre-quantized-activation pipeline (stages above); whatever it
+        // does not take falls through to the fused / generic paths below
+        static const int planes_min_t = getenv("GGML_MI355X_PLANES_MIN_T") ? atoi(getenv("GGML_MI355X_PLANES_MIN_T")) : 3;
+        if (b->fuse && !b->exact && (n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_NORM || n->op == GGML_OP_FLASH_ATTN_EXT)) {
+            const int64_t Tn = n->op == GGML_OP_FLASH_ATTN_EXT ? n->src[0]->ne[1] : (n->op == GGML_OP_MUL_MAT ? n->src[1]->ne[1] : ggml_nrows(n->src[0]));
+            if (Tn >= planes_min_t && Tn <= MI355X_MAX_COLS) {
+                mi_colset cs; cs.S = 1; cs.T = (int) Tn; cs.g[0] = g;
+                int end = i, rc2 = 0; bool took = false;
+                if (n->op == GGML_OP_NORM) { ln_chain c; parse_ln_chain(g, i, true, c); took = q_ln_gemv(b->k, cs, b->qs, i, c, end, rc2); }
+                else if (n->op == GGML_OP_FLASH_ATTN_EXT) took = q_attn_proj(b->k, cs, b->qs, i, end, rc2);
+                else took = q_mm(b->k, cs, b->qs, i, end, rc2);
+                if (took) {
+                    if (rc2 != 0) { GGML_LOG_ERROR("ggml-mi355x: op %s (%s) failed in the plane pipeline: rc=%d %s\n", ggml_op_name(n->op), n->name, rc2, mi355x_last_error()); return rc2; }
+                    b->act_src = nullptr;
+                    i = end;
+                    continue;
+                }
+            }
+        }
+        b->qs = mi_qstate();
         if (n->op == GGML_OP_MUL_MAT) {
             mm_chain c;
             parse_mm_chain(g, i, b->fuse, c);
@@ -1045,16 +1388,21 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
     return mi355x_flush(b->k);            // launches the kernel library held back for grouping (gemm_mfma.hip) leave with their range
 }
 static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
-    b->act_src = nullptr;
+    b->act_src = nullptr; b->qs = mi_qstate();
     return mi_emit_range(b, g, 0, g->n_nodes);
 }
 
 static const char * mi_backend_get_name(ggml_backend_t backend) { return ((mi_backend_ctx *) backend->context)->name.c_str(); }
 
+static void mi_batch_leave(mi_backend_ctx * b);
+
 static void mi_backend_free(ggml_backend_t backend) {
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     (void) hipSetDevice(b->device);
+    mi_batch_leave(b);
     mi355x_ctx_synchronize(b->k);
+    if (b->batch_wait_sync) (void) hipEventSynchronize(b->batch_wait_sync);
+    if (b->own_ev) (void) hipEventDestroy(b->own_ev);
     if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 "\n", b->name.c_str(), b->n_graph_compute);
     if (b->span_pending) mi_span_drain(b);
     for (auto & e : b->span_ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
@@ -1077,29 +1425,17 @@ static void mi_backend_synchronize(ggml_backend_t backend) {
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     (void) hipSetDevice(b->device);
     mi355x_ctx_synchronize(b->k);
+    if (b->batch_wait_sync) { (void) hipEventSynchronize(b->batch_wait_sync); b->batch_wait_sync = nullptr; }      // the launch chain this state was a column of
+    if (g_trace && b->trace_gc_enter) { g_trace_ns[4] += trace_now() - b->trace_gc_enter; g_trace_calls[4]++; b->trace_gc_enter = 0; }
     if (b->span_pending) mi_span_drain(b);
 }
 
-static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
-    mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
-    if (hipSetDevice(b->device) != hipSuccess) return GGML_STATUS_FAILED;
-    b->n_graph_compute++;
-    {   // order this stream behind every input upload enqueued so far
-        mi_io_ctx & io = g_io[b->device];
-        const uint64_t seq = io.ok ? io.seq.load() : 0;
-        if (seq != b->io_seen) {
-            std::lock_guard<std::mutex> lk(io.mtx);
-            hipStream_t cs = (hipStream_t) mi355x_ctx_stream(b->k);
-            // deferred uploads (this step's graph inputs) leave with one scatter launch at the head of this stream; uploads that
-            // another stream flushed, or that went through async copies, are ordered in front of us by their events
-            if (io.flush_count != b->io_flush_seen && io.flush_stream && io.flush_stream != cs) (void) hipStreamWaitEvent(cs, io.ev_flush, 0);
-            mi_io_flush_locked(io, cs);
-            b->io_flush_seen = io.flush_count;
-            if (io.copy_seq.load() != b->io_copy_seen) { (void) hipStreamWaitEvent(cs, io.ev, 0); b->io_copy_seen = io.copy_seq.load(); }
-            b->io_seen = io.seq.load();
-            io.wake_seq = b->io_seen;
-        }
-    }
+// one graph on the backend's own stream
+static ggml_status mi_compute_own(mi_backend_ctx * b, ggml_cgraph * cgraph) {
+    hipStream_t cs = (hipStream_t) mi355x_ctx_stream(b->k);
+    if (b->batch_wait_stream) { (void) hipStreamWaitEvent(cs, b->batch_wait_stream, 0); b->batch_wait_stream = nullptr; }    // a batch wrote this state's KV / activations
+    b->own_dirty = true;
+    mi_io_order_stream(b->device, b->io, cs);
     // GPU span bookkeeping (two event records per call)
     static const bool span_on = env_flag("GGML_MI355X_SPAN", true);
     int span_idx = -1;
@@ -1110,13 +1446,179 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
         }
         if (b->span_pending >= (int) b->span_ev.size()) { mi355x_ctx_synchronize(b->k); mi_span_drain(b); }
         span_idx = b->span_next; b->span_next = (b->span_next + 1) % (int) b->span_ev.size(); b->span_pending++;
-        (void) hipEventRecord(b->span_ev[span_idx].first, (hipStream_t) mi355x_ctx_stream(b->k));
+        (void) hipEventRecord(b->span_ev[span_idx].first, cs);
     }
     struct span_end { mi_backend_ctx * b; int idx; ~span_end() { if (idx >= 0) (void) hipEventRecord(b->span_ev[idx].second, (hipStream_t) mi355x_ctx_stream(b->k)); } } span_guard{ b, span_idx };
     const double t0 = now_ms();
     const int rc = mi_emit_graph(b, cgraph);
     b->t_eager_ms += now_ms() - t0;
     return rc == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cross-state batches: the rendezvous.  Every whisper_state has its own ggml_backend_t (own host thread, own HIP stream: src/
+// whisper.cpp:7848-7869).  When batching is on (GGML_MI355X_BATCH=1 / ggml_backend_mi355x_set_batching), a backend whose graph is a
+// single-token decoder step does not launch it: it joins its device's group, and once every backend that is currently decoding has
+// arrived (or the window closes) ONE of the waiting threads launches the merged chain on the group's stream (mi_walk_batch) — up to
+// MI355X_MAX_COLS states as the columns of one pass over the weights.  A state that stops decoding (its next graph is an encoder,
+// a prompt, a beam-search step) leaves the group at once, so nobody waits for it; one that simply stays away is dropped after the
+// window.  Stream order: the group's stream waits for each member's earlier work on its own stream (encoder -> cross-KV), each
+// member's stream and synchronize() wait for the batch's completion event.  One state alone runs exactly the non-batched path.
+// ---------------------------------------------------------------------------------------------------
+struct mi_batch_member { mi_backend_ctx * b; ggml_cgraph * g; int state; ggml_status status; };       // state: 0 waiting, 1 being launched, 2 done
+struct mi_batch_group {
+    std::mutex m; std::condition_variable cv;
+    std::vector<mi_batch_member *> waiting;
+    std::vector<mi_backend_ctx *>  members;          // backends currently counted in n_active
+    bool        leader_busy = false;
+    double      last_finish_ms = 0;
+    mi355x_ctx * k = nullptr;                        // the batch's own stream, scratch arena and activation planes
+    mi_io_marks io;
+    hipEvent_t  ev_ring[16] = {}; int ev_next = 0;
+    uint64_t    sig_nodes = 0; const void * sig_w = nullptr;   // graph shape the dry walk + congruence check last accepted
+    uint64_t    n_batches = 0, n_columns = 0, n_solo = 0, n_fallback = 0, n_timeouts = 0;
+};
+static mi_batch_group     g_batch[MI_MAX_DEVICES];
+static std::atomic<int>   g_batching{-1};            // -1: not decided yet (environment), 0 off, 1 on
+static bool mi_batching_on() {
+    int v = g_batching.load();
+    if (v < 0) { v = env_flag("GGML_MI355X_BATCH", false) ? 1 : 0; g_batching.store(v); }
+    return v != 0;
+}
+
+// a single-token decoder step?  (cheap signature; whether every node fits is decided once per graph shape by the dry walk)
+static bool mi_is_step_graph(const ggml_cgraph * g) {
+    if (g->n_nodes < 32) return false;
+    const ggml_tensor * last = g->nodes[g->n_nodes - 1];
+    if (last->op != GGML_OP_MUL_MAT || last->ne[1] != 1 || last->ne[2] != 1 || last->ne[3] != 1) return false;
+    for (int i = 0; i < g->n_nodes && i < 16; i++) {
+        const ggml_tensor * n = g->nodes[i];
+        if (op_is_empty(n)) continue;
+        return n->op == GGML_OP_GET_ROWS && ggml_nelements(n->src[1]) == 1;
+    }
+    return false;
+}
+
+static void mi_batch_leave(mi_backend_ctx * b) {
+    if (!b->in_group) return;
+    mi_batch_group & grp = g_batch[b->device];
+    std::lock_guard<std::mutex> lk(grp.m);
+    if (!b->in_group) return;
+    b->in_group = false;
+    for (size_t i = 0; i < grp.members.size(); i++) if (grp.members[i] == b) { grp.members.erase(grp.members.begin() + i); break; }
+    grp.cv.notify_all();
+}
+
+static ggml_status mi_compute_own(mi_backend_ctx * b, ggml_cgraph * cgraph);
+
+// the merged launch chain for `n` members (group lock NOT held).  Falls back to every member alone when the graphs do not fit.
+static void mi_compute_batch(mi_batch_group & grp, mi_batch_member ** mem, int n) {
+    mi_backend_ctx * b0 = mem[0]->b;
+    (void) hipSetDevice(b0->device);
+    bool ok = true;
+    if (!grp.k) {
+        grp.k = mi355x_ctx_create(b0->device);
+        for (auto & e : grp.ev_ring) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+        if (!grp.k) ok = false;
+    }
+    mi_colset cs; cs.S = n; cs.T = n;
+    for (int c = 0; c < n; c++) cs.g[c] = mem[c]->g;
+    if (ok) {
+        const ggml_cgraph * g0 = cs.g[0];
+        const uint64_t sn = (uint64_t) g0->n_nodes; const void * sw = g0->nodes[g0->n_nodes - 1]->src[0]->data;
+        bool same = true;
+        for (int c = 1; c < n; c++) same = same && cs.g[c]->n_nodes == g0->n_nodes && cs.g[c]->nodes[g0->n_nodes - 1]->src[0]->data == sw;
+        if (!same) ok = false;
+        else if (grp.sig_nodes != sn || grp.sig_w != sw) {
+            for (int c = 1; c < n && ok; c++) ok = mi_graphs_congruent(g0, cs.g[c]);
+            if (ok) ok = mi_walk_batch(nullptr, cs) == 0;
+            if (ok) { grp.sig_nodes = sn; grp.sig_w = sw; }
+            else for (int c = 0; c < n; c++) mem[c]->b->no_batch_nodes = g0->n_nodes;       // this graph shape never batches: stop joining with it
+        }
+    }
+    if (!ok) {
+        grp.n_fallback++;
+        for (int c = 0; c < n; c++) mem[c]->status = mi_compute_own(mem[c]->b, mem[c]->g);
+        return;
+    }
+    hipStream_t bs = (hipStream_t) mi355x_ctx_stream(grp.k);
+    for (int c = 0; c < n; c++) {
+        mi_backend_ctx * b = mem[c]->b;
+        if (b->own_dirty) {                                   // the member's earlier work on its own stream (encoder -> cross-KV, a solo step's KV writes)
+            (void) mi355x_flush(b->k);
+            if (!b->own_ev) (void) hipEventCreateWithFlags(&b->own_ev, hipEventDisableTiming);
+            (void) hipEventRecord(b->own_ev, (hipStream_t) mi355x_ctx_stream(b->k));
+            (void) hipStreamWaitEvent(bs, b->own_ev, 0);
+            b->own_dirty = false;
+        }
+    }
+    mi_io_order_stream(b0->device, grp.io, bs);               // every member's graph inputs leave with one scatter launch at the head of the chain
+    const int rc = mi_walk_batch(grp.k, cs);
+    hipEvent_t ev = grp.ev_ring[grp.ev_next]; grp.ev_next = (grp.ev_next + 1) % 16;
+    (void) hipEventRecord(ev, bs);
+    for (int c = 0; c < n; c++) {
+        mem[c]->b->batch_wait_sync = ev; mem[c]->b->batch_wait_stream = ev;
+        mem[c]->status = rc == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+    }
+    grp.n_batches++; grp.n_columns += (uint64_t) n;
+}
+
+static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
+    static const double window_ms = getenv("GGML_MI355X_BATCH_WINDOW_US") ? atof(getenv("GGML_MI355X_BATCH_WINDOW_US")) * 1e-3 : 3.0;
+    mi_batch_group & grp = g_batch[b->device];
+    mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
+    std::unique_lock<std::mutex> lk(grp.m);
+    if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
+    grp.waiting.push_back(&me);
+    const double arrived = now_ms();
+    grp.cv.notify_all();                                      // a waiter may now have its full set
+    for (;;) {
+        if (me.state == 2) return me.status;
+        bool lead = false;
+        if (me.state == 0 && !grp.leader_busy) {
+            const int want = std::min<int>((int) grp.members.size(), MI355X_MAX_COLS);
+            if ((int) grp.waiting.size() >= want) lead = true;
+            else if (grp.waiting.front() == &me && now_ms() > std::max(arrived, grp.last_finish_ms) + window_ms) {
+                // the window closed: whoever is counted but neither here nor on its way through a running batch is dropped (it rejoins
+                // with its next step)
+                for (size_t i = 0; i < grp.members.size(); ) {
+                    bool here = false;
+                    for (auto * w : grp.waiting) here = here || w->b == grp.members[i];
+                    if (!here) { grp.members[i]->in_group = false; grp.members.erase(grp.members.begin() + i); } else i++;
+                }
+                grp.n_timeouts++;
+                lead = true;
+            }
+        }
+        if (!lead) {
+            grp.cv.wait_for(lk, std::chrono::microseconds(200));
+            continue;
+        }
+        mi_batch_member * mem[MI355X_MAX_COLS];
+        int n = 0;
+        while (n < MI355X_MAX_COLS && !grp.waiting.empty()) { mem[n] = grp.waiting.front(); mem[n]->state = 1; grp.waiting.erase(grp.waiting.begin()); n++; }
+        grp.leader_busy = true;
+        lk.unlock();
+        if (n == 1) { mem[0]->status = mi_compute_own(mem[0]->b, mem[0]->g); }
+        else        mi_compute_batch(grp, mem, n);
+        lk.lock();
+        if (n == 1) grp.n_solo++;
+        for (int c = 0; c < n; c++) mem[c]->state = 2;
+        grp.leader_busy = false;
+        grp.last_finish_ms = now_ms();
+        grp.cv.notify_all();
+    }
+}
+
+static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgraph) {
+    mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
+    if (hipSetDevice(b->device) != hipSuccess) return GGML_STATUS_FAILED;
+    b->n_graph_compute++;
+    trace_scope trace_gc(3);
+    if (g_trace) b->trace_gc_enter = trace_gc.t0;
+    if (mi_batching_on() && b->fuse && !b->exact && !b->prof && cgraph->n_nodes != b->no_batch_nodes && mi_is_step_graph(cgraph)) return mi_batch_join(b, cgraph);
+    mi_batch_leave(b);                          // anything else (encoder, prompt, beam step): this state is not decoding token by token right now
+    return mi_compute_own(b, cgraph);
 }
 
 static const ggml_backend_i mi_backend_iface = {
@@ -1176,6 +1678,7 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
 }
 static ggml_backend_buffer_type_t mi_dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi_device_ctx *) dev->context)->buft; }
 static bool mi_dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
+    trace_scope tr(0);
     const bool ok = mi_supports_op_impl(op);
     if (!ok) {
         MI_LOG("unsupported op %s (%s) type=%s", ggml_op_name(op->op), op->name, ggml_type_name(op->type));
@@ -1187,6 +1690,7 @@ static bool mi_dev_supports_op(ggml_backend_dev_t, const ggml_tensor * op) {
     return ok;
 }
 static bool mi_dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    trace_scope tr(1);
     return buft->iface.get_name == mi_buft_get_name && buft->context == dev->context;
 }
 
@@ -1311,6 +1815,56 @@ void ggml_backend_mi355x_host_times(double * out) {
     for (int i = 0; i < 4; i++) { out[4 + i] = g_io_ns[i].load() * 1e-6; out[8 + i] = (double) g_io_calls[i].load(); }
     out[12] = g_total_gpu_span_ms;
     for (auto * b : g_backends) out[12] += b->t_gpu_span_ms;       // completed (drained) graph_computes only
+}
+
+// cross-state batching (mi_batch_group): on = 1 / 0 at run time (the environment's GGML_MI355X_BATCH is only the initial value)
+void ggml_backend_mi355x_set_batching(int on) { g_batching.store(on ? 1 : 0); }
+// out[0..4] of `device`: merged launch chains, columns they carried, steps a state ran alone, groups that fell back to one launch chain
+// per state (graphs did not fit), windows that closed on an absent state
+void ggml_backend_mi355x_batch_stats(int device, uint64_t * out5) {
+    for (int i = 0; i < 5; i++) out5[i] = 0;
+    if (device < 0 || device >= MI_MAX_DEVICES) return;
+    mi_batch_group & grp = g_batch[device];
+    std::lock_guard<std::mutex> lk(grp.m);
+    out5[0] = grp.n_batches; out5[1] = grp.n_columns; out5[2] = grp.n_solo; out5[3] = grp.n_fallback; out5[4] = grp.n_timeouts;
+}
+
+// TEST hook (no device needed: nothing is launched).  S >= 2: would S copies of `cgraph` run as the columns of one launch chain?
+// out[0] = mi_walk_batch's verdict (0 yes).  S == 1: which nodes would the T >= 3 plane pipeline take?  out[1..3] = LayerNorm stages,
+// attention stages, plain mat-vec stages taken; out[4] = compute nodes left to the other paths; out[5] = stages whose epilogue writes planes.
+int ggml_backend_mi355x_debug_walk(void * cgraph, int S, int64_t * out6) {
+    ggml_cgraph * g = (ggml_cgraph *) cgraph;
+    for (int i = 0; i < 6; i++) out6[i] = 0;
+    if (S >= 2) {
+        if (S > MI355X_MAX_COLS) return -1;
+        mi_colset cs; cs.S = S; cs.T = S;
+        for (int c = 0; c < S; c++) cs.g[c] = g;
+        out6[0] = mi_is_step_graph(g) && mi_graphs_congruent(g, g) ? mi_walk_batch(nullptr, cs) : -2;
+        return 0;
+    }
+    mi_qstate qs;
+    for (int i = 0; i < g->n_nodes; i++) {
+        const ggml_tensor * n = g->nodes[i];
+        if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
+        int end = i, rc = 0; bool took = false;
+        if (n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_NORM || n->op == GGML_OP_FLASH_ATTN_EXT) {
+            const int64_t Tn = n->op == GGML_OP_FLASH_ATTN_EXT ? n->src[0]->ne[1] : (n->op == GGML_OP_MUL_MAT ? n->src[1]->ne[1] : ggml_nrows(n->src[0]));
+            if (Tn >= 1 && Tn <= MI355X_MAX_COLS) {
+                mi_colset cs; cs.S = 1; cs.T = (int) Tn; cs.g[0] = g;
+                if (n->op == GGML_OP_NORM) { ln_chain c; parse_ln_chain(g, i, true, c); took = q_ln_gemv(nullptr, cs, qs, i, c, end, rc); if (took) out6[1]++; }
+                else if (n->op == GGML_OP_FLASH_ATTN_EXT) { took = q_attn_proj(nullptr, cs, qs, i, end, rc); if (took) out6[2]++; }
+                else { took = q_mm(nullptr, cs, qs, i, end, rc); if (took) out6[3]++; }
+            }
+        }
+        if (took) i = end; else out6[4]++;
+    }
+    return 0;
+}
+
+// GGML_MI355X_TRACE=1: out[2*i] = nanoseconds, out[2*i + 1] = calls of trace slot i (8 slots, see g_trace_ns); returns 0 when tracing is off
+int ggml_backend_mi355x_trace(uint64_t * out16) {
+    for (int i = 0; i < 8; i++) { out16[2*i] = g_trace_ns[i].load(); out16[2*i + 1] = g_trace_calls[i].load(); }
+    return g_trace ? 1 : 0;
 }
 
 int ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap) {
@@ -1556,6 +2110,7 @@ int ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, 
 } // extern "C"
 
 static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    trace_scope tr(5);
     if (!strcmp(name, "ggml_backend_get_features"))           return (void *) ggml_backend_mi355x_get_features;
     if (!strcmp(name, "ggml_backend_set_n_threads"))          return (void *) ggml_backend_mi355x_set_n_threads;
     if (!strcmp(name, "ggml_backend_mi355x_prof_enable"))     return (void *) ggml_backend_mi355x_prof_enable;
@@ -1574,6 +2129,10 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_prof_report_all")) return (void *) ggml_backend_mi355x_prof_report_all;
     if (!strcmp(name, "ggml_backend_mi355x_stats"))           return (void *) ggml_backend_mi355x_stats;
     if (!strcmp(name, "ggml_backend_mi355x_host_times"))      return (void *) ggml_backend_mi355x_host_times;
+    if (!strcmp(name, "ggml_backend_mi355x_trace"))           return (void *) ggml_backend_mi355x_trace;
+    if (!strcmp(name, "ggml_backend_mi355x_set_batching"))    return (void *) ggml_backend_mi355x_set_batching;
+    if (!strcmp(name, "ggml_backend_mi355x_debug_walk"))      return (void *) ggml_backend_mi355x_debug_walk;
+    if (!strcmp(name, "ggml_backend_mi355x_batch_stats"))     return (void *) ggml_backend_mi355x_batch_stats;
     return nullptr;
 }
 

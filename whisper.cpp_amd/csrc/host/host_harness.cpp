@@ -99,6 +99,8 @@ std::mutex g_last_mtx;
 typedef int  (*bcast_peer_fn)(int, int, double *);
 typedef void (*defer_fn)(int);
 typedef int  (*clone_fn)(int, int, double *);
+typedef void (*set_batching_fn)(int);
+typedef void (*batch_stats_fn)(int, uint64_t *);
 
 } // namespace
 
@@ -159,11 +161,19 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
     whisper_log_set(log_quiet, nullptr);
     ggml_backend_reg_t reg = nullptr;
     if (cfg->use_gpu) {
-        if (cfg->plugin_path) reg = ggml_backend_load(cfg->plugin_path);
-        if (!reg) reg = ggml_backend_reg_by_name("MI355X");
+        reg = ggml_backend_reg_by_name("MI355X");                  // already registered by the host application?  (loading it again would list its devices twice)
+        if (!reg && cfg->plugin_path) reg = ggml_backend_load(cfg->plugin_path);
         if (!reg) return fail(2, "MI355X plugin not loaded (no CPU fallback in GPU mode)");
         if ((int) ggml_backend_reg_dev_count(reg) < cfg->first_device + (cfg->replicas_on_one_device ? 1 : cfg->n_devices)) return fail(2, "fewer MI355X devices than requested");
     }
+    set_batching_fn set_batching = reg ? (set_batching_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_set_batching") : nullptr;
+    batch_stats_fn  batch_stats  = reg ? (batch_stats_fn)  ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_batch_stats")  : nullptr;
+    if (cfg->batching >= 0 && cfg->use_gpu) {
+        if (!set_batching) return fail(2, "plugin has no ggml_backend_mi355x_set_batching");
+        set_batching(cfg->batching);
+    }
+    uint64_t bs0[5] = { 0, 0, 0, 0, 0 };
+    if (batch_stats) batch_stats(cfg->first_device, bs0);
     const int nd = cfg->n_devices, ns = cfg->streams_per_device;
     const bool one_dev = cfg->use_gpu && cfg->replicas_on_one_device;
     auto device_of = [&](int r) { return cfg->first_device + (one_dev ? 0 : r); };
@@ -252,6 +262,7 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
         for (auto & v : last) g_last_logits.insert(g_last_logits.end(), v.begin(), v.end());
     }
     cleanup();
+    if (batch_stats) { uint64_t bs1[5]; batch_stats(cfg->first_device, bs1); for (int i = 0; i < 5; i++) out->batch_stats[i] = bs1[i] - bs0[i]; }
     if (errors.load() != 0) return fail(6, "a whisper_encode / whisper_decode call failed");
     out->wall_s = t1 - t0;
     out->chunks_per_s = (double) total * cfg->steps / out->wall_s;

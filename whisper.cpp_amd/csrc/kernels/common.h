@@ -35,6 +35,7 @@ struct mi355x_ctx {
     size_t      scratch_size = 0;
     size_t      scratch_used = 0;        // bump pointer, reset per op group
     std::vector<void *> scratch_retired; // outgrown arenas that may still back pointers of the current op group
+    void *      qact = nullptr;          // two quantized-activation plane buffers (decode_q.hip, mi355x_act_scratch)
     float *     mel_tab = nullptr;       // sin / cos / Hann tables + the running maximum of mi355x_log_mel (device)
     uint64_t    n_eager = 0;             // launches issued directly on the stream so far (mi355x_eager_count)
     // profiling
@@ -44,6 +45,7 @@ struct mi355x_ctx {
     std::vector<pending>                 ev_pending;
     std::map<std::string, prof_acc>      prof_rows;
     int                                  n_cu = 256;
+    int                                  cu_mask_xcd = -1;       // >= 0: the stream is confined to this XCD (GGML_MI355X_XCD_STREAMS)
     void *                               dbg_stamps = nullptr;   // 16 x u64 (device), GGML_MI355X_KTIME=1 only
     // launches held back so that independent neighbours can go out as ONE grouped launch (gemm_mfma.hip: the Q / K / V projections
     // of an encoder layer, the cross-attention K / V projections of consecutive layers).  Anything else that is emitted, and every
@@ -74,6 +76,8 @@ static inline int emit(mi355x_ctx * ctx, const char * name, void (*kernel)(Args)
 
 // second-generation decoder mat-vec (decode.hip); MI355X_E_UNSUPPORTED => caller uses k_gemv (gemv.hip)
 int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
+// mat-vec over pre-quantized activation planes (decode_q.hip); MI355X_E_UNSUPPORTED => mi355x_gemv8 copies the same planes (k_gemv8)
+int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
 
 // ---------------------------------------------------------------------------------------------
 // tensor helpers (host)

@@ -4,6 +4,7 @@
 #include <cxxabi.h>
 #include <chrono>
 #include <mutex>
+#include <atomic>
 
 #include <math.h>
 #include <stdarg.h>
@@ -59,7 +60,22 @@ extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
     ctx->device = device;
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) ctx->n_cu = p.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    // GGML_MI355X_XCD_STREAMS=1 (experiment): the n-th context of a device gets a stream whose CU mask is ONE XCD
+    // (n mod 8), so that up to eight concurrent decode streams each own an XCD (own L2, no interleaving of their dependent launch
+    // chains on shared CUs).  Mask layout: GGML_MI355X_XCD_MASK_LAYOUT=0 bit (8k + x) = k-th CU of XCD x (default, what the
+    // driver's symmetric mapping implies), 1 = bits [32x, 32x + 32); scripts/cumask_probe.hip measures which one is right.
+    static const int xcd_streams = getenv("GGML_MI355X_XCD_STREAMS") ? atoi(getenv("GGML_MI355X_XCD_STREAMS")) : 0;
+    bool have_stream = false;
+    if (xcd_streams > 0) {
+        static std::atomic<int> next_xcd[64];
+        static const int layout = getenv("GGML_MI355X_XCD_MASK_LAYOUT") ? atoi(getenv("GGML_MI355X_XCD_MASK_LAYOUT")) : 0;
+        const int x = next_xcd[device & 63].fetch_add(1) % 8, per = ctx->n_cu / 8, nwords = (ctx->n_cu + 31) / 32;
+        uint32_t mask[16] = { 0 };
+        for (int i = 0; i < per && nwords <= 16; i++) { const int bit = layout == 0 ? x + 8 * i : x * per + i; mask[bit >> 5] |= 1u << (bit & 31); }
+        if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t) nwords, mask) == hipSuccess) { have_stream = true; ctx->cu_mask_xcd = x; }
+        else (void) hipGetLastError();
+    }
+    if (!have_stream && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
     std::vector<uint16_t> tab(65536);
     mi355x_gelu_table_host(tab.data());
     if (hipMalloc((void **) &ctx->gelu_tab, 65536*2) != hipSuccess ||
@@ -79,6 +95,7 @@ extern "C" void mi355x_ctx_destroy(mi355x_ctx * ctx) {
     for (void * r : ctx->scratch_retired) (void) hipFree(r);
     if (ctx->gelu_tab) (void) hipFree(ctx->gelu_tab);
     if (ctx->mel_tab)  (void) hipFree(ctx->mel_tab);
+    if (ctx->qact)     (void) hipFree(ctx->qact);
     (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -23,6 +23,7 @@ SYMBOLS = [
     "mi355x_prof_reset", "mi355x_type_is_quantized", "mi355x_type_row_bytes", "mi355x_repack_to_planar",
     "mi355x_repack_from_planar", "mi355x_mul_mat", "mi355x_prep_act", "mi355x_gemm_f16act", "mi355x_dequant_f16", "mi355x_gemv_fused",
     "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_combine", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
+    "mi355x_act_planes_bytes", "mi355x_act_prepare", "mi355x_act_scratch", "mi355x_flash_attn_partial_multi", "mi355x_decode_head_multi",
     "mi355x_get_rows", "mi355x_get_rows_add", "mi355x_im2col_1d", "mi355x_soft_max", "mi355x_rope", "mi355x_concat", "mi355x_memset", "mi355x_checksum", "mi355x_log_mel", "mi355x_log_mel_n_len", "mi355x_debug_read_stamps", "mi355x_wake",
 ]
 
@@ -45,7 +46,31 @@ class GemvDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_nb1", C.c_int64), ("K", C.c_int32), ("T", C.c_int32), ("has_norm", C.c_int32),
                 ("eps", C.c_float), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("nseg", C.c_int32), ("reserved", C.c_int32),
                 ("seg", GemvSeg * 3), ("attn_part_o", C.c_void_p), ("attn_part_ml", C.c_void_p), ("attn_nparts", C.c_int32),
+                ("reserved2", C.c_int32), ("x_planes", C.c_void_p), ("planes_out", C.c_void_p), ("planes_out_only", C.c_int32),
+                ("reserved3", C.c_int32), ("cols", C.c_void_p)]
+
+
+MAX_COLS = 8
+
+
+class GemvCols(C.Structure):          # mi355x_gemv_cols: [segment][column] destinations / residuals
+    _fields_ = [("dst", (C.c_void_p * MAX_COLS) * 3), ("res", (C.c_void_p * MAX_COLS) * 3)]
+
+
+class ActDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_nb1", C.c_int64), ("xcol", C.c_void_p * MAX_COLS), ("K", C.c_int32), ("T", C.c_int32),
+                ("wtype", C.c_int32), ("has_norm", C.c_int32), ("eps", C.c_float), ("reserved", C.c_int32), ("ln_w", C.c_void_p),
+                ("ln_b", C.c_void_p), ("attn_part_o", C.c_void_p), ("attn_part_ml", C.c_void_p), ("attn_nparts", C.c_int32),
                 ("reserved2", C.c_int32)]
+
+
+class AttnState(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("mask", C.c_void_p), ("n_kv", C.c_int32), ("reserved", C.c_int32)]
+
+
+class HeadState(C.Structure):
+    _fields_ = [("tok", C.c_void_p), ("pos", C.c_void_p), ("dst", C.c_void_p), ("mask_f32", C.c_void_p), ("mask_f16", C.c_void_p),
+                ("n_mask", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AttnPartials(C.Structure):
@@ -96,6 +121,13 @@ def lib() -> C.CDLL:
         L.mi355x_flash_attn_ext_exact.argtypes = [C.c_void_p, TP, TP, TP, TP, TP, C.c_float, C.c_int]
         L.mi355x_flash_attn_partial.argtypes = [C.c_void_p, TP, TP, TP, TP, C.c_float, C.POINTER(AttnPartials)]
         L.mi355x_flash_attn_combine.argtypes = [C.c_void_p, C.POINTER(AttnPartials), TP]
+        L.mi355x_act_planes_bytes.restype = C.c_size_t
+        L.mi355x_act_planes_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.mi355x_act_prepare.argtypes = [C.c_void_p, C.POINTER(ActDesc), C.c_void_p]
+        L.mi355x_act_scratch.restype = C.c_void_p
+        L.mi355x_act_scratch.argtypes = [C.c_void_p, C.c_int]
+        L.mi355x_flash_attn_partial_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(AttnState), TP, TP, TP, C.c_float, C.POINTER(AttnPartials)]
+        L.mi355x_decode_head_multi.argtypes = [C.c_void_p, C.c_int, C.POINTER(HeadState), TP, TP]
         L.mi355x_norm.argtypes = [C.c_void_p, TP, TP, C.c_float, C.c_void_p, C.c_void_p]
         L.mi355x_norm_prep.argtypes = [C.c_void_p, TP, TP, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.mi355x_binary.argtypes = [C.c_void_p, C.c_int, TP, TP, TP]
