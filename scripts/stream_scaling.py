@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Concurrent streams on ONE MI355X through the native harness (include/mi355x_host.h): chunks/s for 1, 2, 4, 6, 8, 12 streams.
-   usage: scripts/stream_scaling.py [arch=large-v3] [qtype=q5_0] [streams...]"""
+"""Concurrent streams on ONE MI355X through the native harness (include/mi355x_host.h): chunks/s per stream count, with the plugin's
+cross-state batching off and / or on.
+   usage: scripts/stream_scaling.py [--arch large-v3] [--qtype q5_0] [--streams 1,2,4,8] [--batching 0,1] [--n-decode 256] [--steps 2]
+   env:   GPU_MAX_HW_QUEUES (8), GGML_MI355X_XCD_STREAMS=1 (one XCD-masked HIP stream per state)"""
+import argparse
 import json
 import os
 import sys
@@ -16,13 +19,21 @@ g.load_package()
 from synth_model import make_model  # noqa: E402
 from whisper_cpp_amd import host_api as h  # noqa: E402
 
-arch = sys.argv[1] if len(sys.argv) > 1 else "large-v3"
-qtype = sys.argv[2] if len(sys.argv) > 2 else "q5_0"
-counts = [int(x) for x in sys.argv[3:]] or [1, 2, 4, 6, 8, 12]
-m = make_model(arch, qtype)
+ap = argparse.ArgumentParser()
+ap.add_argument("--arch", default="large-v3")
+ap.add_argument("--qtype", default="q5_0")
+ap.add_argument("--streams", default="1,2,4,6,8,12")
+ap.add_argument("--batching", default="0")
+ap.add_argument("--n-decode", type=int, default=256)
+ap.add_argument("--steps", type=int, default=2)
+a = ap.parse_args()
+m = make_model(a.arch, a.qtype)
 rows = []
-for s in counts:
-    r = h.run(m, use_gpu=True, n_devices=1, streams=s, n_decode=256, steps=2, warmup=1)
-    rows.append({"streams": s, "chunks_per_s": round(r["chunks_per_s"], 3), "ms_per_chunk_per_stream": round(r["ms_per_chunk_per_stream"], 1), "rc": r["rc"], "error": r["error"]})
-    print(json.dumps(rows[-1]), flush=True)
-print(json.dumps({"arch": arch, "qtype": qtype, "hw_queues": os.environ["GPU_MAX_HW_QUEUES"], "rows": rows}))
+for batching in [int(x) for x in a.batching.split(",")]:
+    for s in [int(x) for x in a.streams.split(",")]:
+        r = h.run(m, use_gpu=True, n_devices=1, streams=s, n_decode=a.n_decode, steps=a.steps, warmup=1, batching=batching)
+        rows.append({"batching": batching, "streams": s, "chunks_per_s": round(r["chunks_per_s"], 3), "ms_per_chunk_per_stream": round(r["ms_per_chunk_per_stream"], 1),
+                     "batch_stats": r["batch_stats"], "rc": r["rc"], "error": r["error"]})
+        print(json.dumps(rows[-1]), flush=True)
+print(json.dumps({"arch": a.arch, "qtype": a.qtype, "n_decode": a.n_decode, "hw_queues": os.environ["GPU_MAX_HW_QUEUES"],
+                  "xcd_streams": os.environ.get("GGML_MI355X_XCD_STREAMS", "0"), "xcd_mask_layout": os.environ.get("GGML_MI355X_XCD_MASK_LAYOUT", "0"), "rows": rows}))
