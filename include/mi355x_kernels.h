@@ -74,6 +74,13 @@ MI355X_API int          mi355x_ctx_synchronize(mi355x_ctx * ctx);
  * synchronize, memset and profile call flushes them first, so stream order equals program order.  A host that enqueues
  * its OWN work on mi355x_ctx_stream() calls this before. */
 MI355X_API int          mi355x_flush(mi355x_ctx * ctx);
+/* Next-stage weight prefetch (experiment, single-token decode steps): mi355x_prefetch_hint tells the NEXT decode mat-vec / attention launch
+ * on this context which bytes the launch after it will stream — workgroup j of that launch reads [base + j*wg_bytes, + wg_bytes), j < nwg —
+ * so that its workgroups touch those lines while their own weights are in flight (one-shot: consumed by that launch).
+ * mi355x_last_weights_geometry returns (and clears) the same triple for the mat-vec launched last: a host that replays the same launch
+ * sequence every step (a decoder) learns in step s what to hint in step s + 1.  Returns 1 if a geometry was recorded. */
+MI355X_API void         mi355x_prefetch_hint(mi355x_ctx * ctx, const void * base, int wg_bytes, int nwg);
+MI355X_API int          mi355x_last_weights_geometry(mi355x_ctx * ctx, const void ** base, int * wg_bytes, int * nwg);
 MI355X_API const char * mi355x_last_error(void);
 
 /* n small host-to-device copies in ONE launch on `stream`: src_dev[i] are DEVICE addresses of pinned, device-mapped host memory

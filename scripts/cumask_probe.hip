@@ -34,6 +34,7 @@ static void make_mask(uint32_t * m, int nwords, int layout, int xcd, int ncu) {
 }
 
 int main() {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     const int ncu = p.multiProcessorCount, nwords = (ncu + 31) / 32;
     printf("device: %s, %d CUs\n", p.name, ncu);

@@ -463,10 +463,17 @@ struct mi_backend_ctx {
     mi_qstate   qs;                                             // planes a producer's epilogue left for the next mat-vec (T >= 3 pipeline)
     // cross-state batches (mi_batch_group)
     bool        in_group = false;                               // counted among the device's decoding states (guarded by the group's mutex)
+    bool        in_flight = false;                              // a column of a chain that is being launched right now (group's mutex)
     bool        own_dirty = false;                              // work was launched on the own stream since the group's stream last waited for it
     hipEvent_t  own_ev = nullptr;
     hipEvent_t  batch_wait_sync = nullptr, batch_wait_stream = nullptr;   // completion of the last batch this state was a column of: synchronize() / the own stream still have to wait for it
     int         no_batch_nodes = 0;                             // graph size (n_nodes) that was found not to fit the batch walker
+    // next-stage weight prefetch (GGML_MI355X_PREFETCH=1, single-token steps): what the launch keyed by its weights / K cache may prefetch
+    // for the launch that followed it in the previous step (a decoder replays the same launch sequence every step)
+    struct pf_geom { const void * base; int wg_bytes, nwg; };
+    bool        prefetch = false;
+    std::unordered_map<const void *, pf_geom> pf_next;
+    const void * pf_prev_key = nullptr;
     uint64_t n_graph_compute = 0;
     double   t_eager_ms = 0;                                    // host time inside graph_compute
     uint64_t trace_gc_enter = 0;                                // GGML_MI355X_TRACE: entry time of the graph_compute still waiting for its synchronize
@@ -662,6 +669,9 @@ static bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, 
     return true;
 }
 
+static void pf_before(mi_backend_ctx * b, const void * key);
+static void pf_after(mi_backend_ctx * b, const void * key, bool is_matvec);
+
 static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgraph * g = nullptr) {
     const ggml_tensor * mm = c.mm, * w = mm->src[0], * x = mm->src[1];
     mi355x_tensor mw = to_mt(w), mx = to_mt(x);
@@ -750,7 +760,11 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             if (rc != MI355X_E_UNSUPPORTED) return rc;
         }
     }
-    return mi355x_mul_mat(b->k, &mw, &mx, &md, has_ep ? &c.ep : nullptr);
+    const bool step1 = two_d && T == 1 && is_quant_type(w->type);
+    if (step1) pf_before(b, w->data);
+    const int rc_mm = mi355x_mul_mat(b->k, &mw, &mx, &md, has_ep ? &c.ep : nullptr);
+    if (step1) pf_after(b, w->data, true);
+    return rc_mm;
 }
 
 // ---- norm [-> mul w -> add b] ---------------------------------------------------------------------
@@ -805,6 +819,20 @@ static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c, const ggml_cgrap
 static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const mi355x_attn_partials & parts, int & end_out, int & rc_out);
 static int  run_node(mi_backend_ctx * b, const ggml_tensor * n);
 
+// next-stage weight prefetch around one launch of a single-token step: give it the hint learned for its key in the previous step, and
+// afterwards remember that the PREVIOUS launch may prefetch this one's weights
+static void pf_before(mi_backend_ctx * b, const void * key) {
+    if (!b->prefetch) return;
+    auto it = b->pf_next.find(key);
+    if (it != b->pf_next.end()) mi355x_prefetch_hint(b->k, it->second.base, it->second.wg_bytes, it->second.nwg);
+}
+static void pf_after(mi_backend_ctx * b, const void * key, bool is_matvec) {
+    if (!b->prefetch) return;
+    const void * base = nullptr; int wgb = 0, nwg = 0;
+    if (is_matvec && mi355x_last_weights_geometry(b->k, &base, &wgb, &nwg) && b->pf_prev_key) b->pf_next[b->pf_prev_key] = { base, wgb, nwg };
+    b->pf_prev_key = key;
+}
+
 // decoder step: LayerNorm fused into the mat-vec products that consume it (Q/K/V, cross-Q, fc1)
 static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chain & ln, int & end_out, int & rc_out) {
     if (!ln.w || !ln.b) return false;
@@ -841,7 +869,9 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
     // (A one-launch "LN + Q projection + cross-attention" kernel existed in round 1.  Re-measured with plain launches it LOSES to the
     //  two launches it replaced, 1.478 -> 1.435 ms/token with it switched off (profiles/r02_decode_env_sweep_final.txt): 64 rows of
     //  W_q per workgroup serialise what 256 workgroups otherwise do in parallel, and a dependent boundary costs only ~1.5 us.  Removed.)
+    if (T == 1) pf_before(b, d.seg[0].w);
     const int rc = mi355x_gemv_fused(b->k, &d);
+    if (T == 1) pf_after(b, d.seg[0].w, true);
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = ch[n - 1].end;
     return true;
@@ -861,7 +891,9 @@ static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int
     if (m) mm_ = to_mt(m);
     float scale; memcpy(&scale, fa->op_params, 4);
     mi355x_attn_partials parts;
+    if (T == 1) pf_before(b, k->data);
     int rc = mi355x_flash_attn_partial(b->k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
+    if (T == 1) pf_after(b, k->data, false);
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = i;
     if (rc) return true;
@@ -893,7 +925,9 @@ static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const
             sg.w = w->data; sg.wtype = (int32_t) w->type; sg.N = (int32_t) w->ne[1]; sg.ep = ch.ep;
             sg.dst = ch.last->data; sg.dst_type = (int32_t) ch.last->type;
             sg.dst_nb1 = ch.last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch.last == ch.mm ? (int64_t) ch.mm->nb[1] : (int64_t) ch.last->nb[1]);
+            if (T == 1) pf_before(b, sg.w);
             rc = mi355x_gemv_fused(b->k, &d);
+            if (T == 1) pf_after(b, sg.w, true);
             if (rc != MI355X_E_UNSUPPORTED) { fused = true; rc_out = rc; end_out = ch.end; }
         }
     }
@@ -1269,12 +1303,14 @@ static bool mi_graphs_congruent(const ggml_cgraph * a, const ggml_cgraph * b) {
     if (a->n_nodes != b->n_nodes) return false;
     for (int i = 0; i < a->n_nodes; i++) {
         const ggml_tensor * x = a->nodes[i], * y = b->nodes[i];
-        if (x->op != y->op || x->type != y->type || x->ne[0] != y->ne[0] || (x->flags & GGML_TENSOR_FLAG_COMPUTE) != (y->flags & GGML_TENSOR_FLAG_COMPUTE)) return false;
+        // (extents are not compared: the key count n_kv — mask rows, K / V views — legitimately differs between states that are at
+        //  different positions; with equal ops, types and WEIGHTS every other extent follows from the model)
+        if (x->op != y->op || x->type != y->type || (x->flags & GGML_TENSOR_FLAG_COMPUTE) != (y->flags & GGML_TENSOR_FLAG_COMPUTE)) return false;
         for (int s = 0; s < 4; s++) {
             const ggml_tensor * xs = x->src[s], * ys = y->src[s];
             if ((xs == nullptr) != (ys == nullptr)) return false;
             if (!xs) continue;
-            if (xs->type != ys->type || xs->ne[0] != ys->ne[0]) return false;
+            if (xs->type != ys->type) return false;
             ggml_backend_buffer_t xb = xs->view_src ? xs->view_src->buffer : xs->buffer;
             if (xb && xb->usage == GGML_BACKEND_BUFFER_USAGE_WEIGHTS && xs->data != ys->data) return false;     // the same weights
         }
@@ -1388,7 +1424,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
     return mi355x_flush(b->k);            // launches the kernel library held back for grouping (gemm_mfma.hip) leave with their range
 }
 static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
-    b->act_src = nullptr; b->qs = mi_qstate();
+    b->act_src = nullptr; b->qs = mi_qstate(); b->pf_prev_key = nullptr;
     return mi_emit_range(b, g, 0, g->n_nodes);
 }
 
@@ -1465,17 +1501,19 @@ static ggml_status mi_compute_own(mi_backend_ctx * b, ggml_cgraph * cgraph) {
 // window.  Stream order: the group's stream waits for each member's earlier work on its own stream (encoder -> cross-KV), each
 // member's stream and synchronize() wait for the batch's completion event.  One state alone runs exactly the non-batched path.
 // ---------------------------------------------------------------------------------------------------
+#define MI_BATCH_LANES 4
 struct mi_batch_member { mi_backend_ctx * b; ggml_cgraph * g; int state; ggml_status status; };       // state: 0 waiting, 1 being launched, 2 done
 struct mi_batch_group {
     std::mutex m; std::condition_variable cv;
     std::vector<mi_batch_member *> waiting;
     std::vector<mi_backend_ctx *>  members;          // backends currently counted in n_active
-    bool        leader_busy = false;
     double      last_finish_ms = 0;
-    mi355x_ctx * k = nullptr;                        // the batch's own stream, scratch arena and activation planes
-    mi_io_marks io;
-    hipEvent_t  ev_ring[16] = {}; int ev_next = 0;
-    uint64_t    sig_nodes = 0; const void * sig_w = nullptr;   // graph shape the dry walk + congruence check last accepted
+    // up to MI_BATCH_LANES merged chains in flight at once, each on its own stream (own scratch arena, activation planes, event ring):
+    // with more decoding states than columns per chain (GGML_MI355X_BATCH_COLS) the chains of different state groups overlap on the GPU
+    struct lane { mi355x_ctx * k = nullptr; mi_io_marks io; hipEvent_t ev_ring[16] = {}; int ev_next = 0; bool busy = false; } lanes[MI_BATCH_LANES];
+    int         lane_cols[MI_BATCH_LANES] = {};      // columns of the chain each busy lane is launching
+    std::mutex  sig_m;
+    uint64_t    sig_nodes = 0; const void * sig_w = nullptr;   // graph shape the dry walk + congruence check last accepted (sig_m)
     uint64_t    n_batches = 0, n_columns = 0, n_solo = 0, n_fallback = 0, n_timeouts = 0;
 };
 static mi_batch_group     g_batch[MI_MAX_DEVICES];
@@ -1512,14 +1550,15 @@ static void mi_batch_leave(mi_backend_ctx * b) {
 static ggml_status mi_compute_own(mi_backend_ctx * b, ggml_cgraph * cgraph);
 
 // the merged launch chain for `n` members (group lock NOT held).  Falls back to every member alone when the graphs do not fit.
-static void mi_compute_batch(mi_batch_group & grp, mi_batch_member ** mem, int n) {
+// returns true when the members left as ONE merged chain
+static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi_batch_member ** mem, int n) {
     mi_backend_ctx * b0 = mem[0]->b;
     (void) hipSetDevice(b0->device);
     bool ok = true;
-    if (!grp.k) {
-        grp.k = mi355x_ctx_create(b0->device);
-        for (auto & e : grp.ev_ring) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
-        if (!grp.k) ok = false;
+    if (!ln.k) {
+        ln.k = mi355x_ctx_create(b0->device);
+        for (auto & e : ln.ev_ring) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) ok = false;
+        if (!ln.k) ok = false;
     }
     mi_colset cs; cs.S = n; cs.T = n;
     for (int c = 0; c < n; c++) cs.g[c] = mem[c]->g;
@@ -1528,6 +1567,7 @@ static void mi_compute_batch(mi_batch_group & grp, mi_batch_member ** mem, int n
         const uint64_t sn = (uint64_t) g0->n_nodes; const void * sw = g0->nodes[g0->n_nodes - 1]->src[0]->data;
         bool same = true;
         for (int c = 1; c < n; c++) same = same && cs.g[c]->n_nodes == g0->n_nodes && cs.g[c]->nodes[g0->n_nodes - 1]->src[0]->data == sw;
+        std::lock_guard<std::mutex> sl(grp.sig_m);
         if (!same) ok = false;
         else if (grp.sig_nodes != sn || grp.sig_w != sw) {
             for (int c = 1; c < n && ok; c++) ok = mi_graphs_congruent(g0, cs.g[c]);
@@ -1539,9 +1579,9 @@ static void mi_compute_batch(mi_batch_group & grp, mi_batch_member ** mem, int n
     if (!ok) {
         grp.n_fallback++;
         for (int c = 0; c < n; c++) mem[c]->status = mi_compute_own(mem[c]->b, mem[c]->g);
-        return;
+        return false;
     }
-    hipStream_t bs = (hipStream_t) mi355x_ctx_stream(grp.k);
+    hipStream_t bs = (hipStream_t) mi355x_ctx_stream(ln.k);
     for (int c = 0; c < n; c++) {
         mi_backend_ctx * b = mem[c]->b;
         if (b->own_dirty) {                                   // the member's earlier work on its own stream (encoder -> cross-KV, a solo step's KV writes)
@@ -1552,19 +1592,21 @@ static void mi_compute_batch(mi_batch_group & grp, mi_batch_member ** mem, int n
             b->own_dirty = false;
         }
     }
-    mi_io_order_stream(b0->device, grp.io, bs);               // every member's graph inputs leave with one scatter launch at the head of the chain
-    const int rc = mi_walk_batch(grp.k, cs);
-    hipEvent_t ev = grp.ev_ring[grp.ev_next]; grp.ev_next = (grp.ev_next + 1) % 16;
+    mi_io_order_stream(b0->device, ln.io, bs);                // every member's graph inputs leave with one scatter launch at the head of the chain
+    const int rc = mi_walk_batch(ln.k, cs);
+    hipEvent_t ev = ln.ev_ring[ln.ev_next]; ln.ev_next = (ln.ev_next + 1) % 16;
     (void) hipEventRecord(ev, bs);
     for (int c = 0; c < n; c++) {
         mem[c]->b->batch_wait_sync = ev; mem[c]->b->batch_wait_stream = ev;
         mem[c]->status = rc == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
     }
-    grp.n_batches++; grp.n_columns += (uint64_t) n;
+    return true;
 }
 
 static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     static const double window_ms = getenv("GGML_MI355X_BATCH_WINDOW_US") ? atof(getenv("GGML_MI355X_BATCH_WINDOW_US")) * 1e-3 : 3.0;
+    // columns per merged chain (2..8): with fewer columns than decoding states several chains run side by side (MI_BATCH_LANES streams)
+    static const int max_cols = std::max(2, std::min(MI355X_MAX_COLS, getenv("GGML_MI355X_BATCH_COLS") ? atoi(getenv("GGML_MI355X_BATCH_COLS")) : MI355X_MAX_COLS));
     mi_batch_group & grp = g_batch[b->device];
     mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
     std::unique_lock<std::mutex> lk(grp.m);
@@ -1574,15 +1616,20 @@ static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     grp.cv.notify_all();                                      // a waiter may now have its full set
     for (;;) {
         if (me.state == 2) return me.status;
+        int lane = -1;
+        for (int i = 0; i < MI_BATCH_LANES && lane < 0; i++) if (!grp.lanes[i].busy) lane = i;
         bool lead = false;
-        if (me.state == 0 && !grp.leader_busy) {
-            const int want = std::min<int>((int) grp.members.size(), MI355X_MAX_COLS);
+        if (me.state == 0 && lane >= 0) {
+            // states that are on their way through a running chain come back later: the set to wait for is everybody else
+            int in_flight = 0;
+            for (int i = 0; i < MI_BATCH_LANES; i++) if (grp.lanes[i].busy) in_flight += grp.lane_cols[i];
+            const int want = std::max(1, std::min<int>((int) grp.members.size() - in_flight, max_cols));
             if ((int) grp.waiting.size() >= want) lead = true;
             else if (grp.waiting.front() == &me && now_ms() > std::max(arrived, grp.last_finish_ms) + window_ms) {
-                // the window closed: whoever is counted but neither here nor on its way through a running batch is dropped (it rejoins
-                // with its next step)
+                // the window closed: whoever is counted but neither here nor a column of a running chain is dropped (it rejoins with its
+                // next step)
                 for (size_t i = 0; i < grp.members.size(); ) {
-                    bool here = false;
+                    bool here = grp.members[i]->in_flight;
                     for (auto * w : grp.waiting) here = here || w->b == grp.members[i];
                     if (!here) { grp.members[i]->in_group = false; grp.members.erase(grp.members.begin() + i); } else i++;
                 }
@@ -1596,15 +1643,17 @@ static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
         }
         mi_batch_member * mem[MI355X_MAX_COLS];
         int n = 0;
-        while (n < MI355X_MAX_COLS && !grp.waiting.empty()) { mem[n] = grp.waiting.front(); mem[n]->state = 1; grp.waiting.erase(grp.waiting.begin()); n++; }
-        grp.leader_busy = true;
+        while (n < max_cols && !grp.waiting.empty()) { mem[n] = grp.waiting.front(); mem[n]->state = 1; mem[n]->b->in_flight = true; grp.waiting.erase(grp.waiting.begin()); n++; }
+        mi_batch_group::lane & ln = grp.lanes[lane];
+        ln.busy = true; grp.lane_cols[lane] = n;
         lk.unlock();
+        bool merged = false;
         if (n == 1) { mem[0]->status = mi_compute_own(mem[0]->b, mem[0]->g); }
-        else        mi_compute_batch(grp, mem, n);
+        else        merged = mi_compute_batch(grp, ln, mem, n);
         lk.lock();
-        if (n == 1) grp.n_solo++;
-        for (int c = 0; c < n; c++) mem[c]->state = 2;
-        grp.leader_busy = false;
+        if (n == 1) grp.n_solo++; else if (merged) { grp.n_batches++; grp.n_columns += (uint64_t) n; }
+        for (int c = 0; c < n; c++) { mem[c]->state = 2; mem[c]->b->in_flight = false; }
+        ln.busy = false; grp.lane_cols[lane] = 0;
         grp.last_finish_ms = now_ms();
         grp.cv.notify_all();
     }
@@ -1671,6 +1720,7 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
     // Plain launches on the backend's stream.  (Rounds 1-2 carried a record / patch / replay path over hipGraphs; on ROCm 7.2 it lost to
     //  the plain launch loop on the same kernels — 1.515 vs 1.473 ms/token, profiles/r02_decode_launch_mode_sweep.txt — and was removed.)
     b->fuse = env_flag("GGML_MI355X_FUSE", true); b->prof = env_flag("GGML_MI355X_PROF", false);
+    b->prefetch = env_flag("GGML_MI355X_PREFETCH", false);
     b->exact = env_flag("GGML_MI355X_EXACT", false);
     if (b->prof) mi355x_prof_enable(k, 1);
     { std::lock_guard<std::mutex> lk(g_weights_mtx); g_backends.push_back(b); }
