@@ -326,6 +326,7 @@ __global__ void __launch_bounds__(512) k_gemv_q(const QGArgs a) {
         ((u32x4 *) smem)[idx < n16 ? idx : n16] = cp[i];
     }
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);          // nothing that needs the WEIGHTS may move above the barrier: they are still in flight while the planes settle
     const uint4 * alo = (const uint4 *) smem;
     const uint4 * ahi = alo + (size_t) T*nb;
     const float * dx = Q4K ? (const float *) (smem + (size_t) T*K) : (const float *) (ahi + (size_t) T*nb);
