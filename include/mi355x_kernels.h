@@ -74,13 +74,6 @@ MI355X_API int          mi355x_ctx_synchronize(mi355x_ctx * ctx);
  * synchronize, memset and profile call flushes them first, so stream order equals program order.  A host that enqueues
  * its OWN work on mi355x_ctx_stream() calls this before. */
 MI355X_API int          mi355x_flush(mi355x_ctx * ctx);
-/* Next-stage weight prefetch (experiment, single-token decode steps): mi355x_prefetch_hint tells the NEXT decode mat-vec / attention launch
- * on this context which bytes the launch after it will stream — workgroup j of that launch reads [base + j*wg_bytes, + wg_bytes), j < nwg —
- * so that its workgroups touch those lines while their own weights are in flight (one-shot: consumed by that launch).
- * mi355x_last_weights_geometry returns (and clears) the same triple for the mat-vec launched last: a host that replays the same launch
- * sequence every step (a decoder) learns in step s what to hint in step s + 1.  Returns 1 if a geometry was recorded. */
-MI355X_API void         mi355x_prefetch_hint(mi355x_ctx * ctx, const void * base, int wg_bytes, int nwg);
-MI355X_API int          mi355x_last_weights_geometry(mi355x_ctx * ctx, const void ** base, int * wg_bytes, int * nwg);
 MI355X_API const char * mi355x_last_error(void);
 
 /* n small host-to-device copies in ONE launch on `stream`: src_dev[i] are DEVICE addresses of pinned, device-mapped host memory
@@ -210,7 +203,13 @@ MI355X_API int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
 typedef struct mi355x_gemv_cols {
     void *        dst[3][MI355X_MAX_COLS];     /* [segment][column] */
     const float * res[3][MI355X_MAX_COLS];     /* NULL entries where the segment has no residual */
+    /* optional second F32 copy of segment 0's column t (single-segment launches of the vocabulary projection): e.g. pinned host memory
+     * mapped into the device, so that the caller's read-back of the logits (src/whisper.cpp:2957-2963) needs no device-to-host copy.
+     * Honoured with or without x_planes; dst / res above only with x_planes.  mi355x_last_launch_mirrored tells whether the launch that
+     * mi355x_gemv_fused just issued wrote them (a kernel family without the option ignores them). */
+    void *        mirror[MI355X_MAX_COLS];
 } mi355x_gemv_cols;
+MI355X_API int mi355x_last_launch_mirrored(mi355x_ctx * ctx);
 
 typedef struct mi355x_act_desc {
     const float * x;               /* f32 [K, T], column stride x_nb1 bytes — or NULL with xcol / attention partials */

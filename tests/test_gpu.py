@@ -862,7 +862,9 @@ def test_bench_smoke():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
-    assert d["multi_stream"]["streams"] == 4 and d["multi_stream"]["chunks_per_s"] > 0, d["multi_stream"]
+    ms = d["multi_stream"]
+    assert ms["streams"] == 8 and ms["batched"]["chunks_per_s"] > 0 and ms["unbatched"]["chunks_per_s"] > 0, ms
+    assert ms["batched"]["batch_stats"]["chains"] > 0 and ms["batched"]["mean_columns_per_chain"] > 2 and ms["unbatched"]["batch_stats"]["chains"] == 0, ms
 
 
 def test_bench_under_torchrun_exercises_the_native_weight_distribution():

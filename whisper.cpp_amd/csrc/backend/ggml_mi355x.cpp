@@ -246,6 +246,9 @@ static bool mi_io_download(int device, void * dst, const void * src, size_t size
 // head of this stream; uploads that another stream flushed, or that went through async copies, are ordered in front of it by their events
 struct mi_io_marks;
 static void mi_io_order_stream(int device, mi_io_marks & mk, hipStream_t cs);
+// host-visible mirrors of logits rows (defined with the backend): stale after any other write to the range, readable once valid
+static void mi_mirror_invalidate(int device, const void * p, size_t n);
+static bool mi_mirror_read(int device, const void * src, void * dst, size_t size);
 
 // ---------------------------------------------------------------------------------------------------
 // buffer
@@ -257,6 +260,7 @@ static void mi_buffer_free(ggml_backend_buffer_t buffer) {
         for (size_t i = 0; i < g_buffers.size(); i++) if (g_buffers[i].base == ctx->base) { g_buffers.erase(g_buffers.begin() + i); break; }
     }
     mi_shadows_drop(ctx->device, ctx->base);
+    mi_mirror_invalidate(ctx->device, ctx->base, ctx->size);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     (void) hipDeviceSynchronize();
@@ -282,6 +286,7 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     (void) hipSetDevice(ctx->device);
     MI_REQUIRE_WHOLE_QUANT(tensor, "set_tensor");
+    mi_mirror_invalidate(ctx->device, (const char *) tensor->data + offset, size);
     // (the buffer is not yet marked WEIGHTS while the loader fills it: ggml_backend_buffer_set_usage comes after the loop, W:1956)
     if (t_defer_weights != 0 && buffer->usage != GGML_BACKEND_BUFFER_USAGE_COMPUTE && ggml_nbytes(tensor) >= (1u << 16)) {
         g_deferred_bytes += size;
@@ -315,6 +320,7 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
 static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     io_timer tm(1);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
+    if (!is_quant_type(tensor->type) && mi_mirror_read(ctx->device, (const char *) tensor->data + offset, data, size)) return;     // logits: already in host memory
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     MI_REQUIRE_WHOLE_QUANT(tensor, "get_tensor");
@@ -337,6 +343,7 @@ static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * 
     if (is_quant_type(tensor->type) && !(offset == 0 && size == ggml_nbytes(tensor)))
         GGML_ABORT("ggml-mi355x: partial memset of quantized tensor '%s': planar layout, whole tensors only", tensor->name);
     if (is_quant_type(tensor->type)) mi_shadows_drop(ctx->device, ctx->base);
+    mi_mirror_invalidate(ctx->device, (const char *) tensor->data + offset, size);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     (void) hipMemset((char *) tensor->data + offset, value, size);
@@ -346,6 +353,7 @@ static void mi_buffer_memset_tensor(ggml_backend_buffer_t buffer, ggml_tensor * 
 static void mi_buffer_clear(ggml_backend_buffer_t buffer, uint8_t value) {
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     mi_shadows_drop(ctx->device, ctx->base);
+    mi_mirror_invalidate(ctx->device, ctx->base, ctx->size);
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     (void) hipMemset(ctx->base, value, ctx->size);
@@ -362,6 +370,7 @@ static bool mi_buffer_cpy_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
     MI_REQUIRE_WHOLE_QUANT(src, "cpy_tensor (source)");
     MI_REQUIRE_WHOLE_QUANT(dst, "cpy_tensor (destination)");
     if (is_quant_type(dst->type)) mi_shadows_drop(ctx->device, ctx->base);
+    mi_mirror_invalidate(ctx->device, dst->data, ggml_nbytes(dst));
     // uploads still in flight for the SOURCE (it may live on another of our devices) must land before the raw copy reads it
     const int sdev = ((mi_buffer_ctx *) sbuf->context)->device;
     if (sdev != ctx->device) { (void) hipSetDevice(sdev); mi_io_drain(sdev); }
@@ -436,10 +445,12 @@ static const ggml_backend_buffer_type_i mi_buft_iface = {
 // common graph, so the batch is formed here, behind the backend boundary.  Per column the arithmetic is that of the fused T <= 2
 // kernels, bit for bit (tests/test_gpu_batch.py).
 // ---------------------------------------------------------------------------------------------------
+struct mi_backend_ctx;
 struct mi_colset {
     int S = 1;                                       // 1: the T token columns of one graph (strided); > 1: S graphs, one single-token column each
     int T = 1;                                       // columns in total
     const ggml_cgraph * g[MI355X_MAX_COLS] = {};
+    mi_backend_ctx * owner[MI355X_MAX_COLS] = {};    // whose state column c belongs to (S == 1: owner[0] for all) — for the logits mirror
 };
 struct mi_qstate { const void * src = nullptr; int64_t K = 0; int T = 0; int which = 0; };      // planes a producer's epilogue left for its consumer
 
@@ -468,12 +479,11 @@ struct mi_backend_ctx {
     hipEvent_t  own_ev = nullptr;
     hipEvent_t  batch_wait_sync = nullptr, batch_wait_stream = nullptr;   // completion of the last batch this state was a column of: synchronize() / the own stream still have to wait for it
     int         no_batch_nodes = 0;                             // graph size (n_nodes) that was found not to fit the batch walker
-    // next-stage weight prefetch (GGML_MI355X_PREFETCH=1, single-token steps): what the launch keyed by its weights / K cache may prefetch
-    // for the launch that followed it in the previous step (a decoder replays the same launch sequence every step)
-    struct pf_geom { const void * base; int wg_bytes, nwg; };
-    bool        prefetch = false;
-    std::unordered_map<const void *, pf_geom> pf_next;
-    const void * pf_prev_key = nullptr;
+    // host-visible mirror of the logits: the vocabulary projection stores its result a second time into pinned, device-mapped host memory,
+    // so whisper's read-back of the row(s) (ggml_backend_tensor_get, src/whisper.cpp:2957-2963) is a memcpy instead of a device-to-host copy
+    char *      mirror_host = nullptr; char * mirror_dev = nullptr;
+    const void * mirror_src = nullptr; size_t mirror_bytes = 0;  // device range [mirror_src, + mirror_bytes) is what the mirror holds
+    std::atomic<int> mirror_state{0};                           // 0 nothing, 1 launched (not yet synchronized), 2 valid
     uint64_t n_graph_compute = 0;
     double   t_eager_ms = 0;                                    // host time inside graph_compute
     uint64_t trace_gc_enter = 0;                                // GGML_MI355X_TRACE: entry time of the graph_compute still waiting for its synchronize
@@ -511,6 +521,35 @@ static inline double now_ms() {
 }
 
 static std::vector<mi_backend_ctx *> g_backends;           // live backends (guarded by g_weights_mtx)
+
+#define MI_MIRROR_CAP ((size_t) 2 << 20)
+static const bool g_mirror_on = env_flag("GGML_MI355X_LOGITS_MIRROR", true);
+static char * mi_mirror_dev(mi_backend_ctx * b) {             // device address of the backend's mirror (allocated on first use), or nullptr
+    if (!g_mirror_on) return nullptr;
+    if (!b->mirror_host) {
+        void * h = nullptr, * d = nullptr;
+        if (hipHostMalloc(&h, MI_MIRROR_CAP, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void) hipGetLastError(); (void) hipHostFree(h); return nullptr; }
+        b->mirror_host = (char *) h; b->mirror_dev = (char *) d;
+    }
+    return b->mirror_dev;
+}
+// a write to [p, p + n) of `device` memory that did not come from the mirroring kernel: mirrors of that range are stale
+static void mi_mirror_invalidate(int device, const void * p, size_t n) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    for (auto * b : g_backends)
+        if (b->device == device && b->mirror_state.load() != 0 && (const char *) b->mirror_src < (const char *) p + n && (const char *) p < (const char *) b->mirror_src + b->mirror_bytes) b->mirror_state.store(0);
+}
+// read [src, src + size) from a valid mirror instead of the device; false: no mirror holds it
+static bool mi_mirror_read(int device, const void * src, void * dst, size_t size) {
+    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    for (auto * b : g_backends) {
+        if (b->device != device || b->mirror_state.load() != 2) continue;
+        const char * s0 = (const char *) b->mirror_src;
+        if ((const char *) src >= s0 && (const char *) src + size <= s0 + b->mirror_bytes) { memcpy(dst, b->mirror_host + ((const char *) src - s0), size); return true; }
+    }
+    return false;
+}
 static uint64_t g_total_stats[4] = { 0, 0, 0, 0 };         // counters of already freed backends
 static double   g_total_host_ms[4] = { 0, 0, 0, 0 };
 
@@ -669,9 +708,6 @@ static bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, 
     return true;
 }
 
-static void pf_before(mi_backend_ctx * b, const void * key);
-static void pf_after(mi_backend_ctx * b, const void * key, bool is_matvec);
-
 static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgraph * g = nullptr) {
     const ggml_tensor * mm = c.mm, * w = mm->src[0], * x = mm->src[1];
     mi355x_tensor mw = to_mt(w), mx = to_mt(x);
@@ -760,11 +796,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             if (rc != MI355X_E_UNSUPPORTED) return rc;
         }
     }
-    const bool step1 = two_d && T == 1 && is_quant_type(w->type);
-    if (step1) pf_before(b, w->data);
-    const int rc_mm = mi355x_mul_mat(b->k, &mw, &mx, &md, has_ep ? &c.ep : nullptr);
-    if (step1) pf_after(b, w->data, true);
-    return rc_mm;
+    return mi355x_mul_mat(b->k, &mw, &mx, &md, has_ep ? &c.ep : nullptr);
 }
 
 // ---- norm [-> mul w -> add b] ---------------------------------------------------------------------
@@ -819,18 +851,12 @@ static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c, const ggml_cgrap
 static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const mi355x_attn_partials & parts, int & end_out, int & rc_out);
 static int  run_node(mi_backend_ctx * b, const ggml_tensor * n);
 
-// next-stage weight prefetch around one launch of a single-token step: give it the hint learned for its key in the previous step, and
-// afterwards remember that the PREVIOUS launch may prefetch this one's weights
-static void pf_before(mi_backend_ctx * b, const void * key) {
-    if (!b->prefetch) return;
-    auto it = b->pf_next.find(key);
-    if (it != b->pf_next.end()) mi355x_prefetch_hint(b->k, it->second.base, it->second.wg_bytes, it->second.nwg);
-}
-static void pf_after(mi_backend_ctx * b, const void * key, bool is_matvec) {
-    if (!b->prefetch) return;
-    const void * base = nullptr; int wgb = 0, nwg = 0;
-    if (is_matvec && mi355x_last_weights_geometry(b->k, &base, &wgb, &nwg) && b->pf_prev_key) b->pf_next[b->pf_prev_key] = { base, wgb, nwg };
-    b->pf_prev_key = key;
+
+// is this chain the vocabulary projection whose rows the caller reads back (src/whisper.cpp:2957-2963)?  Then its rows are mirrored.
+static bool mirror_wanted(const mm_chain & ch, int64_t T) {
+    const ggml_tensor * l = ch.last;
+    return g_mirror_on && (l->flags & GGML_TENSOR_FLAG_OUTPUT) && l == ch.mm && l->type == GGML_TYPE_F32 && l->ne[0] > 8192 && (int64_t) l->nb[1] == l->ne[0]*4 &&
+           l->ne[2] == 1 && l->ne[3] == 1 && T >= 1 && T <= MI355X_MAX_COLS && (size_t) (l->ne[0]*4*T) <= MI_MIRROR_CAP;
 }
 
 // decoder step: LayerNorm fused into the mat-vec products that consume it (Q/K/V, cross-Q, fc1)
@@ -869,10 +895,19 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
     // (A one-launch "LN + Q projection + cross-attention" kernel existed in round 1.  Re-measured with plain launches it LOSES to the
     //  two launches it replaced, 1.478 -> 1.435 ms/token with it switched off (profiles/r02_decode_env_sweep_final.txt): 64 rows of
     //  W_q per workgroup serialise what 256 workgroups otherwise do in parallel, and a dependent boundary costs only ~1.5 us.  Removed.)
-    if (T == 1) pf_before(b, d.seg[0].w);
+    mi355x_gemv_cols mcols;
+    if (n == 1 && mirror_wanted(ch[0], T)) {
+        if (char * md = mi_mirror_dev(b)) {
+            memset(&mcols, 0, sizeof(mcols));
+            for (int t = 0; t < (int) T; t++) mcols.mirror[t] = md + (size_t) t * (size_t) ch[0].last->ne[0] * 4;
+            d.cols = &mcols;
+        }
+    }
     const int rc = mi355x_gemv_fused(b->k, &d);
-    if (T == 1) pf_after(b, d.seg[0].w, true);
     if (rc == MI355X_E_UNSUPPORTED) return false;
+    if (rc == 0 && d.cols && mi355x_last_launch_mirrored(b->k)) {
+        b->mirror_src = ch[0].last->data; b->mirror_bytes = (size_t) ch[0].last->ne[0] * 4 * (size_t) T; b->mirror_state.store(1);
+    }
     rc_out = rc; end_out = ch[n - 1].end;
     return true;
 }
@@ -891,9 +926,7 @@ static bool try_fattn_gemv(mi_backend_ctx * b, const ggml_cgraph * g, int i, int
     if (m) mm_ = to_mt(m);
     float scale; memcpy(&scale, fa->op_params, 4);
     mi355x_attn_partials parts;
-    if (T == 1) pf_before(b, k->data);
     int rc = mi355x_flash_attn_partial(b->k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
-    if (T == 1) pf_after(b, k->data, false);
     if (rc == MI355X_E_UNSUPPORTED) return false;
     rc_out = rc; end_out = i;
     if (rc) return true;
@@ -925,9 +958,7 @@ static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const
             sg.w = w->data; sg.wtype = (int32_t) w->type; sg.N = (int32_t) w->ne[1]; sg.ep = ch.ep;
             sg.dst = ch.last->data; sg.dst_type = (int32_t) ch.last->type;
             sg.dst_nb1 = ch.last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch.last == ch.mm ? (int64_t) ch.mm->nb[1] : (int64_t) ch.last->nb[1]);
-            if (T == 1) pf_before(b, sg.w);
             rc = mi355x_gemv_fused(b->k, &d);
-            if (T == 1) pf_after(b, sg.w, true);
             if (rc != MI355X_E_UNSUPPORTED) { fused = true; rc_out = rc; end_out = ch.end; }
         }
     }
@@ -1141,7 +1172,22 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
     d.K = (int) K; d.T = cs.T; d.nseg = n; d.x_planes = p0; d.cols = &cols;
     for (int s = 0; s < n; s++) q_fill_seg(cs, ch[s], s, d, cols);
     if (pout) { d.planes_out = p1; d.planes_out_only = only ? 1 : 0; }
+    bool mirror = n == 1 && cs.owner[0] && mirror_wanted(ch[0], cs.S > 1 ? 1 : cs.T);
+    if (mirror) {
+        const size_t rowb = (size_t) ch[0].last->ne[0] * 4;
+        for (int c = 0; c < cs.T && mirror; c++) {
+            mi_backend_ctx * ob = cs.S > 1 ? cs.owner[c] : cs.owner[0];
+            char * md = ob ? mi_mirror_dev(ob) : nullptr;
+            if (!md) mirror = false; else cols.mirror[c] = cs.S > 1 ? md : md + (size_t) c * rowb;
+        }
+        if (!mirror) memset(cols.mirror, 0, sizeof(cols.mirror));
+    }
     rc = mi355x_gemv_fused(k, &d);
+    if (rc == 0 && mirror && mi355x_last_launch_mirrored(k)) {
+        const size_t rowb = (size_t) ch[0].last->ne[0] * 4;
+        if (cs.S > 1) for (int c = 0; c < cs.T; c++) { mi_backend_ctx * ob = cs.owner[c]; ob->mirror_src = cs_tensor(cs, c, ch[0].end, -1)->data; ob->mirror_bytes = rowb; ob->mirror_state.store(1); }
+        else { mi_backend_ctx * ob = cs.owner[0]; ob->mirror_src = ch[0].last->data; ob->mirror_bytes = rowb * (size_t) cs.T; ob->mirror_state.store(1); }
+    }
     if (rc == MI355X_E_UNSUPPORTED && pout) { d.planes_out = nullptr; d.planes_out_only = 0; pout = false; rc = mi355x_gemv_fused(k, &d); }
     if (rc == MI355X_E_UNSUPPORTED) { rc_out = (int) hipErrorInvalidValue; GGML_LOG_ERROR("ggml-mi355x: plane mat-vec rejected a shape its planes were already prepared for\n"); return true; }
     rc_out = rc;
@@ -1334,7 +1380,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         if (b->fuse && !b->exact && (n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_NORM || n->op == GGML_OP_FLASH_ATTN_EXT)) {
             const int64_t Tn = n->op == GGML_OP_FLASH_ATTN_EXT ? n->src[0]->ne[1] : (n->op == GGML_OP_MUL_MAT ? n->src[1]->ne[1] : ggml_nrows(n->src[0]));
             if (Tn >= planes_min_t && Tn <= MI355X_MAX_COLS) {
-                mi_colset cs; cs.S = 1; cs.T = (int) Tn; cs.g[0] = g;
+                mi_colset cs; cs.S = 1; cs.T = (int) Tn; cs.g[0] = g; cs.owner[0] = b;
                 int end = i, rc2 = 0; bool took = false;
                 if (n->op == GGML_OP_NORM) { ln_chain c; parse_ln_chain(g, i, true, c); took = q_ln_gemv(b->k, cs, b->qs, i, c, end, rc2); }
                 else if (n->op == GGML_OP_FLASH_ATTN_EXT) took = q_attn_proj(b->k, cs, b->qs, i, end, rc2);
@@ -1424,7 +1470,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
     return mi355x_flush(b->k);            // launches the kernel library held back for grouping (gemm_mfma.hip) leave with their range
 }
 static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
-    b->act_src = nullptr; b->qs = mi_qstate(); b->pf_prev_key = nullptr;
+    b->act_src = nullptr; b->qs = mi_qstate();
     return mi_emit_range(b, g, 0, g->n_nodes);
 }
 
@@ -1439,6 +1485,7 @@ static void mi_backend_free(ggml_backend_t backend) {
     mi355x_ctx_synchronize(b->k);
     if (b->batch_wait_sync) (void) hipEventSynchronize(b->batch_wait_sync);
     if (b->own_ev) (void) hipEventDestroy(b->own_ev);
+    b->mirror_state.store(0);
     if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 "\n", b->name.c_str(), b->n_graph_compute);
     if (b->span_pending) mi_span_drain(b);
     for (auto & e : b->span_ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
@@ -1452,6 +1499,7 @@ static void mi_backend_free(ggml_backend_t backend) {
         g_total_gpu_span_ms += b->t_gpu_span_ms;
     }
     mi355x_ctx_destroy(b->k);
+    if (b->mirror_host) (void) hipHostFree(b->mirror_host);
     delete b;
     delete backend;
 }
@@ -1462,6 +1510,7 @@ static void mi_backend_synchronize(ggml_backend_t backend) {
     (void) hipSetDevice(b->device);
     mi355x_ctx_synchronize(b->k);
     if (b->batch_wait_sync) { (void) hipEventSynchronize(b->batch_wait_sync); b->batch_wait_sync = nullptr; }      // the launch chain this state was a column of
+    { int one = 1; b->mirror_state.compare_exchange_strong(one, 2); }                                              // the mirrored logits have landed in host memory
     if (g_trace && b->trace_gc_enter) { g_trace_ns[4] += trace_now() - b->trace_gc_enter; g_trace_calls[4]++; b->trace_gc_enter = 0; }
     if (b->span_pending) mi_span_drain(b);
 }
@@ -1561,7 +1610,7 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
         if (!ln.k) ok = false;
     }
     mi_colset cs; cs.S = n; cs.T = n;
-    for (int c = 0; c < n; c++) cs.g[c] = mem[c]->g;
+    for (int c = 0; c < n; c++) { cs.g[c] = mem[c]->g; cs.owner[c] = mem[c]->b; }
     if (ok) {
         const ggml_cgraph * g0 = cs.g[0];
         const uint64_t sn = (uint64_t) g0->n_nodes; const void * sw = g0->nodes[g0->n_nodes - 1]->src[0]->data;
@@ -1665,6 +1714,7 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
     b->n_graph_compute++;
     trace_scope trace_gc(3);
     if (g_trace) b->trace_gc_enter = trace_gc.t0;
+    b->mirror_state.store(0);                   // the new graph reuses the compute buffer the mirrored tensor lived in
     if (mi_batching_on() && b->fuse && !b->exact && !b->prof && cgraph->n_nodes != b->no_batch_nodes && mi_is_step_graph(cgraph)) return mi_batch_join(b, cgraph);
     mi_batch_leave(b);                          // anything else (encoder, prompt, beam step): this state is not decoding token by token right now
     return mi_compute_own(b, cgraph);
@@ -1720,7 +1770,6 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
     // Plain launches on the backend's stream.  (Rounds 1-2 carried a record / patch / replay path over hipGraphs; on ROCm 7.2 it lost to
     //  the plain launch loop on the same kernels — 1.515 vs 1.473 ms/token, profiles/r02_decode_launch_mode_sweep.txt — and was removed.)
     b->fuse = env_flag("GGML_MI355X_FUSE", true); b->prof = env_flag("GGML_MI355X_PROF", false);
-    b->prefetch = env_flag("GGML_MI355X_PREFETCH", false);
     b->exact = env_flag("GGML_MI355X_EXACT", false);
     if (b->prof) mi355x_prof_enable(k, 1);
     { std::lock_guard<std::mutex> lk(g_weights_mtx); g_backends.push_back(b); }

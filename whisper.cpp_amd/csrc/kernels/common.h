@@ -35,9 +35,7 @@ struct mi355x_ctx {
     size_t      scratch_size = 0;
     size_t      scratch_used = 0;        // bump pointer, reset per op group
     std::vector<void *> scratch_retired; // outgrown arenas that may still back pointers of the current op group
-    // next-stage weight prefetch: one-shot hint consumed by the next decode mat-vec / attention launch, and the geometry of the last mat-vec
-    const char * pf_base = nullptr; int pf_wg_bytes = 0, pf_nwg = 0;
-    const char * geom_base = nullptr; int geom_wg_bytes = 0, geom_nwg = 0;
+    int         last_mirrored = 0;      // the last mat-vec launch also wrote its caller's mirror columns (mi355x_last_launch_mirrored)
     void *      qact = nullptr;          // two quantized-activation plane buffers (decode_q.hip, mi355x_act_scratch)
     float *     mel_tab = nullptr;       // sin / cos / Hann tables + the running maximum of mi355x_log_mel (device)
     uint64_t    n_eager = 0;             // launches issued directly on the stream so far (mi355x_eager_count)

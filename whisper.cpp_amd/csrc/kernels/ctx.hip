@@ -137,15 +137,8 @@ static void prof_drain(mi355x_ctx * ctx) {
 }
 
 extern "C" int mi355x_flush(mi355x_ctx * ctx) { return mi355x_flush_pending(ctx); }
+extern "C" int mi355x_last_launch_mirrored(mi355x_ctx * ctx) { const int r = ctx->last_mirrored; ctx->last_mirrored = 0; return r; }
 
-extern "C" void mi355x_prefetch_hint(mi355x_ctx * ctx, const void * base, int wg_bytes, int nwg) {
-    if (base && wg_bytes > 0 && nwg > 0) { ctx->pf_base = (const char *) base; ctx->pf_wg_bytes = wg_bytes; ctx->pf_nwg = nwg; } else ctx->pf_base = nullptr;
-}
-extern "C" int mi355x_last_weights_geometry(mi355x_ctx * ctx, const void ** base, int * wg_bytes, int * nwg) {
-    *base = ctx->geom_base; *wg_bytes = ctx->geom_wg_bytes; *nwg = ctx->geom_nwg;
-    ctx->geom_base = nullptr;
-    return *base != nullptr;
-}
 
 extern "C" int mi355x_ctx_synchronize(mi355x_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
@@ -217,7 +210,6 @@ int mi355x_emit(mi355x_ctx * ctx, const char * name, const void * func, dim3 gri
         e = hipLaunchKernel(func, grid, block, kargs, shmem, ctx->stream);
     }
     if (e != hipSuccess) { mi355x_set_error("launch of %s failed: %s", name, hipGetErrorString(e)); return (int) e; }
-    ctx->pf_base = nullptr;                 // a prefetch hint is for the very next launch: whoever could use it has copied it into its arguments
     if (ctx->prof) {
         // profile rows are keyed by the kernel's own (demangled) symbol, i.e. exactly the name rocprofv3 reports
         static std::map<const void *, const char *> names;

@@ -255,6 +255,12 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
                     for (int t = 1; t < T; t++) dp = (j8 == t) ? (char *) a.dstcol[t] : dp;
                 }
                 if (sg.dst_f16) ((uint16_t *) dp)[row] = f2h(v); else ((float *) dp)[row] = v;
+                if (a.mircol[0]) {
+                    char * mp = (char *) a.mircol[0];
+                    #pragma unroll
+                    for (int t = 1; t < T; t++) mp = (j8 == t) ? (char *) a.mircol[t] : mp;
+                    ((float *) mp)[row] = v;
+                }
             }
             #pragma unroll
             for (int t = 0; t < T; t++) acc[t] = 0.0f;
@@ -307,7 +313,7 @@ static int launch_gemv8(mi355x_ctx * ctx, const DGArgs & k, int T, int lpr, dim3
 // R = weight rows per wave.  1 for T <= 2.  With more columns every workgroup re-reads T*K*4 bytes of activations from L2
 // (26 MB per launch for 1024 workgroups at T = 5, six times the weight bytes): R = 4 rows per wave cuts the workgroup count
 // and that traffic by 4 while the same number of weight loads stays in flight.
-template <int WT, int T, int XS, int MODE, bool NSEG1, int R = 1, bool PF = false>  // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads); PF: also prefetch the next launch's weights
+template <int WT, int T, int XS, int MODE, bool NSEG1, int R = 1>                   // XS = float4 activation slots per column per thread: 1 (K <= 2048, threads >= K/4) or 5 (K <= 5120, 256 threads)
 __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
     constexpr int NU = Q4K ? (XS == 1 ? 1 : 2) : (XS == 1 ? 1 : 3);      // units per lane: 32-element blocks (64-element chunks for Q4_K)
@@ -418,8 +424,6 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    dg_pf pfr;
-    if constexpr (PF) { pfr = dg_prefetch(a.pf_base, a.pf_wg_bytes, a.pf_nwg, (int) blockIdx.x, (int) gridDim.x, tid); __builtin_amdgcn_sched_barrier(0); }
     DG_STAMP(1);                                                        // all loads issued
 
     float * red = (float *) smem;                                       // [2][T][8]
@@ -697,7 +701,6 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         char * dp = (char *) sg.dst + (int64_t) tcol*sg.dst_nb1;
         if (sg.dst_f16) ((uint16_t *) dp)[row + rlane] = f2h(v); else ((float *) dp)[row + rlane] = v;
     }
-    if constexpr (PF) DG_PF_SINK(pfr);
     DG_STAMP(6);
 }
 
@@ -719,10 +722,7 @@ static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 gri
         }
     }
     if (k.K > 2048) {
-        if constexpr (MODE == 0 || MODE == 1) {
-            if (T == 1 && k.pf_base) return emit(ctx, name, k_gemv_row<WT, 1, 5, MODE, NSEG1, 1, true>, grid, dim3(256), lds, k, bytes, flops);
-            if (T == 1) return emit(ctx, name, k_gemv_row<WT, 1, 5, MODE, NSEG1>, grid, dim3(256), lds, k, bytes, flops);
-        }
+        if constexpr (MODE == 0 || MODE == 1) { if (T == 1) return emit(ctx, name, k_gemv_row<WT, 1, 5, MODE, NSEG1>, grid, dim3(256), lds, k, bytes, flops); }
         return MI355X_E_UNSUPPORTED;
     }
     const dim3 block(64 * gemv_row_waves(k.K));
@@ -732,8 +732,7 @@ static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 gri
         return MI355X_E_UNSUPPORTED;
     } else {
         switch (T) {
-            case 1: if (k.pf_base) return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE, NSEG1, 1, true>, grid, block, lds, k, bytes, flops);
-                    return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+            case 1: return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
             case 2: return emit(ctx, name, k_gemv_row<WT, 2, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
             case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
             case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
@@ -787,6 +786,9 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     k.dbg = (unsigned long long *) mi355x_debug_stamps(ctx);
     k.part_o = d->attn_part_o; k.part_ml = d->attn_part_ml; k.nparts = d->attn_nparts;
     k.xq = d->x_planes;
+    ctx->last_mirrored = 0;
+    const bool want_mirror = d->cols && d->cols->mirror[0] && d->nseg == 1 && d->seg[0].dst_type == MI355X_TYPE_F32;
+    if (want_mirror) for (int t = 0; t < 8; t++) { k.mircol[t] = d->cols->mirror[t < T ? t : T - 1]; if (!k.mircol[t]) return MI355X_E_UNSUPPORTED; }
     if (from_q && d->cols) {
         k.use_cols = 1;
         for (int t = 0; t < 8; t++) k.dstcol[t] = d->cols->dst[0][t < T ? t : T - 1];
@@ -811,7 +813,7 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const double bytes0 = wbytes + (double) K*T*4 + (double) ntot*T*4;
     const double flops0 = 2.0 * ntot * K * T;
     static const int env_lean = getenv("GGML_MI355X_GEMV_LEAN") ? atoi(getenv("GGML_MI355X_GEMV_LEAN")) : 1;
-    if (env_lean && !from_q && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
+    if (env_lean && !from_q && !want_mirror && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
         const int rpw = gemv_row_waves(K);
         // 512-byte reduction header + activation planes (+ one float4 per thread and column when the attention combine
         // of T > 2 columns is staged through LDS)
@@ -826,13 +828,6 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         if (d->has_norm && env_wave_ln) R = 1;
         const int rpb = gemv_row_waves(K) * R;
         const dim3 grid((ntot + rpb - 1) / rpb);
-        if (T == 1) {
-            // what the launch AFTER this one may prefetch of THIS one's weights next step: the bytes of segment 0's quant plane per workgroup
-            const int upb = wt == MI355X_TYPE_Q8_0 ? 32 : (wt == MI355X_TYPE_Q4_K ? 128 : 16);           // quant-plane bytes per unit (block / super-block)
-            const int units = wt == MI355X_TYPE_Q4_K ? K / 256 : K / 32;
-            ctx->geom_base = (const char *) d->seg[0].w; ctx->geom_wg_bytes = rpb * units * upb; ctx->geom_nwg = (d->seg[0].N + rpb - 1) / rpb;
-            if (ctx->pf_base) { k.pf_base = ctx->pf_base; k.pf_wg_bytes = ctx->pf_wg_bytes; k.pf_nwg = ctx->pf_nwg; ctx->pf_base = nullptr; }
-        }
         int rc = MI355X_E_UNSUPPORTED;
         switch (wt) {
             case MI355X_TYPE_Q4_0: rc = launch_gemv_row<MI355X_TYPE_Q4_0>(ctx, k, T, grid, (uint32_t) lds_row, bytes0, flops0, R); break;
@@ -868,13 +863,15 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const double bytes = wbytes + (double) K*T*4 + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;
     const dim3 grid(nblocks), block(64*wpb);
+    int rc8 = MI355X_E_UNSUPPORTED;
     switch (wt) {
-        case MI355X_TYPE_Q4_0: return launch_gemv8<MI355X_TYPE_Q4_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q5_0: return launch_gemv8<MI355X_TYPE_Q5_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q8_0: return launch_gemv8<MI355X_TYPE_Q8_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q4_K: return launch_gemv8<MI355X_TYPE_Q4_K>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q4_0: rc8 = launch_gemv8<MI355X_TYPE_Q4_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops); break;
+        case MI355X_TYPE_Q5_0: rc8 = launch_gemv8<MI355X_TYPE_Q5_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops); break;
+        case MI355X_TYPE_Q8_0: rc8 = launch_gemv8<MI355X_TYPE_Q8_0>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops); break;
+        case MI355X_TYPE_Q4_K: rc8 = launch_gemv8<MI355X_TYPE_Q4_K>(ctx, k, T, lpr, grid, block, (uint32_t) lds, bytes, flops); break;
     }
-    return MI355X_E_UNSUPPORTED;
+    if (rc8 == 0 && want_mirror) ctx->last_mirrored = 1;
+    return rc8;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -887,10 +884,9 @@ struct FDArgs {
     int has_mask; float scale;
     int T, n_kv, H, rk2, rv2, nparts;
     float * part_o; float * part_ml;
-    const char * pf_base; int pf_wg_bytes; int pf_nwg;       // PF kernel only, as in DGArgs
 };
 
-template <int T, bool PF = false>
+template <int T>
 __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
     __shared__ __attribute__((aligned(16))) float wo[4][T][64];
     __shared__ float wml[4][T][2];
@@ -932,8 +928,6 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
             const int key = kbeg + kg + 8*i, kc = key < a.n_kv ? key : a.n_kv - 1;
             mkh[t][i] = *(const uint16_t *) (mbase + (int64_t) t*mnb1 + (int64_t) kc*2);
         }
-    dg_pf pfr;
-    if constexpr (PF) pfr = dg_prefetch(a.pf_base, a.pf_wg_bytes, a.pf_nwg, (int) (blockIdx.y*gridDim.x + blockIdx.x), (int) (gridDim.x*gridDim.y), tid);
     float sc[T][4];
     #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -996,7 +990,6 @@ __global__ void __launch_bounds__(256) k_fattn_dec(const FDArgs a) {
             a.part_ml[rec*2 + 1] = fmaf(w3, wml[3][t][1], fmaf(w2, wml[2][t][1], fmaf(w1, wml[1][t][1], w0 * wml[0][t][1])));
         }
     }
-    if constexpr (PF) DG_PF_SINK(pfr);
 }
 
 
@@ -1050,9 +1043,7 @@ extern "C" int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor *
     const double flops = 4.0 * T * (double) n_kv * 64 * H;
     int rc;
     switch (T) {
-        case 1: if (ctx->pf_base) { a.pf_base = ctx->pf_base; a.pf_wg_bytes = ctx->pf_wg_bytes; a.pf_nwg = ctx->pf_nwg; ctx->pf_base = nullptr;
-                                    rc = emit(ctx, "fattn_dec", k_fattn_dec<1, true>, grid, block, 0, a, bytes, flops); break; }
-                rc = emit(ctx, "fattn_dec", k_fattn_dec<1>, grid, block, 0, a, bytes, flops); break;
+        case 1: rc = emit(ctx, "fattn_dec", k_fattn_dec<1>, grid, block, 0, a, bytes, flops); break;
         case 2: rc = emit(ctx, "fattn_dec", k_fattn_dec<2>, grid, block, 0, a, bytes, flops); break;
         case 3: rc = emit(ctx, "fattn_dec", k_fattn_dec<3>, grid, block, 0, a, bytes, flops); break;
         case 4: rc = emit(ctx, "fattn_dec", k_fattn_dec<4>, grid, block, 0, a, bytes, flops); break;

@@ -27,30 +27,8 @@ struct DGArgs {
     const void * xq;                   // activations already quantized: image of the LDS planes for (K, T) (decode_q.hip), copied instead of computed
     void * dstcol[8];                  // use_cols: column t of segment 0 is stored at dstcol[t] instead of dst + t*dst_nb1 (cross-state batches)
     int use_cols; int pad2;
-    // PF kernels only: the weight bytes the NEXT launch's workgroup j will stream are [pf_base + j*pf_wg_bytes, + pf_wg_bytes), j < pf_nwg
-    const char * pf_base; int pf_wg_bytes; int pf_nwg;
+    void * mircol[8];                  // mircol[0] != NULL: column t of segment 0 is also stored (F32) at mircol[t] (host-visible mirror of the logits)
 };
-
-// Next-stage weight prefetch (VERDICT r02 next #3 ii): weights do not depend on activations, so a kernel can pull the bytes of the launch
-// that FOLLOWS it towards the L2 of the XCD that will read them while its own weights are still in flight.  Workgroup p touches one dword
-// of every 128-byte line of consumer workgroups p, p + G, p + 2G, p + 3G (G = this grid rounded down to a multiple of 8: block b runs on
-// XCD b % 8 — observed, a performance hint only).  Plain loads whose values are only consumed by an empty asm at the kernel's end: the
-// compiler's wait counts stay exact (the prefetches are the YOUNGEST loads: nothing older ever waits for them).
-struct dg_pf { uint32_t v[4]; };
-__device__ __forceinline__ dg_pf dg_prefetch(const char * base, int wg_bytes, int nwg, int wg, int nwgs, int tid) {
-    dg_pf r;
-    const int G = nwgs >= 8 ? (nwgs & ~7) : nwgs;
-    const int lines = (wg_bytes + 127) >> 7;
-    const int l = tid < lines ? tid : lines - 1;
-    #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        int j = wg + q*G;
-        j = j < nwg ? j : nwg - 1;
-        r.v[q] = *(const uint32_t *) (base + (int64_t) j*wg_bytes + (int64_t) l*128);
-    }
-    return r;
-}
-#define DG_PF_SINK(r) asm volatile("" :: "v"((r).v[0]), "v"((r).v[1]), "v"((r).v[2]), "v"((r).v[3]))
 // Kernel-anatomy stamps are compiled in only with -DMI355X_KTIME (MI355X_KTIME_BUILD=1 python whisper.cpp_amd/build.py): even
 // with a null pointer each of the seven stamp sites costs a saveexec / branch / restore triple and a basic-block boundary in
 // kernels whose whole body is ~2 us.

@@ -246,7 +246,7 @@ __device__ __forceinline__ void wblk_dot_q4k_rt(const wblk<MI355X_TYPE_Q4_K> & r
 // units are 64 elements: 1: K <= 4096, 2: K <= 8192).  R rows per wave.  POUT: 8 waves x 4 rows = the 32 rows of one Q8_0
 // block of the RESULT per workgroup, whose planes are written as well (single segment).
 template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT>
-__global__ void __launch_bounds__(512) k_gemv_q(const QGArgs a) {
+__global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QGArgs a) {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
     constexpr int CP = (TMAX * (Q4K ? NU*4096*9/8 + 256 : NU*64*40) / 16 + 255) / 256;       // uint4 copy slots per thread (>= 256 threads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -431,7 +431,10 @@ __global__ void __launch_bounds__(512) k_gemv_q(const QGArgs a) {
 template <int WT, int TMAX, int NU>
 static int launch_gemv_q_v(mi355x_ctx * ctx, const QGArgs & k, bool nseg1, bool pout, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv_q";
-    if constexpr (NU == 1 && WT != MI355X_TYPE_Q4_K) { if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true>, grid, block, lds, k, bytes, flops); }
+    if constexpr (NU == 1 && WT != MI355X_TYPE_Q4_K) {
+        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
+        if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
+    }
     if (pout) return MI355X_E_UNSUPPORTED;
     if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false>, grid, block, lds, k, bytes, flops);
     if constexpr (NU == 1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false>, grid, block, lds, k, bytes, flops);
@@ -497,7 +500,9 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const size_t img = (dg_act_bytes(wt, K, T) + 15) & ~(size_t) 15;
     const size_t lds = img + 16 + (pout ? (size_t) MI355X_MAX_COLS * 32 * 4 : 0);      // image | dummy word | result tile
     if (lds > 64 * 1024) return MI355X_E_UNSUPPORTED;
-    const int waves = pout ? 8 : gemv_row_waves(K), rpb = pout ? 32 : waves;
+    // the 32 rows of a planes-out workgroup: 8 waves x 4 rows or 16 waves x 2 rows (GGML_MI355X_POUT_ROWS; more waves = more loads in flight per CU)
+    static const int pout_rows = getenv("GGML_MI355X_POUT_ROWS") && atoi(getenv("GGML_MI355X_POUT_ROWS")) == 2 ? 2 : 4;
+    const int waves = pout ? 32 / pout_rows : gemv_row_waves(K), rpb = pout ? 32 : waves;
     const dim3 grid((ntot + rpb - 1) / rpb), block(64 * waves);
     const double bytes = wbytes + (double) dg_act_bytes(wt, K, T) + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;
