@@ -252,6 +252,11 @@ MI355X_API int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_par
 typedef struct mi355x_attn_state { const void * q; const void * k; const void * v; const void * mask /* f16 row or NULL */; int32_t n_kv; int32_t reserved; } mi355x_attn_state;
 MI355X_API int mi355x_flash_attn_partial_multi(mi355x_ctx * ctx, int S, const mi355x_attn_state * st, const mi355x_tensor * q0, const mi355x_tensor * k0,
                                                const mi355x_tensor * v0, float scale, mi355x_attn_partials * out);
+/* decoder SELF-attention of T columns (at most 512 keys each) in one launch, ending in the Q8_0 activation planes of the output
+ * projection (Q4_0 / Q5_0 / Q8_0 weights): the result of mi355x_flash_attn_partial[_multi] -> mi355x_act_prepare(partials), bit for bit,
+ * without the record round trip and the second launch.  st[c]: column c's q [64, 1, H], K / V (shapes and strides of k0 / v0), mask row, keys. */
+MI355X_API int mi355x_flash_attn_planes(mi355x_ctx * ctx, int T, const mi355x_attn_state * st, const mi355x_tensor * q0, const mi355x_tensor * k0,
+                                        const mi355x_tensor * v0, float scale, void * planes);
 /* head of S single-token decoder steps in ONE launch: dst[s] = te[tok[s]] + pe[pos[s]] (src/whisper.cpp:2524-2526) and the
  * F32 -> F16 cast of every state's mask row (ggml_cast, :2520); a state with tok == NULL / mask_f32 == NULL skips that half */
 typedef struct mi355x_head_state { const int32_t * tok; const int32_t * pos; float * dst; const float * mask_f32; void * mask_f16; int32_t n_mask; int32_t reserved; } mi355x_head_state;
@@ -295,6 +300,12 @@ MI355X_API int mi355x_scale(mi355x_ctx * ctx, const mi355x_tensor * x, const mi3
 
 /* ggml_gelu (ggml/src/ggml.c:2781; CPU ggml_vec_gelu_f32, ggml-cpu/vec.h:987-1000: f16 lookup table) */
 MI355X_API int mi355x_gelu(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst);
+/* the element-wise ops of the voice-activity-detection graph (src/whisper.cpp:4545-4680: encoder ReLUs, LSTM gates, STFT magnitude):
+ * ggml_relu / ggml_sigmoid / ggml_tanh / ggml_sqrt (CPU ggml-cpu/unary-ops.cpp:19-53), contiguous F32 */
+enum mi355x_unary_op { MI355X_UNARY_RELU = 2, MI355X_UNARY_SIGMOID = 3, MI355X_UNARY_TANH = 4, MI355X_UNARY_SQRT = 5 };
+MI355X_API int mi355x_unary(mi355x_ctx * ctx, int op, const mi355x_tensor * x, const mi355x_tensor * dst);
+/* ggml_pad_reflect_1d (CPU ggml-cpu/ops.cpp:8149-8180): reflective padding of dim 0 by p0 / p1 elements, F32 (the VAD's STFT input) */
+MI355X_API int mi355x_pad_reflect_1d(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * dst, int p0, int p1);
 
 /* ggml_cpy / ggml_cont / ggml_dup / ggml_cast between F32 and F16 (CPU ggml-cpu/ops.cpp:17-654) */
 MI355X_API int mi355x_cpy(mi355x_ctx * ctx, const mi355x_tensor * src, const mi355x_tensor * dst);
@@ -315,11 +326,13 @@ MI355X_API int mi355x_im2col_1d(mi355x_ctx * ctx, const mi355x_tensor * x, const
 MI355X_API int mi355x_soft_max(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * mask /* nullable */,
                                const mi355x_tensor * dst, float scale, float max_bias);
 
-/* ggml_rope_ext, modes NORMAL(0) and NEOX(2) incl. YaRN parameters (ggml/src/ggml.c:4168; CPU
- * ggml-cpu/ops.cpp:5822-6131).  Not on whisper's graph; standalone op. */
+/* ggml_rope_ext / ggml_rope_multi: modes NORMAL(0), NEOX(2), MROPE(8), VISION(24), IMROPE(40) incl. YaRN parameters (ggml/src/ggml.c:4168;
+ * CPU ggml-cpu/ops.cpp:5822-6131; modes ggml/include/ggml.h:250-254).  pos: I32 [ne2] (x 4 for the multi-position modes: t | h | w | e).
+ * Not on whisper's graph; standalone op. */
 typedef struct mi355x_rope_params {
     int32_t n_dims, mode, n_ctx_orig;
     float   freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+    int32_t sections[4];           /* modes MROPE (8), VISION (24), IMROPE (40): dims per position stream t / h / w / e (ggml_rope_multi) */
 } mi355x_rope_params;
 MI355X_API int mi355x_rope(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * pos /* I32 [ne2] */,
                            const float * freq_factors /* nullable */, const mi355x_tensor * dst,

@@ -9,7 +9,9 @@ from collections import defaultdict
 # checks the attention kernels against an exact f64 attention: ours < 1e-6, the reference's own result ~3e-5).
 THRESH = [
     ("mul_mat", 2e-6), ("conv1d", 2e-6), ("flash_attn", 1e-4), ("declayer", 1e-4), ("xattnlayer", 1e-4), ("soft_max", 1e-10), ("rope", 1e-9),
-    ("norm", 1e-10), ("gelu", 1e-12), ("get_rows", 1e-12), ("embed", 1e-12), ("", 1e-12),
+    ("norm", 1e-10), ("gelu", 1e-12), ("get_rows", 1e-12), ("embed", 1e-12),
+    # the voice-activity-detection graph's ops: device expf / tanhf differ from glibc's by an ulp; its convolutions are f16 mat-muls
+    ("unary_sigmoid", 1e-12), ("unary_tanh", 1e-12), ("vad_lstm", 1e-10), ("vad_", 2e-6), ("", 1e-12),
 ]
 
 

@@ -65,7 +65,19 @@ class _Rng:
         return out.reshape(shape)
 
 
-def write_f16_model(path: Path, arch: str, seed: int = 1234):
+def planted_token(pos: int) -> int:
+    """the token a PLANTED model emits after the token at decoder position `pos` (ordinary text tokens, all different)"""
+    return 1000 + (pos * 7919) % 40000
+
+
+def write_f16_model(path: Path, arch: str, seed: int = 1234, plant: bool = False):
+    """plant=True: a model with LARGE logit margins and a known transcript.  Random-weight models have near-Gaussian logits whose top-2
+    margin falls below any backend's rounding differences every 10-20 steps, so free-running token sequences of two correct back ends
+    part ways for reasons that have nothing to do with correctness.  Trained models have margins orders of
+    magnitude larger; this plants that property: positional embedding p = 12 x the embedding of token planted_token(p), and the three
+    residual-writing projections of every decoder layer scaled by 0.02, so that the final hidden state at position p points at
+    planted_token(p) and the logits (token_embedding . LayerNorm(x), the same quantized matrix) put it ~50 above the runner-up.  Every
+    kernel of the path still runs on full-size data; greedy AND beam search must then produce the planted sequence on any correct back end."""
     (n_vocab, n_audio_ctx, n_as, n_ah, n_al, n_text_ctx, n_ts, n_th, n_tl, n_mels) = ARCHS[arch]
     rng = _Rng(seed)
     with open(path, "wb") as f:
@@ -92,6 +104,11 @@ def write_f16_model(path: Path, arch: str, seed: int = 1234):
         def mat(name, out_f, in_f):          # 2-D weights: f16, N(0, 1/in)
             _w_tensor(f, name, rng.normal((out_f, in_f), 1.0 / np.sqrt(in_f)).astype(np.float16))
 
+        def omat(name, out_f, in_f):         # the projections that write into the decoder's residual stream (scaled down in a planted model)
+            _w_tensor(f, name, (rng.normal((out_f, in_f), 1.0 / np.sqrt(in_f)) * out_scale).astype(np.float16))
+
+        out_scale = 1.0
+
         def vec(name, n, scale=0.02, base=0.0):  # biases / LN: f32
             _w_tensor(f, name, (rng.normal((n,), scale) + base).astype(np.float32))
 
@@ -114,41 +131,47 @@ def write_f16_model(path: Path, arch: str, seed: int = 1234):
             mat(p + "attn.value.weight", n_as, n_as); vec(p + "attn.value.bias", n_as)
             mat(p + "attn.out.weight", n_as, n_as); vec(p + "attn.out.bias", n_as)
         # decoder
-        _w_tensor(f, "decoder.positional_embedding", rng.normal((n_text_ctx, n_ts), 0.02).astype(np.float32))
+        pe = rng.normal((n_text_ctx, n_ts), 0.02).astype(np.float32)
         # token embedding doubles as the logits matrix: larger scale so that logits are well separated
-        _w_tensor(f, "decoder.token_embedding.weight", rng.normal((n_vocab, n_ts), 0.05).astype(np.float16))
+        te = rng.normal((n_vocab, n_ts), 0.05).astype(np.float16)
+        if plant:
+            pe = np.stack([12.0 * te[planted_token(p)].astype(np.float32) for p in range(n_text_ctx)])
+        _w_tensor(f, "decoder.positional_embedding", pe)
+        _w_tensor(f, "decoder.token_embedding.weight", te)
+        out_scale = 0.02 if plant else 1.0
         vec("decoder.ln.weight", n_ts, 0.02, 1.0)
         vec("decoder.ln.bias", n_ts)
         for i in range(n_tl):
             p = f"decoder.blocks.{i}."
             vec(p + "mlp_ln.weight", n_ts, 0.02, 1.0); vec(p + "mlp_ln.bias", n_ts)
             mat(p + "mlp.0.weight", 4 * n_ts, n_ts); vec(p + "mlp.0.bias", 4 * n_ts)
-            mat(p + "mlp.2.weight", n_ts, 4 * n_ts); vec(p + "mlp.2.bias", n_ts)
+            omat(p + "mlp.2.weight", n_ts, 4 * n_ts); vec(p + "mlp.2.bias", n_ts, 0.02 * out_scale)
             vec(p + "attn_ln.weight", n_ts, 0.02, 1.0); vec(p + "attn_ln.bias", n_ts)
             mat(p + "attn.query.weight", n_ts, n_ts); vec(p + "attn.query.bias", n_ts)
             mat(p + "attn.key.weight", n_ts, n_ts)
             mat(p + "attn.value.weight", n_ts, n_ts); vec(p + "attn.value.bias", n_ts)
-            mat(p + "attn.out.weight", n_ts, n_ts); vec(p + "attn.out.bias", n_ts)
+            omat(p + "attn.out.weight", n_ts, n_ts); vec(p + "attn.out.bias", n_ts, 0.02 * out_scale)
             vec(p + "cross_attn_ln.weight", n_ts, 0.02, 1.0); vec(p + "cross_attn_ln.bias", n_ts)
             mat(p + "cross_attn.query.weight", n_ts, n_ts); vec(p + "cross_attn.query.bias", n_ts)
             mat(p + "cross_attn.key.weight", n_ts, n_ts)
             mat(p + "cross_attn.value.weight", n_ts, n_ts); vec(p + "cross_attn.value.bias", n_ts)
-            mat(p + "cross_attn.out.weight", n_ts, n_ts); vec(p + "cross_attn.out.bias", n_ts)
+            omat(p + "cross_attn.out.weight", n_ts, n_ts); vec(p + "cross_attn.out.bias", n_ts, 0.02 * out_scale)
 
 
-def make_model(arch: str, qtype: str, out_dir: Path | None = None, seed: int = 1234, quantize_bin: Path | None = None) -> Path:
-    """Create (or reuse) <out_dir>/synth-<arch>-<qtype>.bin and return its path."""
+def make_model(arch: str, qtype: str, out_dir: Path | None = None, seed: int = 1234, quantize_bin: Path | None = None, plant: bool = False) -> Path:
+    """Create (or reuse) <out_dir>/synth-<arch>[-planted]-<qtype>.bin and return its path."""
     assert arch in ARCHS and qtype in QTYPES
     out_dir = Path(out_dir or os.environ.get("WHISPER_SYNTH_DIR", "/tmp/whisper_synth"))
     out_dir.mkdir(parents=True, exist_ok=True)
-    f16 = out_dir / f"synth-{arch}-f16.bin"
+    tag = f"{arch}-planted" if plant else arch
+    f16 = out_dir / f"synth-{tag}-f16.bin"
     if not f16.exists():
         tmp = f16.with_suffix(".tmp")
-        write_f16_model(tmp, arch, seed)
+        write_f16_model(tmp, arch, seed, plant)
         tmp.rename(f16)
     if qtype == "f16":
         return f16
-    q = out_dir / f"synth-{arch}-{qtype}.bin"
+    q = out_dir / f"synth-{tag}-{qtype}.bin"
     if not q.exists():
         # the reference application's own quantizer, installed next to the unmodified libwhisper the plugin drops into
         qb = Path(quantize_bin or ROOT / "whisper.cpp_amd" / "host" / "_whisper" / "whisper-quantize")
@@ -185,5 +208,6 @@ if __name__ == "__main__":
     ap.add_argument("--qtype", default="q5_0", choices=QTYPES)
     ap.add_argument("--out-dir", default=None)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--plant", action="store_true", help="large-margin model with a known transcript (see write_f16_model)")
     a = ap.parse_args()
-    print(make_model(a.arch, a.qtype, a.out_dir, a.seed))
+    print(make_model(a.arch, a.qtype, a.out_dir, a.seed, plant=a.plant))

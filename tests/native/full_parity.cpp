@@ -6,6 +6,7 @@
 #include "whisper.h"
 #include "ggml-backend.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -29,7 +30,16 @@ static std::vector<float> synth_pcm(int n) {
     return x;
 }
 
-static std::vector<int> run(const char * model, bool gpu, int strategy, int beam, const std::vector<float> & pcm, int max_tokens, int n_threads = 8) {
+// greedy runs: the logits every decoding step sampled from (whisper's own hook, include/whisper.h:474-482: called once per decoder and
+// step, before the sampler's filters), so that a divergence of two back ends can be judged by the margin at the step where it happens
+struct step_logits { std::vector<std::vector<float>> rows; int n_vocab = 0; };
+static void capture_logits(struct whisper_context * ctx, struct whisper_state *, const whisper_token_data *, int, float * logits, void * ud) {
+    step_logits * sl = (step_logits *) ud;
+    if (!sl->n_vocab) sl->n_vocab = whisper_n_vocab(ctx);
+    if (sl->rows.size() < 512) sl->rows.emplace_back(logits, logits + sl->n_vocab);
+}
+
+static std::vector<int> run(const char * model, bool gpu, int strategy, int beam, const std::vector<float> & pcm, int max_tokens, int n_threads = 8, step_logits * cap = nullptr) {
     whisper_context_params cp = whisper_context_default_params();
     cp.use_gpu = gpu; cp.gpu_device = 0; cp.flash_attn = true;
     whisper_context * ctx = whisper_init_from_file_with_params(model, cp);
@@ -40,6 +50,7 @@ static std::vector<int> run(const char * model, bool gpu, int strategy, int beam
     p.temperature = 0.0f; p.temperature_inc = 0.0f;            // no temperature fallback: one deterministic pass
     p.max_tokens = max_tokens; p.language = "en";
     p.greedy.best_of = 1; p.beam_search.beam_size = beam;
+    if (cap) { p.logits_filter_callback = capture_logits; p.logits_filter_callback_user_data = cap; }
     if (whisper_full(ctx, p, pcm.data(), (int) pcm.size()) != 0) { fprintf(stderr, "whisper_full failed\n"); exit(4); }
     std::vector<int> toks;
     for (int s = 0; s < whisper_full_n_segments(ctx); s++)
@@ -59,16 +70,38 @@ int main(int argc, char ** argv) {
     printf("{\"model\": \"%s\"", argv[1]);
     const struct { const char * name; int strategy, beam; } modes[] = { { "greedy", WHISPER_SAMPLING_GREEDY, 1 }, { "beam5", WHISPER_SAMPLING_BEAM_SEARCH, 5 } };
     for (const auto & m : modes) {
-        const std::vector<int> a = run(argv[1], false, m.strategy, m.beam, pcm, max_tokens);
+        const bool greedy = m.beam == 1;
+        step_logits la, lb;
+        const std::vector<int> a = run(argv[1], false, m.strategy, m.beam, pcm, max_tokens, 8, greedy ? &la : nullptr);
         // self-test with FULL_PARITY_THREADS_B=n: reference CPU path with 8 threads against the reference CPU path with n
         // threads (different f32 summation order only) — how stable free-running decoding of this model is in the reference itself
         const int tb = selftest && getenv("FULL_PARITY_THREADS_B") ? atoi(getenv("FULL_PARITY_THREADS_B")) : 8;
         // self-test with FULL_PARITY_PERTURB=eps: the reference against itself on the signal scaled by (1 + eps)
         std::vector<float> pcm_b = pcm;
         if (selftest && getenv("FULL_PARITY_PERTURB")) { const float e = 1.0f + (float) atof(getenv("FULL_PARITY_PERTURB")); for (auto & x : pcm_b) x *= e; }
-        const std::vector<int> b = run(argv[1], !selftest, m.strategy, m.beam, pcm_b, max_tokens, tb);
+        const std::vector<int> b = run(argv[1], !selftest, m.strategy, m.beam, pcm_b, max_tokens, tb, greedy ? &lb : nullptr);
         size_t same = 0; while (same < a.size() && same < b.size() && a[same] == b[same]) same++;
-        printf(",\n \"%s\": {\"n_cpu\": %zu, \"n_gpu\": %zu, \"identical_prefix\": %zu, \"cpu\": [", m.name, a.size(), b.size(), same);
+        printf(",\n \"%s\": {\"n_cpu\": %zu, \"n_gpu\": %zu, \"identical_prefix\": %zu, ", m.name, a.size(), b.size(), same);
+        if (greedy) {
+            // steps 0 .. first divergence were computed on the SAME token prefix by both back ends: per step the reference's top-2 margin
+            // and the largest logit difference; a divergence is explained by a near-tie when margin <= 4 x difference AT that step
+            const size_t n = std::min(std::min(la.rows.size(), lb.rows.size()), same + 1);
+            double min_margin = 1e30, max_diff = 0, div_margin = -1, div_diff = -1;
+            for (size_t s = 0; s < n; s++) {
+                const std::vector<float> & x = la.rows[s], & y = lb.rows[s];
+                float t1 = -INFINITY, t2 = -INFINITY; double dmax = 0;
+                for (size_t i = 0; i < x.size(); i++) {
+                    if (!std::isfinite(x[i]) || !std::isfinite(y[i])) continue;
+                    if (x[i] > t1) { t2 = t1; t1 = x[i]; } else if (x[i] > t2) t2 = x[i];
+                    dmax = std::max(dmax, (double) fabsf(x[i] - y[i]));
+                }
+                min_margin = std::min(min_margin, (double) (t1 - t2)); max_diff = std::max(max_diff, dmax);
+                if (s == same) { div_margin = t1 - t2; div_diff = dmax; }
+            }
+            printf("\"steps_compared\": %zu, \"min_margin\": %.6g, \"max_logit_diff\": %.6g, \"divergence_margin\": %.6g, \"divergence_logit_diff\": %.6g, ",
+                   n, n ? min_margin : -1.0, max_diff, div_margin, div_diff);
+        }
+        printf("\"cpu\": [");
         for (size_t i = 0; i < a.size(); i++) printf("%s%d", i ? ", " : "", a[i]);
         printf("], \"gpu\": [");
         for (size_t i = 0; i < b.size(); i++) printf("%s%d", i ? ", " : "", b[i]);

@@ -383,6 +383,63 @@ int main(int argc, char ** argv) {
         ggml_tensor * x = b.randn(GGML_TYPE_F32, {128, 4, 17});
         ggml_tensor * pos = b.leaf(GGML_TYPE_I32, {17}, [](int64_t i) { return (float) (i * 97 + 3); });
         return std::vector<ggml_tensor *>{ ggml_rope_ext(b.ctx, x, pos, nullptr, 96, 2, 2048, 500000.0f, 0.25f, 1.0f, 1.1f, 32.0f, 1.0f) }; });
+    // multi-position rope (ggml_rope_multi: MROPE 8, VISION 24, IMROPE 40; ggml/include/ggml.h:250-254) — not on whisper's graph, op-level only
+    struct mr_case { const char * name; int mode, ne0, n_dims; int sect[4]; };
+    const mr_case mr_cases[] = { { "rope_mrope", 8, 128, 128, { 16, 24, 24, 0 } }, { "rope_mrope_partial", 8, 128, 64, { 8, 12, 12, 0 } }, { "rope_imrope", 40, 128, 128, { 24, 20, 20, 0 } },
+                                 { "rope_vision", 24, 64, 32, { 16, 16, 0, 0 } }, { "rope_vision_4sect", 24, 80, 40, { 10, 10, 10, 10 } } };
+    for (const mr_case & mc : mr_cases) {
+        run_case(mc.name, [=](builder & b) {
+            const int n_pos = 23;
+            ggml_tensor * x = b.randn(GGML_TYPE_F32, {mc.ne0, 6, n_pos});
+            ggml_tensor * pos = b.leaf(GGML_TYPE_I32, {4 * n_pos}, [=](int64_t i) { const int s = (int) (i / n_pos), p = (int) (i % n_pos); return (float) (s == 0 ? p * 3 + 1 : (s == 1 ? p / 5 + 2 : (s == 2 ? p % 5 + 7 : p + 11))); });
+            int sect[4] = { mc.sect[0], mc.sect[1], mc.sect[2], mc.sect[3] };
+            return std::vector<ggml_tensor *>{ ggml_rope_multi(b.ctx, x, pos, nullptr, mc.n_dims, sect, mc.mode, 4096, 10000.0f, 1.0f, 0.0f, 1.0f, 32.0f, 1.0f) }; });
+    }
+    // ---------------- the ops of the voice-activity-detection graph (src/whisper.cpp:4545-4680).  whisper_vad_init_context forces
+    // use_gpu = false (:4700-4704), so these never reach a GPU backend through the library: they are checked here, op by op and as the
+    // graph's three sub-graphs with the silero model's shapes (tests/test-vad.cpp:31,39 is the reference's own KAT of the CPU path) ----
+    run_case("unary_relu", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_relu(b.ctx, b.randn(GGML_TYPE_F32, {129, 33}, 2.0f)) }; });
+    run_case("unary_sigmoid", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_sigmoid(b.ctx, b.randn(GGML_TYPE_F32, {128, 7}, 4.0f)) }; });
+    run_case("unary_tanh", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_tanh(b.ctx, b.randn(GGML_TYPE_F32, {128, 7}, 3.0f)) }; });
+    run_case("unary_sqrt", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_sqrt(b.ctx, b.leaf(GGML_TYPE_F32, {4, 129}, [](int64_t i) { return 0.01f * (float) (i % 977) + 1e-3f; })) }; });
+    run_case("pad_reflect_1d", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_pad_reflect_1d(b.ctx, b.randn(GGML_TYPE_F32, {512, 3}), 64, 64) }; });
+    run_case("vad_stft_magnitude", [](builder & b) {
+        // frame [512, 1] -> reflect pad 64 -> conv1d with the STFT basis [256 taps, 1, 258] stride 128 -> magnitude of the 129 bins
+        ggml_tensor * frame = b.randn(GGML_TYPE_F32, {512, 1}, 0.3f);
+        ggml_tensor * basis = b.randn(GGML_TYPE_F16, {256, 1, 258}, 0.06f);
+        ggml_tensor * padded = ggml_pad_reflect_1d(b.ctx, frame, 64, 64);
+        ggml_tensor * stft = ggml_conv_1d(b.ctx, basis, padded, 128, 0, 1);
+        const int cutoff = 129;
+        ggml_tensor * re = ggml_view_2d(b.ctx, stft, 4, cutoff, stft->nb[1], 0);
+        ggml_tensor * im = ggml_view_2d(b.ctx, stft, 4, cutoff, stft->nb[1], cutoff * stft->nb[1]);
+        return std::vector<ggml_tensor *>{ ggml_sqrt(b.ctx, ggml_add(b.ctx, ggml_mul(b.ctx, re, re), ggml_mul(b.ctx, im, im))) }; });
+    run_case("vad_encoder", [](builder & b) {
+        ggml_tensor * cur = b.leaf(GGML_TYPE_F32, {4, 129}, [](int64_t i) { return 0.02f * (float) ((i * 37) % 101); });
+        const int chans[5] = { 129, 128, 64, 64, 128 }, strides[4] = { 1, 2, 2, 1 };
+        for (int l = 0; l < 4; l++) {
+            ggml_tensor * w = b.randn(GGML_TYPE_F16, {3, chans[l], chans[l + 1]}, 1.0f / sqrtf(3.0f * chans[l]));
+            ggml_tensor * bias = b.randn(GGML_TYPE_F32, {chans[l + 1]}, 0.1f);
+            cur = ggml_conv_1d(b.ctx, w, cur, strides[l], 1, 1);
+            cur = ggml_relu(b.ctx, ggml_add(b.ctx, cur, ggml_reshape_3d(b.ctx, bias, 1, chans[l + 1], 1)));
+        }
+        return std::vector<ggml_tensor *>{ cur }; });
+    run_case("vad_lstm_cell", [](builder & b) {
+        const int hdim = 128;
+        ggml_tensor * x = b.randn(GGML_TYPE_F32, {1, 128}, 0.8f);                    // the encoder's first time step, [1, 128] view
+        ggml_tensor * w_ih = b.randn(GGML_TYPE_F32, {128, 4 * hdim}, 0.09f), * b_ih = b.randn(GGML_TYPE_F32, {4 * hdim}, 0.1f);
+        ggml_tensor * w_hh = b.randn(GGML_TYPE_F32, {hdim, 4 * hdim}, 0.09f), * b_hh = b.randn(GGML_TYPE_F32, {4 * hdim}, 0.1f);
+        ggml_tensor * h = b.randn(GGML_TYPE_F32, {hdim}, 0.5f), * c = b.randn(GGML_TYPE_F32, {hdim}, 0.5f);
+        ggml_tensor * gates = ggml_add(b.ctx, ggml_add(b.ctx, ggml_mul_mat(b.ctx, w_ih, ggml_cont(b.ctx, ggml_transpose(b.ctx, x))), b_ih),
+                                       ggml_add(b.ctx, ggml_mul_mat(b.ctx, w_hh, h), b_hh));
+        const size_t hs = ggml_row_size(gates->type, hdim);
+        ggml_tensor * i_t = ggml_sigmoid(b.ctx, ggml_view_1d(b.ctx, gates, hdim, 0 * hs)), * f_t = ggml_sigmoid(b.ctx, ggml_view_1d(b.ctx, gates, hdim, 1 * hs));
+        ggml_tensor * g_t = ggml_tanh(b.ctx, ggml_view_1d(b.ctx, gates, hdim, 2 * hs)),    * o_t = ggml_sigmoid(b.ctx, ggml_view_1d(b.ctx, gates, hdim, 3 * hs));
+        ggml_tensor * c_out = ggml_add(b.ctx, ggml_mul(b.ctx, f_t, c), ggml_mul(b.ctx, i_t, g_t));
+        ggml_tensor * out = ggml_mul(b.ctx, o_t, ggml_tanh(b.ctx, c_out));
+        // final 1x1 convolution + sigmoid of the graph's tail
+        ggml_tensor * fw = b.randn(GGML_TYPE_F16, {1, hdim, 1}, 0.2f), * fb = b.randn(GGML_TYPE_F32, {1}, 0.1f);
+        ggml_tensor * prob = ggml_sigmoid(b.ctx, ggml_add(b.ctx, ggml_conv_1d(b.ctx, fw, ggml_relu(b.ctx, ggml_reshape_2d(b.ctx, out, 1, hdim)), 1, 0, 1), fb));
+        return std::vector<ggml_tensor *>{ c_out, out, prob }; });
     run_case("concat_dim2", [](builder & b) { return std::vector<ggml_tensor *>{ ggml_concat(b.ctx, b.randn(GGML_TYPE_F32, {50, 7, 3}), b.randn(GGML_TYPE_F32, {50, 7, 2}), 2) }; });
 
     // ---------------- fused decoder / encoder sub-graphs (sched mode exercises the fusion planner) ----------------

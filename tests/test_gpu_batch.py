@@ -335,6 +335,44 @@ def test_multi_state_attention_is_bit_identical_to_one_launch_per_state(gpu, S, 
         assert np.array_equal(got[s].view(np.uint32), singles[s].view(np.uint32)), s
 
 
+@pytest.mark.parametrize("S,H,kvs,masked", [(8, 20, (1, 17, 128, 129, 200, 255, 256, 448), True), (5, 8, (33, 512, 64, 300, 2), True), (3, 6, (100, 100, 100), False)])
+def test_self_attention_straight_to_planes_is_bit_identical_to_partials_combine_quantize(gpu, S, H, kvs, masked):
+    """mi355x_flash_attn_planes (one launch) writes the same Q8_0 plane bytes as multi-state attention partials -> mi355x_act_prepare"""
+    ctx, ka, torch = gpu
+    D, K = 64, H * 64
+    rng = np.random.default_rng(S * 17 + H)
+    n_ctx = max(kvs) + 5
+    st = (ka.AttnState * S)()
+    keep = []
+    for s in range(S):
+        q = (rng.standard_normal((1, H, D)) * 0.6).astype(np.float32)
+        k = (rng.standard_normal((n_ctx, H, D)) * 0.6).astype(np.float16)
+        v = rng.standard_normal((n_ctx, H, D)).astype(np.float16)
+        m = np.where(rng.random(n_ctx) < 0.2, -np.inf, 0.0).astype(np.float16)
+        m[0] = 0
+        q_d, k_d, v_d, m_d = (dev(torch, a) for a in (q, k, v, m))
+        keep += [q_d, k_d, v_d, m_d]
+        st[s].q, st[s].k, st[s].v, st[s].mask, st[s].n_kv = q_d.data_ptr(), k_d.data_ptr(), v_d.data_ptr(), (m_d.data_ptr() if masked else 0), kvs[s]
+        if s == 0:
+            tq = ka.tensor(q_d.data_ptr(), ka.F32, [D, 1, H], [4, H * D * 4, D * 4, H * D * 4])
+            tk = ka.tensor(k_d.data_ptr(), ka.F16, [D, kvs[s], H], [2, H * D * 2, D * 2, n_ctx * H * D * 2])
+            tv = ka.tensor(v_d.data_ptr(), ka.F16, [D, kvs[s], H], [2, H * D * 2, D * 2, n_ctx * H * D * 2])
+    nbytes = ka.lib().mi355x_act_planes_bytes(ka.Q5_0, K, S)
+    pa = torch.zeros(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    pb = torch.zeros(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    parts = ka.AttnPartials()
+    ctx.check(ka.lib().mi355x_flash_attn_partial_multi(ctx.h, S, st, C.byref(tq), C.byref(tk), C.byref(tv), 0.125, C.byref(parts)), "partial_multi")
+    a = ka.ActDesc()
+    a.K, a.T, a.wtype = K, S, ka.Q5_0
+    a.attn_part_o, a.attn_part_ml, a.attn_nparts = parts.part_o, parts.part_ml, parts.nparts
+    ctx.check(ka.lib().mi355x_act_prepare(ctx.h, C.byref(a), pa.data_ptr()), "act_prepare(combine)")
+    ctx.check(ka.lib().mi355x_flash_attn_planes(ctx.h, S, st, C.byref(tq), C.byref(tk), C.byref(tv), 0.125, pb.data_ptr()), "flash_attn_planes")
+    ctx.sync()
+    A, B = pa.cpu().numpy()[:nbytes], pb.cpu().numpy()[:nbytes]
+    assert A.any() and np.array_equal(A, B), int((A != B).sum())
+
+
 @pytest.mark.parametrize("t", ["q5_0", "q4_K", "f16"])
 def test_multi_state_step_head_matches_get_rows_and_cast(gpu, oracle, t):
     ctx, ka, torch = gpu

@@ -853,9 +853,10 @@ static int  run_node(mi_backend_ctx * b, const ggml_tensor * n);
 
 
 // is this chain the vocabulary projection whose rows the caller reads back (src/whisper.cpp:2957-2963)?  Then its rows are mirrored.
-static bool mirror_wanted(const mm_chain & ch, int64_t T) {
+// (whisper does not flag the logits as a graph output; they are the LAST node of the decoder graph, src/whisper.cpp:2827-2840)
+static bool mirror_wanted(const ggml_cgraph * g, const mm_chain & ch, int64_t T) {
     const ggml_tensor * l = ch.last;
-    return g_mirror_on && (l->flags & GGML_TENSOR_FLAG_OUTPUT) && l == ch.mm && l->type == GGML_TYPE_F32 && l->ne[0] > 8192 && (int64_t) l->nb[1] == l->ne[0]*4 &&
+    return g_mirror_on && ch.end == g->n_nodes - 1 && l == ch.mm && l->type == GGML_TYPE_F32 && l->ne[0] > 8192 && (int64_t) l->nb[1] == l->ne[0]*4 &&
            l->ne[2] == 1 && l->ne[3] == 1 && T >= 1 && T <= MI355X_MAX_COLS && (size_t) (l->ne[0]*4*T) <= MI_MIRROR_CAP;
 }
 
@@ -896,7 +897,7 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
     //  two launches it replaced, 1.478 -> 1.435 ms/token with it switched off (profiles/r02_decode_env_sweep_final.txt): 64 rows of
     //  W_q per workgroup serialise what 256 workgroups otherwise do in parallel, and a dependent boundary costs only ~1.5 us.  Removed.)
     mi355x_gemv_cols mcols;
-    if (n == 1 && mirror_wanted(ch[0], T)) {
+    if (n == 1 && mirror_wanted(g, ch[0], T)) {
         if (char * md = mi_mirror_dev(b)) {
             memset(&mcols, 0, sizeof(mcols));
             for (int t = 0; t < (int) T; t++) mcols.mirror[t] = md + (size_t) t * (size_t) ch[0].last->ne[0] * 4;
@@ -1006,8 +1007,16 @@ static bool mi_supports_op_impl(const ggml_tensor * op) {
             return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_F32 && ggml_are_same_shape(op, s0);
         case GGML_OP_SCALE:
             return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && ggml_is_contiguous(op) && ggml_is_contiguous(s0);
-        case GGML_OP_UNARY:
-            return ggml_get_unary_op(op) == GGML_UNARY_OP_GELU && op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && ggml_is_contiguous(op) && ggml_is_contiguous(s0);
+        case GGML_OP_UNARY: {
+            // GELU: the whisper graphs; ReLU / sigmoid / tanh: the voice-activity-detection graph (src/whisper.cpp:4545-4680)
+            const ggml_unary_op u = ggml_get_unary_op(op);
+            return (u == GGML_UNARY_OP_GELU || u == GGML_UNARY_OP_RELU || u == GGML_UNARY_OP_SIGMOID || u == GGML_UNARY_OP_TANH) &&
+                   op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && ggml_is_contiguous(op) && ggml_is_contiguous(s0);
+        }
+        case GGML_OP_SQRT:
+            return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && ggml_is_contiguous(op) && ggml_is_contiguous(s0);
+        case GGML_OP_PAD_REFLECT_1D:
+            return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && op->op_params[0] < s0->ne[0] && op->op_params[1] < s0->ne[0];
         case GGML_OP_NORM:
             return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s0->nb[0] == 4 && op->nb[0] == 4;
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP:
@@ -1025,7 +1034,8 @@ static bool mi_supports_op_impl(const ggml_tensor * op) {
                    (!s1 || ((s1->type == GGML_TYPE_F32 || s1->type == GGML_TYPE_F16) && s1->ne[0] == s0->ne[0]));
         case GGML_OP_ROPE: {
             const int mode = op->op_params[2];
-            return (mode == 0 || mode == 2) && op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s0->nb[0] == 4 && op->op_params[15] == 0;
+            if (mode == 24 && op->op_params[1] != s0->ne[0] / 2) return false;
+            return (mode == 0 || mode == 2 || mode == 8 || mode == 24 || mode == 40) && op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s0->nb[0] == 4 && op->op_params[15] == 0;
         }
         case GGML_OP_CONCAT:
             return op->type == GGML_TYPE_F32 && s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_F32;
@@ -1047,7 +1057,21 @@ static int run_node(mi_backend_ctx * b, const ggml_tensor * n) {
         }
         case GGML_OP_UNARY: {
             mi355x_tensor a = to_mt(n->src[0]), d = to_mt(n);
-            return mi355x_gelu(k, &a, &d);
+            switch (ggml_get_unary_op(n)) {
+                case GGML_UNARY_OP_GELU:    return mi355x_gelu(k, &a, &d);
+                case GGML_UNARY_OP_RELU:    return mi355x_unary(k, MI355X_UNARY_RELU, &a, &d);
+                case GGML_UNARY_OP_SIGMOID: return mi355x_unary(k, MI355X_UNARY_SIGMOID, &a, &d);
+                case GGML_UNARY_OP_TANH:    return mi355x_unary(k, MI355X_UNARY_TANH, &a, &d);
+                default: return MI355X_E_UNSUPPORTED;
+            }
+        }
+        case GGML_OP_SQRT: {
+            mi355x_tensor a = to_mt(n->src[0]), d = to_mt(n);
+            return mi355x_unary(k, MI355X_UNARY_SQRT, &a, &d);
+        }
+        case GGML_OP_PAD_REFLECT_1D: {
+            mi355x_tensor a = to_mt(n->src[0]), d = to_mt(n);
+            return mi355x_pad_reflect_1d(k, &a, &d, n->op_params[0], n->op_params[1]);
         }
         case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
             mi355x_tensor a = to_mt(n->src[0]), d = to_mt(n);
@@ -1071,6 +1095,7 @@ static int run_node(mi_backend_ctx * b, const ggml_tensor * n) {
             p.n_dims = n->op_params[1]; p.mode = n->op_params[2]; p.n_ctx_orig = n->op_params[4];
             memcpy(&p.freq_base, n->op_params + 5, 4); memcpy(&p.freq_scale, n->op_params + 6, 4); memcpy(&p.ext_factor, n->op_params + 7, 4);
             memcpy(&p.attn_factor, n->op_params + 8, 4); memcpy(&p.beta_fast, n->op_params + 9, 4); memcpy(&p.beta_slow, n->op_params + 10, 4);
+            memcpy(p.sections, n->op_params + 11, sizeof(int32_t) * 4);
             mi355x_tensor x = to_mt(n->src[0]), pos = to_mt(n->src[1]), d = to_mt(n);
             return mi355x_rope(k, &x, &pos, n->src[2] ? (const float *) n->src[2]->data : nullptr, &d, &p);
         }
@@ -1172,7 +1197,7 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
     d.K = (int) K; d.T = cs.T; d.nseg = n; d.x_planes = p0; d.cols = &cols;
     for (int s = 0; s < n; s++) q_fill_seg(cs, ch[s], s, d, cols);
     if (pout) { d.planes_out = p1; d.planes_out_only = only ? 1 : 0; }
-    bool mirror = n == 1 && cs.owner[0] && mirror_wanted(ch[0], cs.S > 1 ? 1 : cs.T);
+    bool mirror = n == 1 && cs.owner[0] && mirror_wanted(g, ch[0], cs.S > 1 ? 1 : cs.T);
     if (mirror) {
         const size_t rowb = (size_t) ch[0].last->ne[0] * 4;
         for (int c = 0; c < cs.T && mirror; c++) {
@@ -1216,28 +1241,45 @@ static bool q_attn_proj(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, in
     mi355x_attn_partials parts;
     mi355x_tensor mq = to_mt(q), mk = to_mt(kk), mv = to_mt(v), mm_;
     int rc;
-    if (cs.S > 1) {
-        mi355x_attn_state st[MI355X_MAX_COLS]; memset(st, 0, sizeof(st));
-        for (int c = 0; c < cs.T; c++) {
+    void * p0 = mi355x_act_scratch(k, 0);
+    if (!p0) { rc_out = (int) hipErrorOutOfMemory; return true; }
+    // every column's operands (own graph in a cross-state batch; the token columns of the one graph otherwise)
+    mi355x_attn_state st[MI355X_MAX_COLS]; memset(st, 0, sizeof(st));
+    int max_kv = 0;
+    for (int c = 0; c < cs.T; c++) {
+        if (cs.S > 1) {
             const ggml_tensor * qc = cs_tensor(cs, c, i, 0), * kc = cs_tensor(cs, c, i, 1), * vc = cs_tensor(cs, c, i, 2), * mc = cs_tensor(cs, c, i, 3);
             if (kc->nb[1] != kk->nb[1] || kc->nb[2] != kk->nb[2] || vc->nb[1] != v->nb[1] || vc->nb[2] != v->nb[2] || qc->nb[2] != q->nb[2] || (mc != nullptr) != (m != nullptr) || vc->ne[1] != kc->ne[1]) {
                 rc_out = (int) hipErrorInvalidValue; GGML_LOG_ERROR("ggml-mi355x: cross-state batch: attention operands of the states are laid out differently\n"); return true;
             }
             st[c].q = qc->data; st[c].k = kc->data; st[c].v = vc->data; st[c].mask = mc ? mc->data : nullptr; st[c].n_kv = (int32_t) kc->ne[1];
+        } else {
+            st[c].q = (const char *) q->data + (int64_t) c * (int64_t) q->nb[1]; st[c].k = kk->data; st[c].v = v->data;
+            st[c].mask = m ? (const char *) m->data + (int64_t) c * (int64_t) m->nb[1] : nullptr; st[c].n_kv = (int32_t) kk->ne[1];
         }
-        rc = mi355x_flash_attn_partial_multi(k, cs.T, st, &mq, &mk, &mv, scale, &parts);
-    } else {
-        if (m) mm_ = to_mt(m);
-        rc = mi355x_flash_attn_partial(k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
+        max_kv = std::max(max_kv, (int) st[c].n_kv);
     }
-    if (rc == MI355X_E_UNSUPPORTED) return false;
-    if (rc) { rc_out = rc; return true; }
-    void * p0 = mi355x_act_scratch(k, 0);
-    if (!p0) { rc_out = (int) hipErrorOutOfMemory; return true; }
-    mi355x_act_desc a; memset(&a, 0, sizeof(a));
-    a.K = (int) (H*64); a.T = cs.T; a.wtype = (int32_t) w->type;
-    a.attn_part_o = parts.part_o; a.attn_part_ml = parts.part_ml; a.attn_nparts = parts.nparts;
-    rc = mi355x_act_prepare(k, &a, p0);
+    // self-attention (few keys): ONE launch from q / K / V to the projection's activation planes
+    static const bool self_planes = env_flag("GGML_MI355X_SELF_ATTN_PLANES", true);
+    bool have_planes = false;
+    if (self_planes && max_kv <= 512 && w->type != GGML_TYPE_Q4_K && (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2))) {
+        rc = mi355x_flash_attn_planes(k, cs.T, st, &mq, &mk, &mv, scale, p0);
+        if (rc == 0) have_planes = true;
+        else if (rc != MI355X_E_UNSUPPORTED) { rc_out = rc; return true; }
+    }
+    if (!have_planes) {
+        if (cs.S > 1) rc = mi355x_flash_attn_partial_multi(k, cs.T, st, &mq, &mk, &mv, scale, &parts);
+        else {
+            if (m) mm_ = to_mt(m);
+            rc = mi355x_flash_attn_partial(k, &mq, &mk, &mv, m ? &mm_ : nullptr, scale, &parts);
+        }
+        if (rc == MI355X_E_UNSUPPORTED) return false;
+        if (rc) { rc_out = rc; return true; }
+        mi355x_act_desc a; memset(&a, 0, sizeof(a));
+        a.K = (int) (H*64); a.T = cs.T; a.wtype = (int32_t) w->type;
+        a.attn_part_o = parts.part_o; a.attn_part_ml = parts.part_ml; a.attn_nparts = parts.nparts;
+        rc = mi355x_act_prepare(k, &a, p0);
+    }
     mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
     mi355x_gemv_cols cols; memset(&cols, 0, sizeof(cols));
     d.K = (int) (H*64); d.T = cs.T; d.nseg = 1; d.x_planes = p0; d.cols = &cols;

@@ -657,6 +657,155 @@ extern "C" int mi355x_flash_attn_partial_multi(mi355x_ctx * ctx, int S, const mi
     return 0;
 }
 
+// Self-attention of a decoder step (n_kv <= 512) COMPLETE in one launch per layer: one 16-wave workgroup per (head, column) — wave w takes
+// keys [32w, 32w + 32) exactly as a wave of k_fattn_dec does, the four waves of a 128-key chunk are merged into that chunk's record in
+// LDS, the records are combined and the head's 64 outputs leave as two Q8_0 blocks of the output projection's activation planes.
+// Arithmetic = k_fattn_dec -> (records) -> k_act_prepare MODE 2 -> dg_q8_0_store, statement for statement: bit-identical to the three
+// launches it replaces (attention, combine, quantize), one dependent launch less per layer.
+__global__ void __launch_bounds__(1024) k_fattn_self_q(const FDMArgs a) {
+    __shared__ __attribute__((aligned(16))) float wo[16][64];
+    __shared__ float wml[16][2];
+    __shared__ __attribute__((aligned(16))) float ro[4][64];
+    __shared__ float rml[4][2];
+    __shared__ __attribute__((aligned(16))) float xo[64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int kg = lane >> 3, dc = lane & 7;
+    const int hq = blockIdx.x, hk = hq / a.rk2, hv = hq / a.rv2;
+    const int si = blockIdx.y;
+    const FDMState & st = a.st[si];
+    const int n_kv = st.n_kv;
+    const bool has_mask = st.m != nullptr;
+    const int kbeg = wave*32;
+    const char * kbase = st.k + (int64_t) hk*a.k_nb2 + dc*16;
+    const char * vbase = st.v + (int64_t) hv*a.v_nb2 + dc*16;
+    uint4 kr[4], vr[4];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int key = kbeg + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
+        kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k_nb1);
+        vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v_nb1);
+    }
+    float qf[8];
+    {
+        const float * qp = (const float *) (st.q + (int64_t) hq*a.q_nb2) + dc*8;
+        const float4 q0 = *(const float4 *) qp, q1 = *(const float4 *) (qp + 4);
+        qf[0] = round_f16(q0.x); qf[1] = round_f16(q0.y); qf[2] = round_f16(q0.z); qf[3] = round_f16(q0.w);
+        qf[4] = round_f16(q1.x); qf[5] = round_f16(q1.y); qf[6] = round_f16(q1.z); qf[7] = round_f16(q1.w);
+    }
+    uint16_t mkh[4];
+    const char * mbase = has_mask ? st.m : st.k;
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int key = kbeg + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
+        mkh[i] = *(const uint16_t *) (mbase + (int64_t) kc*2);
+    }
+    float sc[4];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int key = kbeg + kg + 8*i;
+        const uint32_t w[4] = { kr[i].x, kr[i].y, kr[i].z, kr[i].w };
+        float kf[8];
+        #pragma unroll
+        for (int e = 0; e < 4; e++) { kf[2*e] = h2f((uint16_t) (w[e] & 0xFFFF)); kf[2*e+1] = h2f((uint16_t) (w[e] >> 16)); }
+        float s = 0.0f;
+        #pragma unroll
+        for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[e], s);
+        s = group_sum<8>(s);
+        const float x = s * a.scale + (has_mask ? h2f(mkh[i]) : 0.0f);
+        sc[i] = key < n_kv ? x : -INFINITY;
+    }
+    {
+        float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        m = stride8_max(m);
+        m = fmaxf(m, -1e30f);
+        float l = 0.0f, o[8];
+        #pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float pk = __expf(sc[i] - m);
+            l += pk;
+            const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
+            #pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o[2*e]   = fmaf(pk, h2f((uint16_t) (w[e] & 0xFFFF)), o[2*e]);
+                o[2*e+1] = fmaf(pk, h2f((uint16_t) (w[e] >> 16)),    o[2*e+1]);
+            }
+        }
+        l = stride8_sum(l);
+        #pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = stride8_sum(o[e]);
+        if (kg == 0) {
+            *(float4 *) &wo[wave][dc*8]     = make_float4(o[0], o[1], o[2], o[3]);
+            *(float4 *) &wo[wave][dc*8 + 4] = make_float4(o[4], o[5], o[6], o[7]);
+            if (dc == 0) { wml[wave][0] = m; wml[wave][1] = l; }
+        }
+    }
+    __syncthreads();
+    const int nparts = (n_kv + 127) >> 7;                       // <= 4
+    if (tid < 256) {
+        // chunk p = tid / 64: the merge of its four waves, as at the end of k_fattn_dec
+        const int p = tid >> 6, d = tid & 63, w0i = p*4;
+        const float m0 = wml[w0i][0], m1 = wml[w0i + 1][0], m2 = wml[w0i + 2][0], m3 = wml[w0i + 3][0];
+        const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        const float w0 = __expf(m0 - M), w1 = __expf(m1 - M), w2 = __expf(m2 - M), w3 = __expf(m3 - M);
+        ro[p][d] = fmaf(w3, wo[w0i + 3][d], fmaf(w2, wo[w0i + 2][d], fmaf(w1, wo[w0i + 1][d], w0 * wo[w0i][d])));
+        if (d == 0) {
+            rml[p][0] = M;
+            rml[p][1] = fmaf(w3, wml[w0i + 3][1], fmaf(w2, wml[w0i + 2][1], fmaf(w1, wml[w0i + 1][1], w0 * wml[w0i][1])));
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // combine of the chunk records, as k_act_prepare MODE 2 / k_gemv_row MODE 2 do it
+        float M = -1e30f, L = 0.0f, o = 0.0f;
+        for (int p = 0; p < nparts; p++) M = fmaxf(M, rml[p][0]);
+        for (int p = 0; p < nparts; p++) {
+            const float w = __expf(rml[p][0] - M);
+            L = fmaf(w, rml[p][1], L);
+            o = fmaf(w, ro[p][tid], o);
+        }
+        const float inv = L == 0.0f ? 0.0f : 1.0f / L;
+        xo[tid] = o*inv;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        // the head's 64 values = blocks 2h and 2h + 1 of column si: lane j quantizes values 4j .. 4j + 3 (8 lanes per block)
+        const float4 x4 = *(const float4 *) &xo[tid*4];
+        const float xv[4] = { x4.x, x4.y, x4.z, x4.w };
+        const int K = a.H*64, T = a.S, nb = K >> 5;
+        uint32_t * lo = (uint32_t *) a.part_o, * hi = lo + (size_t) T*nb*4;
+        float * dx = (float *) (hi + (size_t) T*nb*4);
+        int * sx = (int *) (dx + T*nb);
+        dg_q8_0_store(xv, hq*64 + tid*4, si, nb, lo, hi, dx, sx);
+    }
+}
+
+// decoder self-attention for T columns (own q / K / V / mask row / key count each) straight into the Q8_0 planes of the output projection
+extern "C" int mi355x_flash_attn_planes(mi355x_ctx * ctx, int T, const mi355x_attn_state * st, const mi355x_tensor * q, const mi355x_tensor * k,
+                                        const mi355x_tensor * v, float scale, void * planes) {
+    if (T < 1 || T > MI355X_MAX_COLS || !planes || ((uintptr_t) planes % 16)) return MI355X_E_UNSUPPORTED;
+    if (q->type != MI355X_TYPE_F32 || k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
+    if (q->ne[0] != 64 || k->ne[0] != 64 || v->ne[0] != 64 || q->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1) return MI355X_E_UNSUPPORTED;
+    if (q->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2) return MI355X_E_UNSUPPORTED;
+    const int H = (int) q->ne[2];
+    if (H < 1 || H*64 > 2048 || k->ne[2] <= 0 || H % k->ne[2] || v->ne[2] <= 0 || H % v->ne[2]) return MI355X_E_UNSUPPORTED;
+    if ((q->nb[2] | k->nb[1] | k->nb[2] | v->nb[1] | v->nb[2]) % 16) return MI355X_E_UNSUPPORTED;
+    FDMArgs a; memset(&a, 0, sizeof(a));
+    double bytes = 0, flops = 0;
+    for (int s = 0; s < T; s++) {
+        if (!st[s].q || !st[s].k || !st[s].v || st[s].n_kv < 1 || st[s].n_kv > 512) return MI355X_E_UNSUPPORTED;
+        if (((uintptr_t) st[s].q | (uintptr_t) st[s].k | (uintptr_t) st[s].v) % 16 || ((uintptr_t) st[s].mask % 2)) return MI355X_E_UNSUPPORTED;
+        a.st[s].q = (const char *) st[s].q; a.st[s].k = (const char *) st[s].k; a.st[s].v = (const char *) st[s].v; a.st[s].m = (const char *) st[s].mask;
+        a.st[s].n_kv = st[s].n_kv;
+        bytes += 2.0 * st[s].n_kv * 64 * 2 * H + (double) H*64*4; flops += 4.0 * (double) st[s].n_kv * 64 * H;
+    }
+    a.q_nb2 = q->nb[2]; a.k_nb1 = k->nb[1]; a.k_nb2 = k->nb[2]; a.v_nb1 = v->nb[1]; a.v_nb2 = v->nb[2];
+    a.scale = scale; a.S = T; a.H = H; a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]); a.nparts = 0;
+    a.part_o = (float *) planes;            // (the planes travel in the record pointer's slot)
+    return emit(ctx, "fattn_self_q", k_fattn_self_q, dim3(H, T), dim3(1024), 0, a, bytes + (double) T*H*64*1.25, flops);
+}
+
 struct HeadArgs {
     mi355x_head_state st[MI355X_MAX_COLS];
     const char * te; int64_t te_nbt, te_nb1; int te_rows; int te_type;

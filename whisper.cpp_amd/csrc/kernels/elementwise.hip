@@ -68,6 +68,17 @@ extern "C" int mi355x_binary(mi355x_ctx * ctx, int op, const mi355x_tensor * a, 
 // gelu  (ggml-cpu/vec.h:987-1000)
 // -------------------------------------------------------------------------------------------------
 struct UnaryArgs { const float * x; float * y; int64_t n; float s, b; int mode; const uint16_t * tab; };
+// mode 0 scale (+ bias), 1 GELU (f16 table), 2 ReLU, 3 sigmoid, 4 tanh, 5 sqrt — ggml-cpu/unary-ops.cpp:19-53 (op_tanh, op_relu, op_sigmoid, op_sqrt)
+__device__ __forceinline__ float unary_apply(float x, const UnaryArgs & a) {
+    switch (a.mode) {
+        case 0:  return a.b == 0.0f ? x*a.s : x*a.s + a.b;
+        case 1:  return gelu_lut(x, a.tab);
+        case 2:  return x > 0.0f ? x : 0.0f;
+        case 3:  return 1.0f / (1.0f + expf(-x));
+        case 4:  return tanhf(x);
+        default: return sqrtf(x);
+    }
+}
 __global__ void __launch_bounds__(256) k_unary(const UnaryArgs a) {
     for (int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) * 4; i < a.n; i += (int64_t) gridDim.x * 1024) {
         float v[4];
@@ -75,12 +86,12 @@ __global__ void __launch_bounds__(256) k_unary(const UnaryArgs a) {
             const float4 x = *(const float4 *) (a.x + i);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
             #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = a.mode == 0 ? (a.b == 0.0f ? v[j]*a.s : v[j]*a.s + a.b) : gelu_lut(v[j], a.tab);
+            for (int j = 0; j < 4; j++) v[j] = unary_apply(v[j], a);
             *(float4 *) (a.y + i) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
             for (int j = 0; j < 4 && i + j < a.n; j++) {
                 const float x = a.x[i + j];
-                a.y[i + j] = a.mode == 0 ? (a.b == 0.0f ? x*a.s : x*a.s + a.b) : gelu_lut(x, a.tab);
+                a.y[i + j] = unary_apply(x, a);
             }
         }
     }
@@ -95,6 +106,36 @@ static int unary_launch(mi355x_ctx * ctx, const char * name, const mi355x_tensor
 }
 extern "C" int mi355x_scale(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y, float s, float b) { return unary_launch(ctx, "scale", x, y, 0, s, b); }
 extern "C" int mi355x_gelu(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y) { return unary_launch(ctx, "gelu", x, y, 1, 0, 0); }
+extern "C" int mi355x_unary(mi355x_ctx * ctx, int op, const mi355x_tensor * x, const mi355x_tensor * y) {
+    if (op < MI355X_UNARY_RELU || op > MI355X_UNARY_SQRT) return MI355X_E_UNSUPPORTED;
+    return unary_launch(ctx, "unary", x, y, op, 0, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
+// pad_reflect_1d (ggml-cpu/ops.cpp:8149-8180): dst[p0 + i] = x[i];  dst[p0 - k] = x[k];  dst[p0 + n - 1 + k] = x[n - 1 - k]
+// -------------------------------------------------------------------------------------------------
+struct PadReflectArgs { dtensor x, y; int p0, p1; int64_t n; };
+__global__ void __launch_bounds__(256) k_pad_reflect_1d(const PadReflectArgs a) {
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t) gridDim.x * 256) {
+        int64_t r = i;
+        const int64_t i0 = r % a.y.ne[0]; r /= a.y.ne[0];
+        const int64_t i1 = r % a.y.ne[1]; r /= a.y.ne[1];
+        const int64_t i2 = r % a.y.ne[2], i3 = r / a.y.ne[2];
+        const int64_t n0 = a.x.ne[0];
+        int64_t j = i0 - a.p0;
+        if (j < 0) j = -j; else if (j >= n0) j = 2*(n0 - 1) - j;
+        const float v = *(const float *) (a.x.data + j*a.x.nb[0] + i1*a.x.nb[1] + i2*a.x.nb[2] + i3*a.x.nb[3]);
+        *(float *) (a.y.data + i0*a.y.nb[0] + i1*a.y.nb[1] + i2*a.y.nb[2] + i3*a.y.nb[3]) = v;
+    }
+}
+extern "C" int mi355x_pad_reflect_1d(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * y, int p0, int p1) {
+    if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || p0 < 0 || p1 < 0 || p0 >= x->ne[0] || p1 >= x->ne[0] || y->ne[0] != x->ne[0] + p0 + p1 ||
+        y->ne[1] != x->ne[1] || y->ne[2] != x->ne[2] || y->ne[3] != x->ne[3]) return MI355X_E_UNSUPPORTED;
+    PadReflectArgs k = { to_d(x), to_d(y), p0, p1, t_nelements(y) };
+    if (k.n == 0) return 0;
+    const int64_t nb = (k.n + 255) / 256;
+    return emit(ctx, "pad_reflect_1d", k_pad_reflect_1d, dim3((uint32_t) (nb < 8192 ? nb : 8192)), dim3(256), 0, k, (double) k.n * 8, 0);
+}
 
 // -------------------------------------------------------------------------------------------------
 // norm (+ optional affine): one wave per row (ggml-cpu/ops.cpp:3698-3765)
@@ -478,11 +519,32 @@ __global__ void __launch_bounds__(64) k_rope(const RopeArgs a) {
     const int ne0 = (int) a.x.ne[0], n_dims = a.p.n_dims;
     const int lane = threadIdx.x;
     // each lane computes its theta by the same sequential product the CPU uses: theta_p = (((pos*ts)*ts)...)
+    // modes (ggml.h:250-254): 0 NORMAL (adjacent pairs), 2 NEOX (pairs n_dims/2 apart), 8 MROPE / 40 IMROPE (four position streams t, h, w, e
+    // chosen per pair by `sections`, NEOX pairing), 24 VISION (sections restart their own theta, pairs n_dims apart over the whole row) —
+    // ggml_mrope_cache_init + rotate_pairs, ggml-cpu/ops.cpp:5868-5945
+    const int mode = a.p.mode;
+    const bool mrope = (mode & 8) != 0, vision = mode == 24, imrope = mode == 40;
+    const int s0 = a.p.sections[0], s1 = a.p.sections[1], s2 = a.p.sections[2], s3 = a.p.sections[3];
+    const int sect_dims = s0 + s1 + s2 + s3, sec_w = s1 + s0, sec_e = s2 + sec_w;
+    const int64_t ne2 = a.x.ne[2];
     for (int pr = lane; pr < ne0/2; pr += 64) {
         const int i0 = 2*pr;
-        if (i0 < n_dims) {
-            float theta = (float) a.pos[i2];
-            for (int q = 0; q < pr; q++) theta *= a.theta_scale;
+        if (vision || i0 < n_dims) {
+            float theta; int nmul = pr;
+            if (!mrope) theta = (float) a.pos[i2];
+            else {
+                const int sector = pr % sect_dims;
+                int which = 0;                   // 0 t, 1 h, 2 w, 3 e
+                if (imrope) {
+                    if (sector % 3 == 1 && sector < 3*s1) which = 1; else if (sector % 3 == 2 && sector < 3*s2) which = 2; else if (sector % 3 == 0 && sector < 3*s0) which = 0; else which = 3;
+                } else {
+                    if (sector >= s0 && sector < sec_w) which = 1; else if (sector >= sec_w && sector < sec_w + s2) which = 2; else if (sector >= sec_w + s2) which = 3;
+                }
+                theta = (float) a.pos[i2 + (int64_t) which*ne2];
+                // VISION restarts each section's theta where the section begins (indep_sects): multiplications since that restart
+                if (vision) nmul = sector - (which == 0 ? 0 : (which == 1 ? s0 : (which == 2 ? sec_w : sec_e)));
+            }
+            for (int q = 0; q < nmul; q++) theta *= a.theta_scale;
             const float ffv = a.ff ? a.ff[pr] : 1.0f;
             const float theta_extrap = theta / ffv;
             float theta_interp = a.p.freq_scale * theta_extrap;
@@ -495,7 +557,7 @@ __global__ void __launch_bounds__(64) k_rope(const RopeArgs a) {
             }
             const float c = cosf(th) * mscale, s = sinf(th) * mscale;
             int ia, ib;
-            if (a.p.mode == 0) { ia = i0; ib = i0 + 1; } else { ia = pr; ib = pr + n_dims/2; }
+            if (mode == 0) { ia = i0; ib = i0 + 1; } else if (vision) { ia = pr; ib = pr + n_dims; } else { ia = pr; ib = pr + n_dims/2; }
             const float x0 = x[ia], x1 = x[ib];
             y[ia] = x0*c - x1*s;
             y[ib] = x0*s + x1*c;
@@ -506,7 +568,12 @@ __global__ void __launch_bounds__(64) k_rope(const RopeArgs a) {
 }
 extern "C" int mi355x_rope(mi355x_ctx * ctx, const mi355x_tensor * x, const mi355x_tensor * pos, const float * ff, const mi355x_tensor * y, const mi355x_rope_params * p) {
     if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
-    if ((p->mode != 0 && p->mode != 2) || pos->type != MI355X_TYPE_I32 || pos->ne[0] < x->ne[2] || (p->n_dims & 1) || p->n_dims > x->ne[0] || (x->ne[0] & 1)) return MI355X_E_UNSUPPORTED;
+    const bool mrope = (p->mode & 8) != 0;
+    if (p->mode != 0 && p->mode != 2 && p->mode != 8 && p->mode != 24 && p->mode != 40) return MI355X_E_UNSUPPORTED;
+    if (pos->type != MI355X_TYPE_I32 || pos->ne[0] < x->ne[2] * (mrope ? 4 : 1) || (p->n_dims & 1) || p->n_dims > x->ne[0] || (x->ne[0] & 1)) return MI355X_E_UNSUPPORTED;
+    if (mrope && (p->sections[0] < 0 || p->sections[1] < 0 || p->sections[2] < 0 || p->sections[3] < 0 || p->sections[0] + p->sections[1] + p->sections[2] + p->sections[3] <= 0 ||
+                  p->sections[0] + p->sections[1] + p->sections[2] + p->sections[3] > x->ne[0])) return MI355X_E_UNSUPPORTED;
+    if (p->mode == 24 && p->n_dims != x->ne[0] / 2) return MI355X_E_UNSUPPORTED;
     RopeArgs k; k.x = to_d(x); k.y = to_d(y); k.pos = (const int32_t *) pos->data; k.ff = ff; k.p = *p;
     k.theta_scale = powf(p->freq_base, -2.0f / p->n_dims);
     // ggml_rope_yarn_corr_dims (ggml/src/ggml.c:4371-4383)
