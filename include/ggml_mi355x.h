@@ -79,6 +79,10 @@ GGML_MI355X_API int  ggml_backend_mi355x_trace(uint64_t * out16);
  * ggml_backend_mi355x_set_batching(1) at any time.  ggml_backend_mi355x_batch_stats: out[0..4] = merged chains, columns carried, steps
  * run alone, groups that fell back to one chain per state, windows that closed on an absent state. */
 GGML_MI355X_API void ggml_backend_mi355x_set_batching(int on);
+/* Device-side greedy sampling: most probable token of logits row `row` (-1: last) of the decoder step the CALLING
+ * THREAD issued last, reduced in HBM (16 bytes come back); *top1 = its logit, *margin = distance to the runner-up.  -1: no such step.
+ * For hosts with their own decoding loop above whisper_decode (include/mi355x_host.h greedy mode); whisper_full's sampler is untouched. */
+GGML_MI355X_API int  ggml_backend_mi355x_argmax_last(int row, float * top1, float * margin);
 GGML_MI355X_API void ggml_backend_mi355x_batch_stats(int device, uint64_t * out5);
 /* test hook, needs no device (nothing is launched): does `cgraph` (struct ggml_cgraph *) fit the cross-state walker as S >= 2 columns
  * (out[0] == 0), resp. for S == 1 how many of its stages the T >= 3 plane pipeline takes (out[1..3] LayerNorm / attention / plain

@@ -39,6 +39,9 @@ typedef struct mi355x_host_config {
     int32_t flash_attn;
     int32_t replicas_on_one_device; /* 1: every context uses gpu_device = first_device (a one-GPU machine standing in for n_devices GPUs:
                                      *    the payload-skipping load + device copy + checksum verify path runs on real hardware) */
+    int32_t device_greedy;         /* 1 (GPU only): every stream decodes FREE-RUNNING — the token fed to step i + 1 is the arg-max of step i's logits, taken ON
+                                    * THE DEVICE by ggml_backend_mi355x_argmax_last (16 bytes back instead of a host scan of n_vocab floats) and checked
+                                    * against the host scan of the row whisper_decode returned (result: greedy_checked / greedy_mismatches) */
     int32_t batching;              /* cross-state batching in the plugin (ggml_backend_mi355x_set_batching): 1 on, 0 off, -1 leave as it is.  With
                                     * it the states of one device that decode at the same time run as the columns of ONE launch chain */
 } mi355x_host_config;
@@ -54,6 +57,7 @@ typedef struct mi355x_host_result {
     int64_t file_bytes;
     int32_t n_devices, streams_per_device;
     char    error[256];            /* empty on success */
+    int64_t greedy_checked, greedy_mismatches;   /* device_greedy: tokens compared with the host arg-max of the same logits row, and how many differed */
     uint64_t batch_stats[5];       /* device first_device, over the whole run: merged launch chains, columns they carried, steps a state ran alone,
                                     * groups that fell back to one chain per state, windows closed on an absent state (ggml_backend_mi355x_batch_stats) */
 } mi355x_host_result;

@@ -338,6 +338,11 @@ MI355X_API int mi355x_rope(mi355x_ctx * ctx, const mi355x_tensor * x, const mi35
                            const float * freq_factors /* nullable */, const mi355x_tensor * dst,
                            const mi355x_rope_params * p);
 
+/* arg-max of one F32 row of n values in HBM plus the runner-up: out16 (device-visible, 16 bytes) = { i32 index of the first maximum, f32 its
+ * value, f32 the second largest value, i32 n } — device-side greedy sampling over the logits the decoder left in HBM (the reference's sampler
+ * scans the row on the host, src/whisper.cpp:6486-6543) */
+MI355X_API int mi355x_argmax_top2(mi355x_ctx * ctx, const float * x_dev, int n, void * out16);
+
 /* ggml_concat along `dim` for F32 (CPU ggml-cpu/ops.cpp concat; dtw timestamps only, src/whisper.cpp:2741) */
 MI355X_API int mi355x_concat(mi355x_ctx * ctx, const mi355x_tensor * a, const mi355x_tensor * b, const mi355x_tensor * dst, int dim);
 

@@ -2,10 +2,16 @@
 // A batch-1 decode step of large-v3 is 32 layers x 7 stages, each stage a mat-vec whose input is the WHOLE output of the previous
 // one (all-to-all) and whose weights are 1-7 MB.  Two ways to run that chain:
 //   A  one kernel per stage, the dependency is the kernel boundary (hipGraph of 224 nodes) — what the backend does;
-//   B  ONE persistent launch, one workgroup per CU.  Every workgroup owns a fixed slice of the rows of every stage, requests its
-//      slice of the NEXT stage's weights before it waits (prefetch credit), publishes its outputs as 8-byte {value, tag} granules
-//      with one write-through (sc1) store each, and gathers the next input vector by polling the granules with sc1 loads until all
-//      tags carry the stage number (MI355X_MICROARCH.md, rows handoff-1to1 / allgather: no fences, no flags, no barrier).
+//   B  ONE persistent launch, one workgroup per CU.  Every workgroup owns a fixed slice of the rows of every stage, publishes its outputs
+//      as 8-byte {value, tag} granules with one write-through (sc1) store each, and gathers the next input vector by polling the granules
+//      with sc1 loads until all tags carry the stage number (MI355X_MICROARCH.md, rows handoff-1to1 / allgather: no fences, no flags, no
+//      barrier).
+// WHAT THIS DOES NOT TEST: a run-ahead weight loader.  Only the read-only "extra" stream of a stage is requested
+// before the gather; the stage's WEIGHTS are loaded by row_dot AFTER the gather completes, so the HBM latency of every stage still sits
+// behind its dependency edge — exactly the cost the guide's persistent design removes (1 LDS-DMA loader wave running stages ahead + 3
+// consumer waves, rows prefetch-credit / gather-pass / engine-vs-launches: measured there 0.87-0.89 x the launch chain for a decode
+// layer).  So B / A = 1.05-1.09 measured here bounds the SYNCHRONISATION alone (granule all-gather vs kernel boundary: the boundary is
+// no worse), not the persistent engine; that engine is not built in this repository.
 // Same arithmetic in both (int8 weights x per-32-block int8 activations, like the Q8_0 path), results compared.  Every spin is
 // bounded: a lost granule sets an error code instead of hanging the GPU.
 //   hipcc --offload-arch=gfx950 -O3 scripts/persist_probe.hip -o scripts/_bin/persist_probe && scripts/_bin/persist_probe

@@ -434,3 +434,34 @@ def test_cross_state_batching_is_bit_identical_to_one_launch_chain_per_state(arc
     assert not np.array_equal(rows[1][0], rows[1][1])              # different audio per stream
     for s in range(streams):
         assert np.array_equal(rows[1][s].view(np.uint32), rows[0][s].view(np.uint32)), s
+
+
+def test_argmax_top2_first_maximum_and_runner_up(gpu):
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(3)
+    for n, plant in ((51866, None), (51864, (777, 40000)), (1000, (0, 999)), (70, None)):
+        x = rng.standard_normal(n).astype(np.float32)
+        if plant:                                   # two equal maxima: the first index must win, the margin is 0
+            x[list(plant)] = 9.5
+        x_d = dev(torch, x)
+        out = torch.zeros(4, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.check(ka.lib().mi355x_argmax_top2(ctx.h, x_d.data_ptr(), n, out.data_ptr()), "argmax_top2")
+        ctx.sync()
+        o = out.cpu().numpy()
+        idx, top1, top2 = int(o[0]), o[1:2].view(np.float32)[0], o[2:3].view(np.float32)[0]
+        srt = np.sort(x)[::-1]
+        assert idx == int(np.argmax(x)) and top1 == srt[0] and top2 == srt[1] and int(o[3]) == n, (n, idx, top1, top2)
+
+
+@pytest.mark.parametrize("batching", [0, 1])
+def test_device_side_greedy_sampling_equals_the_host_scan(batching):
+    """free-running decode in the native harness: the token fed to the next step is the arg-max taken on the device
+    (ggml_backend_mi355x_argmax_last); every one of them equals the host scan of the logits row whisper_decode returned"""
+    from synth_model import make_model
+    from whisper_cpp_amd import host_api as h
+    m = make_model("base.en", "q5_0")
+    r = h.run(m, use_gpu=True, n_devices=1, streams=3, n_decode=40, steps=1, warmup=1, batching=batching, device_greedy=True)
+    assert r["rc"] == 0 and r["error"] == "", r
+    assert r["greedy_checked"] == 3 * 40 * 2 and r["greedy_mismatches"] == 0, r
+    h.run(m, use_gpu=True, n_devices=1, streams=1, n_decode=1, steps=1, warmup=0, batching=0)

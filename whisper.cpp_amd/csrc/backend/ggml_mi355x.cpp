@@ -484,6 +484,8 @@ struct mi_backend_ctx {
     char *      mirror_host = nullptr; char * mirror_dev = nullptr;
     const void * mirror_src = nullptr; size_t mirror_bytes = 0;  // device range [mirror_src, + mirror_bytes) is what the mirror holds
     std::atomic<int> mirror_state{0};                           // 0 nothing, 1 launched (not yet synchronized), 2 valid
+    // where the last decoder step of this state left its logits (device): ggml_backend_mi355x_argmax_last reduces a row there
+    const float * logits_dev = nullptr; int logits_n = 0, logits_rows = 0;
     uint64_t n_graph_compute = 0;
     double   t_eager_ms = 0;                                    // host time inside graph_compute
     uint64_t trace_gc_enter = 0;                                // GGML_MI355X_TRACE: entry time of the graph_compute still waiting for its synchronize
@@ -521,6 +523,7 @@ static inline double now_ms() {
 }
 
 static std::vector<mi_backend_ctx *> g_backends;           // live backends (guarded by g_weights_mtx)
+static thread_local mi_backend_ctx * t_last_backend = nullptr;    // the backend whose graph_compute this host thread called last (one thread per whisper_state)
 
 #define MI_MIRROR_CAP ((size_t) 2 << 20)
 static const bool g_mirror_on = env_flag("GGML_MI355X_LOGITS_MIRROR", true);
@@ -857,7 +860,7 @@ static int  run_node(mi_backend_ctx * b, const ggml_tensor * n);
 static bool mirror_wanted(const ggml_cgraph * g, const mm_chain & ch, int64_t T) {
     const ggml_tensor * l = ch.last;
     return g_mirror_on && ch.end == g->n_nodes - 1 && l == ch.mm && l->type == GGML_TYPE_F32 && l->ne[0] > 8192 && (int64_t) l->nb[1] == l->ne[0]*4 &&
-           l->ne[2] == 1 && l->ne[3] == 1 && T >= 1 && T <= MI355X_MAX_COLS && (size_t) (l->ne[0]*4*T) <= MI_MIRROR_CAP;
+           l->ne[2] == 1 && l->ne[3] == 1 && T >= 1 && T <= MI355X_MAX_COLS && (size_t) (l->ne[0]*4*T) <= MI_MIRROR_CAP - 64;
 }
 
 // decoder step: LayerNorm fused into the mat-vec products that consume it (Q/K/V, cross-Q, fc1)
@@ -1524,6 +1527,7 @@ static void mi_backend_free(ggml_backend_t backend) {
     mi_backend_ctx * b = (mi_backend_ctx *) backend->context;
     (void) hipSetDevice(b->device);
     mi_batch_leave(b);
+    if (t_last_backend == b) t_last_backend = nullptr;
     mi355x_ctx_synchronize(b->k);
     if (b->batch_wait_sync) (void) hipEventSynchronize(b->batch_wait_sync);
     if (b->own_ev) (void) hipEventDestroy(b->own_ev);
@@ -1757,6 +1761,13 @@ static ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph 
     trace_scope trace_gc(3);
     if (g_trace) b->trace_gc_enter = trace_gc.t0;
     b->mirror_state.store(0);                   // the new graph reuses the compute buffer the mirrored tensor lived in
+    t_last_backend = b;
+    {   // the logits of a decoder graph: its last node, a mat-vec / mat-mul over the vocabulary (src/whisper.cpp:2827)
+        const ggml_tensor * last = cgraph->n_nodes > 0 ? cgraph->nodes[cgraph->n_nodes - 1] : nullptr;
+        if (last && last->op == GGML_OP_MUL_MAT && last->type == GGML_TYPE_F32 && last->ne[0] > 8192 && (int64_t) last->nb[1] == last->ne[0]*4 && last->ne[2] == 1 && last->ne[3] == 1) {
+            b->logits_dev = (const float *) last->data; b->logits_n = (int) last->ne[0]; b->logits_rows = (int) last->ne[1];
+        } else b->logits_dev = nullptr;
+    }
     if (mi_batching_on() && b->fuse && !b->exact && !b->prof && cgraph->n_nodes != b->no_batch_nodes && mi_is_step_graph(cgraph)) return mi_batch_join(b, cgraph);
     mi_batch_leave(b);                          // anything else (encoder, prompt, beam step): this state is not decoding token by token right now
     return mi_compute_own(b, cgraph);
@@ -1956,6 +1967,30 @@ void ggml_backend_mi355x_host_times(double * out) {
     for (int i = 0; i < 4; i++) { out[4 + i] = g_io_ns[i].load() * 1e-6; out[8 + i] = (double) g_io_calls[i].load(); }
     out[12] = g_total_gpu_span_ms;
     for (auto * b : g_backends) out[12] += b->t_gpu_span_ms;       // completed (drained) graph_computes only
+}
+
+// Device-side greedy sampling for hosts that drive whisper_decode themselves (include/mi355x_host.h): the most probable token of row `row`
+// (-1: the last row) of the logits that the decoder step most recently issued BY THE CALLING THREAD left in HBM, and its margin over the
+// runner-up — 16 bytes cross PCIe instead of the n_vocab floats the reference's sampler scans on the host (src/whisper.cpp:6486-6543).
+// Returns the token id, or -1 when the calling thread has not run a decoder step on this plugin.
+int ggml_backend_mi355x_argmax_last(int row, float * top1, float * margin) {
+    mi_backend_ctx * b = t_last_backend;
+    if (!b || !b->logits_dev) return -1;
+    if (row < 0) row = b->logits_rows - 1;
+    if (row >= b->logits_rows || hipSetDevice(b->device) != hipSuccess) return -1;
+    char * md = mi_mirror_dev(b);
+    if (!md) return -1;
+    hipStream_t cs = (hipStream_t) mi355x_ctx_stream(b->k);
+    if (b->batch_wait_stream) { (void) hipStreamWaitEvent(cs, b->batch_wait_stream, 0); b->batch_wait_stream = nullptr; }      // the step may have run as a column of a batch
+    void * out_dev = md + MI_MIRROR_CAP - 64;                  // the mirror's last 64 bytes are reserved for this
+    if (mi355x_argmax_top2(b->k, b->logits_dev + (size_t) row * (size_t) b->logits_n, b->logits_n, out_dev) != 0) return -1;
+    b->own_dirty = true;
+    if (mi355x_ctx_synchronize(b->k) != 0) return -1;
+    const int32_t * r = (const int32_t *) (b->mirror_host + MI_MIRROR_CAP - 64);
+    float v1, v2; memcpy(&v1, r + 1, 4); memcpy(&v2, r + 2, 4);
+    if (top1) *top1 = v1;
+    if (margin) *margin = v1 - v2;
+    return r[0];
 }
 
 // cross-state batching (mi_batch_group): on = 1 / 0 at run time (the environment's GGML_MI355X_BATCH is only the initial value)
@@ -2272,6 +2307,7 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_host_times"))      return (void *) ggml_backend_mi355x_host_times;
     if (!strcmp(name, "ggml_backend_mi355x_trace"))           return (void *) ggml_backend_mi355x_trace;
     if (!strcmp(name, "ggml_backend_mi355x_set_batching"))    return (void *) ggml_backend_mi355x_set_batching;
+    if (!strcmp(name, "ggml_backend_mi355x_argmax_last"))     return (void *) ggml_backend_mi355x_argmax_last;
     if (!strcmp(name, "ggml_backend_mi355x_debug_walk"))      return (void *) ggml_backend_mi355x_debug_walk;
     if (!strcmp(name, "ggml_backend_mi355x_batch_stats"))     return (void *) ggml_backend_mi355x_batch_stats;
     return nullptr;

@@ -100,6 +100,7 @@ typedef int  (*bcast_peer_fn)(int, int, double *);
 typedef void (*defer_fn)(int);
 typedef int  (*clone_fn)(int, int, double *);
 typedef void (*set_batching_fn)(int);
+typedef int  (*argmax_last_fn)(int, float *, float *);
 typedef void (*batch_stats_fn)(int, uint64_t *);
 
 } // namespace
@@ -172,6 +173,9 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
         if (!set_batching) return fail(2, "plugin has no ggml_backend_mi355x_set_batching");
         set_batching(cfg->batching);
     }
+    argmax_last_fn argmax_last = reg ? (argmax_last_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_argmax_last") : nullptr;
+    if (cfg->device_greedy && !(cfg->use_gpu && argmax_last)) return fail(2, "device_greedy needs the MI355X plugin's ggml_backend_mi355x_argmax_last");
+    std::atomic<int64_t> g_checked{0}, g_mismatch{0};
     uint64_t bs0[5] = { 0, 0, 0, 0, 0 };
     if (batch_stats) batch_stats(cfg->first_device, bs0);
     const int nd = cfg->n_devices, ns = cfg->streams_per_device;
@@ -242,7 +246,23 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
             std::vector<whisper_token> tok(8, 0);
             auto chunk = [&] {
                 if (whisper_encode_with_state(ctx, st, 0, cfg->n_threads) != 0) { errors++; return; }
-                for (int i = 0; i < cfg->n_decode; i++) if (whisper_decode_with_state(ctx, st, tok.data(), 1, i, cfg->n_threads) != 0) { errors++; return; }
+                whisper_token cur = 0;
+                for (int i = 0; i < cfg->n_decode; i++) {
+                    if (cfg->device_greedy) tok[0] = cur;
+                    if (whisper_decode_with_state(ctx, st, tok.data(), 1, i, cfg->n_threads) != 0) { errors++; return; }
+                    if (cfg->device_greedy) {
+                        float top1 = 0, margin = 0;
+                        const int t = argmax_last(-1, &top1, &margin);
+                        if (t < 0) { errors++; return; }
+                        // the same row as whisper's own sampler sees it (first maximum, strict >: src/whisper.cpp:6486-6543)
+                        const float * l = whisper_get_logits_from_state(st);
+                        int best = 0;
+                        for (int v = 1; v < n_vocab; v++) if (l[v] > l[best]) best = v;
+                        g_checked++;
+                        if (best != t) g_mismatch++;
+                        cur = (whisper_token) t;
+                    }
+                }
             };
             for (int i = 0; i < cfg->warmup; i++) chunk();
             g.arrive_and_wait();                       // everybody warm: start together
@@ -262,6 +282,7 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
         for (auto & v : last) g_last_logits.insert(g_last_logits.end(), v.begin(), v.end());
     }
     cleanup();
+    out->greedy_checked = g_checked.load(); out->greedy_mismatches = g_mismatch.load();
     if (batch_stats) { uint64_t bs1[5]; batch_stats(cfg->first_device, bs1); for (int i = 0; i < 5; i++) out->batch_stats[i] = bs1[i] - bs0[i]; }
     if (errors.load() != 0) return fail(6, "a whisper_encode / whisper_decode call failed");
     out->wall_s = t1 - t0;

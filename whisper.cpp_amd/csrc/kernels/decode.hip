@@ -852,7 +852,12 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (env_lpr == 8 || env_lpr == 16 || env_lpr == 32 || env_lpr == 64) lpr = env_lpr;
     const int rpw = 64 / lpr;
     const int ngroups = (ntot + rpw - 1) / rpw;
-    int passes = (ngroups + ctx->n_cu*32 - 1) / (ctx->n_cu*32);
+    // row groups per wave: one wave per row group up to 32 waves per CU (the whole matrix requested at once), more only beyond that.
+    // GGML_MI355X_GEMV_PASS_WAVES=n: at most n waves per CU, each walking several row groups with the next group's loads in flight (A-B knob
+    // for the vocabulary projection, 6484 row groups: 32 -> 1 pass, 16 -> 2, 8 -> 4)
+    static const int env_pw = getenv("GGML_MI355X_GEMV_PASS_WAVES") ? atoi(getenv("GGML_MI355X_GEMV_PASS_WAVES")) : 32;
+    const int pw = env_pw >= 1 && env_pw <= 32 ? env_pw : 32;
+    int passes = (ngroups + ctx->n_cu*pw - 1) / (ctx->n_cu*pw);
     if (passes < 1) passes = 1; if (passes > 16) passes = 16;
     const int nw = (ngroups + passes - 1) / passes;
     int wpb = 4;

@@ -586,6 +586,47 @@ extern "C" int mi355x_rope(mi355x_ctx * ctx, const mi355x_tensor * x, const mi35
 }
 
 // -------------------------------------------------------------------------------------------------
+// arg-max of a logits row with the runner-up's value (device-side greedy sampling: src/whisper.cpp:6486-6543 picks the most probable
+// token of the row the decoder left in HBM).  One workgroup; the FIRST maximum wins, like the sampler's strict `>` scan.
+// -------------------------------------------------------------------------------------------------
+struct ArgmaxArgs { const float * x; int n; int * out; };
+__global__ void __launch_bounds__(1024) k_argmax_top2(const ArgmaxArgs a) {
+    __shared__ float s1[16], s2[16]; __shared__ int si[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float b1 = -INFINITY, b2 = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int i = tid; i < a.n; i += 1024) {
+        const float v = a.x[i];
+        if (v > b1) { b2 = b1; b1 = v; bi = i; } else if (v > b2) b2 = v;
+    }
+    // merge (b1, bi, b2) across lanes: larger value wins, equal values -> smaller index
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float o1 = __shfl_xor(b1, o, 64), o2 = __shfl_xor(b2, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        const bool take = o1 > b1 || (o1 == b1 && oi < bi);
+        const float lose = take ? b1 : o1;
+        b2 = fmaxf(fmaxf(b2, o2), lose);
+        if (take) { b1 = o1; bi = oi; }
+    }
+    if (lane == 0) { s1[wave] = b1; s2[wave] = b2; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float r1 = s1[0], r2 = s2[0]; int ri = si[0];
+        for (int w = 1; w < 16; w++) {
+            const bool take = s1[w] > r1 || (s1[w] == r1 && si[w] < ri);
+            const float lose = take ? r1 : s1[w];
+            r2 = fmaxf(fmaxf(r2, s2[w]), lose);
+            if (take) { r1 = s1[w]; ri = si[w]; }
+        }
+        a.out[0] = ri; ((float *) a.out)[1] = r1; ((float *) a.out)[2] = r2; a.out[3] = a.n;
+    }
+}
+extern "C" int mi355x_argmax_top2(mi355x_ctx * ctx, const float * x_dev, int n, void * out16) {
+    if (!x_dev || n < 1 || !out16 || ((uintptr_t) x_dev % 4)) return MI355X_E_UNSUPPORTED;
+    ArgmaxArgs k = { x_dev, n, (int *) out16 };
+    return emit(ctx, "argmax_top2", k_argmax_top2, dim3(1), dim3(1024), 0, k, (double) n * 4, 0);
+}
+
+// -------------------------------------------------------------------------------------------------
 // concat f32 along dim
 // -------------------------------------------------------------------------------------------------
 struct ConcatArgs { dtensor a, b, d; int dim; int64_t n; };

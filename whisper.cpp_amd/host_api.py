@@ -12,13 +12,13 @@ HOST_SO = LIB_DIR / "libmi355x_host.so"
 class Config(C.Structure):
     _fields_ = [("model_path", C.c_char_p), ("plugin_path", C.c_char_p), ("use_gpu", C.c_int32), ("n_devices", C.c_int32), ("first_device", C.c_int32),
                 ("streams_per_device", C.c_int32), ("n_decode", C.c_int32), ("steps", C.c_int32), ("warmup", C.c_int32), ("n_threads", C.c_int32),
-                ("skip_payloads", C.c_int32), ("flash_attn", C.c_int32), ("replicas_on_one_device", C.c_int32), ("batching", C.c_int32)]
+                ("skip_payloads", C.c_int32), ("flash_attn", C.c_int32), ("replicas_on_one_device", C.c_int32), ("device_greedy", C.c_int32), ("batching", C.c_int32)]
 
 
 class Result(C.Structure):
     _fields_ = [("wall_s", C.c_double), ("chunks_per_s", C.c_double), ("ms_per_chunk_per_stream", C.c_double), ("load_s", C.c_double),
                 ("bcast_bytes", C.c_double), ("bcast_seconds", C.c_double), ("bcast_buffers", C.c_int32), ("bcast_verified", C.c_int32),
-                ("payload_bytes_read", C.c_int64), ("file_bytes", C.c_int64), ("n_devices", C.c_int32), ("streams_per_device", C.c_int32), ("error", C.c_char * 256), ("batch_stats", C.c_uint64 * 5)]
+                ("payload_bytes_read", C.c_int64), ("file_bytes", C.c_int64), ("n_devices", C.c_int32), ("streams_per_device", C.c_int32), ("error", C.c_char * 256), ("greedy_checked", C.c_int64), ("greedy_mismatches", C.c_int64), ("batch_stats", C.c_uint64 * 5)]
 
 
 _lib = None
@@ -43,9 +43,9 @@ def lib() -> C.CDLL:
 
 def run(model: Path, *, use_gpu: bool, n_devices: int = 1, streams: int = 1, n_decode: int = 256, steps: int = 1, warmup: int = 1,
         n_threads: int = 4, skip_payloads: bool = True, first_device: int = 0, flash_attn: bool = True, replicas_on_one_device: bool = False,
-        batching: int = -1) -> dict:
+        batching: int = -1, device_greedy: bool = False) -> dict:
     cfg = Config(str(model).encode(), str(PLUGIN_SO).encode() if use_gpu else None, int(use_gpu), n_devices, first_device, streams, n_decode, steps, warmup,
-                 n_threads, int(skip_payloads), int(flash_attn), int(replicas_on_one_device), int(batching))
+                 n_threads, int(skip_payloads), int(flash_attn), int(replicas_on_one_device), int(device_greedy), int(batching))
     res = Result()
     rc = lib().mi355x_host_run(C.byref(cfg), C.byref(res))
     d = {f: getattr(res, f) for f, _ in Result._fields_}
