@@ -24,7 +24,8 @@ for f in sorted(out.glob("model_parity_*.json")):
         "greedy_divergence_max_diff": g["divergence_max_diff"]}
 for f in sorted(out.glob("full_parity_*.json")):
     d = json.loads(f.read_text())
-    res["whisper_full_pipeline"][f.stem[len("full_parity_"):]] = {m: {k: d[m][k] for k in ("n_cpu", "n_gpu", "identical_prefix")} for m in ("greedy", "beam5") if m in d}
+    keys = ("n_cpu", "n_gpu", "identical_prefix", "steps_compared", "min_margin", "max_logit_diff", "divergence_margin", "divergence_logit_diff")
+    res["whisper_full_pipeline"][f.stem[len("full_parity_"):]] = {m: {k: d[m][k] for k in keys if k in d[m]} for m in ("greedy", "beam5") if m in d}
 for f in sorted(out.glob("lang_detect_*.json")):
     res["language_detection"][f.stem[len("lang_detect_"):]] = json.loads(f.read_text())
 print(json.dumps(res, indent=1))

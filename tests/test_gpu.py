@@ -821,6 +821,17 @@ def test_planted_large_margin_model_is_transcribed_token_for_token(plugin_env, a
     assert d["greedy"]["min_margin"] > 5.0, d["greedy"]          # the margins really are large (random-weight models: ~0.01)
 
 
+def test_whisper_full_with_batching_switched_on_and_one_state(plugin_env):
+    """GGML_MI355X_BATCH=1 with a single whisper_state: every decoder step joins the device's group alone and must take exactly the
+    ordinary path (prompt and beam-search graphs leave the group) — the planted transcript comes out for both samplers"""
+    from synth_model import planted_token
+    d = _full_parity(dict(plugin_env, GGML_MI355X_BATCH="1"), "base.en", "q5_0", exact=False, plant=True, max_tokens="130")
+    for mode in ("greedy", "beam5"):
+        g = d[mode]
+        assert g["n_cpu"] >= 128 and g["cpu"] == g["gpu"], (mode, g["identical_prefix"])
+        assert g["cpu"][:64] == [planted_token(1 + i) for i in range(64)], g["cpu"][:6]
+
+
 @pytest.mark.parametrize("arch,qtype", FULL_CASES)
 def test_plugin_whisper_full_pipeline(plugin_env, arch, qtype):
     """whisper_full() end to end (mel front end, encoder, sampling loop — all unmodified reference code) on a synthetic

@@ -708,9 +708,11 @@ template <int WT, int MODE, bool NSEG1>
 static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops, int R = 1) {
     const char * name = "gemv";
     if constexpr (MODE == 0 || MODE == 1) {
-        if (R == 4 && k.K <= 2048) {            // T >= 3: four rows per wave (grid already sized for it by the caller)
+        if (R == 4 && k.K <= 2048) {            // four rows per wave (grid already sized for it by the caller)
             const dim3 block4(64 * gemv_row_waves(k.K));
             switch (T) {
+                case 1: return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
+                case 2: return emit(ctx, name, k_gemv_row<WT, 2, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
                 case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
                 case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
                 case 5: return emit(ctx, name, k_gemv_row<WT, 5, 1, MODE, NSEG1, 4>, grid, block4, lds, k, bytes, flops);
@@ -822,7 +824,9 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         static const int env_r = getenv("GGML_MI355X_GEMV_ROWS") ? atoi(getenv("GGML_MI355X_GEMV_ROWS")) : 4;
         // (measured at T = 5, large-v3: LN+FC1 11.3 -> 10.0 us, LN+QKV 12.5 -> 10.5 us; the 1280-row O-projection with its
         // attention-combine prologue gets SLOWER on 64 workgroups, 12.1 -> 16.4 us, so it keeps one row per wave)
-        int R = (T >= 3 && K <= 2048 && env_r == 4 && !from_part && ntot / (gemv_row_waves(K) * 4) >= 128) ? 4 : 1;
+        // (GGML_MI355X_GEMV_ROWS_MIN_T=1: also at T = 1 / 2 for the wide mat-vecs — LN + Q/K/V, LN + fc1 — an A-B knob)
+        static const int env_r_min_t = getenv("GGML_MI355X_GEMV_ROWS_MIN_T") ? atoi(getenv("GGML_MI355X_GEMV_ROWS_MIN_T")) : 3;
+        int R = (T >= env_r_min_t && K <= 2048 && env_r == 4 && !from_part && ntot / (gemv_row_waves(K) * 4) >= 128) ? 4 : 1;
         for (int s = 0; s < d->nseg; s++) if (d->seg[s].N % 4) R = 1;
         static const bool env_wave_ln = getenv("GGML_MI355X_GEMV_WAVE_LN") && atoi(getenv("GGML_MI355X_GEMV_WAVE_LN"));
         if (d->has_norm && env_wave_ln) R = 1;
@@ -855,7 +859,8 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     // row groups per wave: one wave per row group up to 32 waves per CU (the whole matrix requested at once), more only beyond that.
     // GGML_MI355X_GEMV_PASS_WAVES=n: at most n waves per CU, each walking several row groups with the next group's loads in flight (A-B knob
     // for the vocabulary projection, 6484 row groups: 32 -> 1 pass, 16 -> 2, 8 -> 4)
-    static const int env_pw = getenv("GGML_MI355X_GEMV_PASS_WAVES") ? atoi(getenv("GGML_MI355X_GEMV_PASS_WAVES")) : 32;
+    // (measured r03, single stream large-v3 Q5_0: 32 -> 1.3921, 16 -> 1.3888, 8 -> 1.3806 ms/token; profiles/r03_single_stream_mirror_and_logits_passes_ab.txt)
+    static const int env_pw = getenv("GGML_MI355X_GEMV_PASS_WAVES") ? atoi(getenv("GGML_MI355X_GEMV_PASS_WAVES")) : 8;
     const int pw = env_pw >= 1 && env_pw <= 32 ? env_pw : 32;
     int passes = (ngroups + ctx->n_cu*pw - 1) / (ctx->n_cu*pw);
     if (passes < 1) passes = 1; if (passes > 16) passes = 16;
