@@ -1187,19 +1187,32 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
     }
     end_out = ch[n - 1].end; rc_out = 0;
     if (!k) return true;
+    // LayerNorm in the mat-vec's own prologue (one launch) — or, GGML_MI355X_LN_FUSED=0 / shapes the plane kernel does not take
+    // that way, k_act_prepare -> planes -> mat-vec (two launches)
+    static const bool ln_fused = !getenv("GGML_MI355X_LN_FUSED") || atoi(getenv("GGML_MI355X_LN_FUSED")) != 0;
     mi355x_act_desc a; memset(&a, 0, sizeof(a));
     a.K = (int) K; a.T = cs.T; a.wtype = (int32_t) w0->type; a.has_norm = 1; memcpy(&a.eps, ln.norm->op_params, sizeof(float)); a.ln_w = ln.w; a.ln_b = ln.b;
     for (int c = 0; c < cs.T; c++) a.xcol[c] = (const float *) cs_col(cs, c, i, 0);
     void * p0 = mi355x_act_scratch(k, 0), * p1 = mi355x_act_scratch(k, 1);
     if (!p0 || !p1) { rc_out = (int) hipErrorOutOfMemory; return true; }
-    int rc = mi355x_act_prepare(k, &a, p0);
-    if (rc == MI355X_E_UNSUPPORTED) return false;
-    if (rc) { rc_out = rc; return true; }
+    int rc = 0;
     mi355x_gemv_desc d; memset(&d, 0, sizeof(d));
     mi355x_gemv_cols cols; memset(&cols, 0, sizeof(cols));
-    d.K = (int) K; d.T = cs.T; d.nseg = n; d.x_planes = p0; d.cols = &cols;
+    d.K = (int) K; d.T = cs.T; d.nseg = n; d.cols = &cols;
     for (int s = 0; s < n; s++) q_fill_seg(cs, ch[s], s, d, cols);
     if (pout) { d.planes_out = p1; d.planes_out_only = only ? 1 : 0; }
+    auto use_planes = [&]() -> int {
+        const int r = mi355x_act_prepare(k, &a, p0);
+        if (r) return r;
+        d.has_norm = 0; d.ln_w = d.ln_b = nullptr; d.x_planes = p0; memset(cols.x, 0, sizeof(cols.x));
+        return 0;
+    };
+    if (ln_fused) { d.has_norm = 1; d.eps = a.eps; d.ln_w = ln.w; d.ln_b = ln.b; for (int c = 0; c < cs.T; c++) cols.x[c] = a.xcol[c]; }
+    else {
+        rc = use_planes();
+        if (rc == MI355X_E_UNSUPPORTED) return false;
+        if (rc) { rc_out = rc; return true; }
+    }
     bool mirror = n == 1 && cs.owner[0] && mirror_wanted(g, ch[0], cs.S > 1 ? 1 : cs.T);
     if (mirror) {
         const size_t rowb = (size_t) ch[0].last->ne[0] * 4;
@@ -1211,6 +1224,12 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
         if (!mirror) memset(cols.mirror, 0, sizeof(cols.mirror));
     }
     rc = mi355x_gemv_fused(k, &d);
+    if (rc == MI355X_E_UNSUPPORTED && d.has_norm) {          // the LayerNorm form was not taken (e.g. the vocabulary projection): planes
+        rc = use_planes();
+        if (rc == MI355X_E_UNSUPPORTED) return false;
+        if (rc) { rc_out = rc; return true; }
+        rc = mi355x_gemv_fused(k, &d);
+    }
     if (rc == 0 && mirror && mi355x_last_launch_mirrored(k)) {
         const size_t rowb = (size_t) ch[0].last->ne[0] * 4;
         if (cs.S > 1) for (int c = 0; c < cs.T; c++) { mi_backend_ctx * ob = cs.owner[c]; ob->mirror_src = cs_tensor(cs, c, ch[0].end, -1)->data; ob->mirror_bytes = rowb; ob->mirror_state.store(1); }
@@ -1262,10 +1281,12 @@ static bool q_attn_proj(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, in
         }
         max_kv = std::max(max_kv, (int) st[c].n_kv);
     }
-    // self-attention (few keys): ONE launch from q / K / V to the projection's activation planes
+    // ONE launch from q / K / V to the projection's activation planes: self-attention, and cross-attention's 1500 keys
+    // (GGML_MI355X_ATTN_PLANES_MAX_KV=512: cross-attention as partial records + combine, the first form of this pipeline)
     static const bool self_planes = env_flag("GGML_MI355X_SELF_ATTN_PLANES", true);
+    static const int planes_max_kv = getenv("GGML_MI355X_ATTN_PLANES_MAX_KV") ? atoi(getenv("GGML_MI355X_ATTN_PLANES_MAX_KV")) : 1536;
     bool have_planes = false;
-    if (self_planes && max_kv <= 512 && w->type != GGML_TYPE_Q4_K && (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2))) {
+    if (self_planes && max_kv <= planes_max_kv && w->type != GGML_TYPE_Q4_K && (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2))) {
         rc = mi355x_flash_attn_planes(k, cs.T, st, &mq, &mk, &mv, scale, p0);
         if (rc == 0) have_planes = true;
         else if (rc != MI355X_E_UNSUPPORTED) { rc_out = rc; return true; }

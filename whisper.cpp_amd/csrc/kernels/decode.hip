@@ -824,8 +824,9 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         static const int env_r = getenv("GGML_MI355X_GEMV_ROWS") ? atoi(getenv("GGML_MI355X_GEMV_ROWS")) : 4;
         // (measured at T = 5, large-v3: LN+FC1 11.3 -> 10.0 us, LN+QKV 12.5 -> 10.5 us; the 1280-row O-projection with its
         // attention-combine prologue gets SLOWER on 64 workgroups, 12.1 -> 16.4 us, so it keeps one row per wave)
-        // (GGML_MI355X_GEMV_ROWS_MIN_T=1: also at T = 1 / 2 for the wide mat-vecs — LN + Q/K/V, LN + fc1 — an A-B knob)
-        static const int env_r_min_t = getenv("GGML_MI355X_GEMV_ROWS_MIN_T") ? atoi(getenv("GGML_MI355X_GEMV_ROWS_MIN_T")) : 3;
+        // Also at T = 1 / 2 for the wide mat-vecs (LN + Q/K/V, LN + fc1): fewer, fatter workgroups stage the activation fewer times
+        // (round-3 A-B, large-v3 Q5_0: 1.391 -> 1.330 ms/token, profiles/r03_ab_gemv_rows_min_t.txt; GGML_MI355X_GEMV_ROWS_MIN_T=3 is round 2)
+        static const int env_r_min_t = getenv("GGML_MI355X_GEMV_ROWS_MIN_T") ? atoi(getenv("GGML_MI355X_GEMV_ROWS_MIN_T")) : 1;
         int R = (T >= env_r_min_t && K <= 2048 && env_r == 4 && !from_part && ntot / (gemv_row_waves(K) * 4) >= 128) ? 4 : 1;
         for (int s = 0; s < d->nseg; s++) if (d->seg[s].N % 4) R = 1;
         static const bool env_wave_ln = getenv("GGML_MI355X_GEMV_WAVE_LN") && atoi(getenv("GGML_MI355X_GEMV_WAVE_LN"));

@@ -207,6 +207,7 @@ struct QGArgs {
     QSeg seg[3];
     const uint16_t * gelu_tab;
     void * planes_out; int planes_only; int pad;
+    const float * ln_w; const float * ln_b; float eps; int pad2;          // LN form: planes built in the prologue from cols.x
     mi355x_gemv_cols cols;
 };
 
@@ -245,10 +246,13 @@ __device__ __forceinline__ void wblk_dot_q4k_rt(const wblk<MI355X_TYPE_Q4_K> & r
 // TMAX: columns the kernel is built for (run-time T <= TMAX).  NU: lane-units per row and lane (1: K <= 2048, 3: K <= 6144; Q4_K
 // units are 64 elements: 1: K <= 4096, 2: K <= 8192).  R rows per wave.  POUT: 8 waves x 4 rows = the 32 rows of one Q8_0
 // block of the RESULT per workgroup, whose planes are written as well (single segment).
-template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT>
+// LN: no planes come in; the prologue is k_act_prepare MODE 1 for all T columns at once (LayerNorm + affine of cols.x[t], then the
+// quantizer), statement for statement, written to the LDS image instead of HBM — one dependent launch less per LayerNorm.  The
+// weights are requested first and stay in flight under it.  K <= 2048 (NU == 1).
+template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT, bool LN>
 __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QGArgs a) {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
-    constexpr int CP = (TMAX * (Q4K ? NU*4096*9/8 + 256 : NU*64*40) / 16 + 255) / 256;       // uint4 copy slots per thread (>= 256 threads)
+    constexpr int CP = LN ? 1 : (TMAX * (Q4K ? NU*4096*9/8 + 256 : NU*64*40) / 16 + 255) / 256;       // uint4 copy slots per thread (>= 256 threads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -269,11 +273,11 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
     const int tl = lane % TMAX, tcol = tl < T ? tl : T - 1;
     const int rlane = lane / TMAX < R ? lane / TMAX : R - 1;
     void * dcol; const float * rcol;
+    // per-column pointer tables: read straight from the kernarg segment (constant address space, scalar loads).  Taking the
+    // address of the by-value argument `a` instead would force a private (scratch) copy of it.
+    typedef const QGArgs __attribute__((address_space(4))) * kargs_t;
+    const kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
     {
-        // per-column pointer tables: read straight from the kernarg segment (constant address space, scalar loads).  Taking the
-        // address of the by-value argument `a` instead would force a private (scratch) copy of it.
-        typedef const QGArgs __attribute__((address_space(4))) * kargs_t;
-        const kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
         const int sc = NSEG1 ? 0 : s;
         void * d0 = ka->cols.dst[sc][0]; const float * r0 = ka->cols.res[sc][0];
         dcol = d0; rcol = r0;
@@ -290,10 +294,22 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
     // ---- the load burst: plane image (L2), bias / residual, weights (HBM) last; clamped addresses, no predicates ----
     const int n16 = (int) (((Q4K ? (size_t) T * ((size_t) K + nsb*4 + (K >> 5)*4) : (size_t) T * nb * 40) + 15) >> 4);
     u32x4 cp[CP];
-    #pragma unroll
-    for (int i = 0; i < CP; i++) {
-        const int idx = tid + i*nthreads;
-        cp[i] = ((const u32x4 *) a.planes)[idx < n16 ? idx : n16 - 1];
+    float4 xr[LN ? TMAX : 1], lw, lb;
+    const int K4 = K >> 2;
+    if constexpr (LN) {
+        const int e4c = tid < K4 ? tid : K4 - 1;
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) {
+            const float * xp = ka->cols.x[tt];                 // (columns >= T repeat column T - 1: launcher)
+            xr[tt] = *(const float4 *) ((const char *) xp + (size_t) e4c*16);
+        }
+        lw = *(const float4 *) (a.ln_w + e4c*4); lb = *(const float4 *) (a.ln_b + e4c*4);
+    } else {
+        #pragma unroll
+        for (int i = 0; i < CP; i++) {
+            const int idx = tid + i*nthreads;
+            cp[i] = ((const u32x4 *) a.planes)[idx < n16 ? idx : n16 - 1];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     const float * bptr = sg.bias ? sg.bias + row + rlane : (const float *) a.gelu_tab;
@@ -320,10 +336,54 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
     // ---- plane image -> LDS ----
     // (unconditional stores: surplus slots land in one dummy word behind the image.  A predicated store in this loop makes the
     //  compiler turn the predicate into a loop exit, keep the loop rolled and park cp[] in scratch memory.)
-    #pragma unroll
-    for (int i = 0; i < CP; i++) {
-        const int idx = tid + i*nthreads;
-        ((u32x4 *) smem)[idx < n16 ? idx : n16] = cp[i];
+    if constexpr (LN) {
+        __shared__ float red[2][TMAX][16];
+        uint32_t * plo, * phi; float * pdx; int * psx;
+        planes_of<Q4K>(smem, K, T, plo, phi, pdx, psx);
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) {
+            float p = 0.0f;
+            if (tid < K4) p += (xr[tt].x + xr[tt].y) + (xr[tt].z + xr[tt].w);
+            p = wave_sum(p);
+            if (lane == 0) red[0][tt][wave] = p;
+        }
+        __syncthreads();
+        float mean[TMAX];
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) {
+            float rs = 0.0f;
+            #pragma unroll
+            for (int w = 0; w < 8; w++) { const float pw = red[0][tt][w]; rs += w < nwaves ? pw : 0.0f; }
+            mean[tt] = rs / K;
+            float p = 0.0f;
+            if (tid < K4) {
+                const float d0 = xr[tt].x - mean[tt], d1 = xr[tt].y - mean[tt], d2 = xr[tt].z - mean[tt], d3 = xr[tt].w - mean[tt];
+                p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+            }
+            p = wave_sum(p);
+            if (lane == 0) red[1][tt][wave] = p;
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) {
+            float rs = 0.0f;
+            #pragma unroll
+            for (int w = 0; w < 8; w++) { const float pw = red[1][tt][w]; rs += w < nwaves ? pw : 0.0f; }
+            const float rstd = 1.0f / sqrtf(rs / K + a.eps);
+            if (tt < T && tid < K4) {
+                float o[4] = { (xr[tt].x - mean[tt]) * rstd, (xr[tt].y - mean[tt]) * rstd, (xr[tt].z - mean[tt]) * rstd, (xr[tt].w - mean[tt]) * rstd };
+                o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
+                o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
+                if constexpr (Q4K) dg_q8_K_store(o, tid*4, tt, K, T, plo, pdx, psx);
+                else               dg_q8_0_store(o, tid*4, tt, K >> 5, plo, phi, pdx, psx);
+            }
+        }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < CP; i++) {
+            const int idx = tid + i*nthreads;
+            ((u32x4 *) smem)[idx < n16 ? idx : n16] = cp[i];
+        }
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);          // nothing that needs the WEIGHTS may move above the barrier: they are still in flight while the planes settle
@@ -429,33 +489,47 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
 }
 
 template <int WT, int TMAX, int NU>
-static int launch_gemv_q_v(mi355x_ctx * ctx, const QGArgs & k, bool nseg1, bool pout, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
+static int launch_gemv_q_v(mi355x_ctx * ctx, const QGArgs & k, bool nseg1, bool pout, bool ln, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv_q";
+    if constexpr (NU == 1) {
+        if (ln) {
+            if constexpr (WT != MI355X_TYPE_Q4_K) {
+                if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, true>, grid, block, lds, k, bytes, flops);
+                if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, true>, grid, block, lds, k, bytes, flops);
+            }
+            if (pout) return MI355X_E_UNSUPPORTED;
+            if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, true>, grid, block, lds, k, bytes, flops);
+            return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, true>, grid, block, lds, k, bytes, flops);
+        }
+    }
+    if (ln) return MI355X_E_UNSUPPORTED;
     if constexpr (NU == 1 && WT != MI355X_TYPE_Q4_K) {
-        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
-        if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
+        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, false>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
+        if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, false>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
     }
     if (pout) return MI355X_E_UNSUPPORTED;
-    if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false>, grid, block, lds, k, bytes, flops);
-    if constexpr (NU == 1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false>, grid, block, lds, k, bytes, flops);
+    if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, false>, grid, block, lds, k, bytes, flops);
+    if constexpr (NU == 1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, false>, grid, block, lds, k, bytes, flops);
     return MI355X_E_UNSUPPORTED;
 }
 template <int WT>
-static int launch_gemv_q(mi355x_ctx * ctx, const QGArgs & k, int nu, bool nseg1, bool pout, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
+static int launch_gemv_q(mi355x_ctx * ctx, const QGArgs & k, int nu, bool nseg1, bool pout, bool ln, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     constexpr int NUBIG = WT == MI355X_TYPE_Q4_K ? 2 : 3;
     if (k.T <= 4) {
-        if (nu == 1) return launch_gemv_q_v<WT, 4, 1>(ctx, k, nseg1, pout, grid, block, lds, bytes, flops);
-        if (pout) return MI355X_E_UNSUPPORTED;
-        return launch_gemv_q_v<WT, 4, NUBIG>(ctx, k, nseg1, false, grid, block, lds, bytes, flops);
+        if (nu == 1) return launch_gemv_q_v<WT, 4, 1>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
+        if (pout || ln) return MI355X_E_UNSUPPORTED;
+        return launch_gemv_q_v<WT, 4, NUBIG>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
     }
-    if (nu == 1) return launch_gemv_q_v<WT, 8, 1>(ctx, k, nseg1, pout, grid, block, lds, bytes, flops);
-    if (pout) return MI355X_E_UNSUPPORTED;
-    return launch_gemv_q_v<WT, 8, NUBIG>(ctx, k, nseg1, false, grid, block, lds, bytes, flops);
+    if (nu == 1) return launch_gemv_q_v<WT, 8, 1>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
+    if (pout || ln) return MI355X_E_UNSUPPORTED;
+    return launch_gemv_q_v<WT, 8, NUBIG>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
 }
 
 // mat-vec over pre-quantized activation planes; MI355X_E_UNSUPPORTED: the caller tries k_gemv8 (which copies the same image)
 int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
-    if (!d->x_planes || d->x || d->attn_part_o || d->has_norm) return MI355X_E_UNSUPPORTED;
+    // activations: prepared planes, or (LN form) per-column F32 vectors normalised and quantized in the prologue
+    const bool ln = !d->x_planes && d->has_norm && d->cols && d->cols->x[0];
+    if ((!d->x_planes && !ln) || d->x || d->attn_part_o || (d->has_norm && !ln)) return MI355X_E_UNSUPPORTED;
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > MI355X_MAX_COLS || ((uintptr_t) d->x_planes % 16)) return MI355X_E_UNSUPPORTED;
     const int wt = d->seg[0].wtype, K = d->K, T = d->T;
     if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;
@@ -466,6 +540,12 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (units > 64 * nu) return MI355X_E_UNSUPPORTED;
     QGArgs k; memset(&k, 0, sizeof(k));
     k.planes = d->x_planes; k.K = K; k.T = T; k.nseg = d->nseg; k.gelu_tab = ctx->gelu_tab;
+    if (ln) {
+        if (K > 2048 || nu != 1 || !d->ln_w || !d->ln_b || ((uintptr_t) d->ln_w % 16) || ((uintptr_t) d->ln_b % 16)) return MI355X_E_UNSUPPORTED;
+        for (int t = 0; t < T; t++) if (!d->cols->x[t] || ((uintptr_t) d->cols->x[t] % 16)) return MI355X_E_UNSUPPORTED;
+        for (int t = 0; t < MI355X_MAX_COLS; t++) k.cols.x[t] = d->cols->x[t < T ? t : T - 1];
+        k.ln_w = d->ln_w; k.ln_b = d->ln_b; k.eps = d->eps;
+    }
     int ntot = 0; double wbytes = 0;
     for (int s = 0; s < d->nseg; s++) {
         const mi355x_gemv_seg & g = d->seg[s];
@@ -504,13 +584,13 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     static const int pout_rows = getenv("GGML_MI355X_POUT_ROWS") && atoi(getenv("GGML_MI355X_POUT_ROWS")) == 2 ? 2 : 4;
     const int waves = pout ? 32 / pout_rows : gemv_row_waves(K), rpb = pout ? 32 : waves;
     const dim3 grid((ntot + rpb - 1) / rpb), block(64 * waves);
-    const double bytes = wbytes + (double) dg_act_bytes(wt, K, T) + (double) ntot*T*4;
+    const double bytes = wbytes + (ln ? (double) T*K*4 : (double) dg_act_bytes(wt, K, T)) + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;
     switch (wt) {
-        case MI355X_TYPE_Q4_0: return launch_gemv_q<MI355X_TYPE_Q4_0>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q5_0: return launch_gemv_q<MI355X_TYPE_Q5_0>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q8_0: return launch_gemv_q<MI355X_TYPE_Q8_0>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q4_K: return launch_gemv_q<MI355X_TYPE_Q4_K>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q4_0: return launch_gemv_q<MI355X_TYPE_Q4_0>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q5_0: return launch_gemv_q<MI355X_TYPE_Q5_0>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q8_0: return launch_gemv_q<MI355X_TYPE_Q8_0>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q4_K: return launch_gemv_q<MI355X_TYPE_Q4_K>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
     }
     return MI355X_E_UNSUPPORTED;
 }
@@ -657,16 +737,19 @@ extern "C" int mi355x_flash_attn_partial_multi(mi355x_ctx * ctx, int S, const mi
     return 0;
 }
 
-// Self-attention of a decoder step (n_kv <= 512) COMPLETE in one launch per layer: one 16-wave workgroup per (head, column) — wave w takes
-// keys [32w, 32w + 32) exactly as a wave of k_fattn_dec does, the four waves of a 128-key chunk are merged into that chunk's record in
-// LDS, the records are combined and the head's 64 outputs leave as two Q8_0 blocks of the output projection's activation planes.
+// Attention of a decoder step (n_kv <= 512 * ROUNDS: self-attention, and the 1500 keys of cross-attention in three rounds) COMPLETE
+// in one launch per layer: one 16-wave workgroup per (head, column).  In round r wave w takes keys [32 (16 r + w), + 32) exactly as a
+// wave of k_fattn_dec does (the next round's K / V rows are requested before this round's are used), the four waves of a 128-key chunk
+// are merged into that chunk's record in LDS, at the end the records are combined and the head's 64 outputs leave as two Q8_0 blocks of
+// the output projection's activation planes.
 // Arithmetic = k_fattn_dec -> (records) -> k_act_prepare MODE 2 -> dg_q8_0_store, statement for statement: bit-identical to the three
-// launches it replaces (attention, combine, quantize), one dependent launch less per layer.
+// launches it replaces (attention, combine, quantize), one or two dependent launches less per layer.
+template <int ROUNDS>
 __global__ void __launch_bounds__(1024) k_fattn_self_q(const FDMArgs a) {
     __shared__ __attribute__((aligned(16))) float wo[16][64];
     __shared__ float wml[16][2];
-    __shared__ __attribute__((aligned(16))) float ro[4][64];
-    __shared__ float rml[4][2];
+    __shared__ __attribute__((aligned(16))) float ro[ROUNDS*4][64];
+    __shared__ float rml[ROUNDS*4][2];
     __shared__ __attribute__((aligned(16))) float xo[64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int kg = lane >> 3, dc = lane & 7;
@@ -675,15 +758,16 @@ __global__ void __launch_bounds__(1024) k_fattn_self_q(const FDMArgs a) {
     const FDMState & st = a.st[si];
     const int n_kv = st.n_kv;
     const bool has_mask = st.m != nullptr;
-    const int kbeg = wave*32;
     const char * kbase = st.k + (int64_t) hk*a.k_nb2 + dc*16;
     const char * vbase = st.v + (int64_t) hv*a.v_nb2 + dc*16;
-    uint4 kr[4], vr[4];
+    const char * mbase = has_mask ? st.m : st.k;
+    uint4 kr[2][4], vr[2][4];
+    uint16_t mkh[2][4];
     #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int key = kbeg + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
-        kr[i] = *(const uint4 *) (kbase + (int64_t) kc*a.k_nb1);
-        vr[i] = *(const uint4 *) (vbase + (int64_t) kc*a.v_nb1);
+        const int key = wave*32 + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
+        kr[0][i] = *(const uint4 *) (kbase + (int64_t) kc*a.k_nb1);
+        vr[0][i] = *(const uint4 *) (vbase + (int64_t) kc*a.v_nb1);
     }
     float qf[8];
     {
@@ -692,70 +776,83 @@ __global__ void __launch_bounds__(1024) k_fattn_self_q(const FDMArgs a) {
         qf[0] = round_f16(q0.x); qf[1] = round_f16(q0.y); qf[2] = round_f16(q0.z); qf[3] = round_f16(q0.w);
         qf[4] = round_f16(q1.x); qf[5] = round_f16(q1.y); qf[6] = round_f16(q1.z); qf[7] = round_f16(q1.w);
     }
-    uint16_t mkh[4];
-    const char * mbase = has_mask ? st.m : st.k;
     #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const int key = kbeg + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
-        mkh[i] = *(const uint16_t *) (mbase + (int64_t) kc*2);
+        const int key = wave*32 + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
+        mkh[0][i] = *(const uint16_t *) (mbase + (int64_t) kc*2);
     }
-    float sc[4];
     #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int key = kbeg + kg + 8*i;
-        const uint32_t w[4] = { kr[i].x, kr[i].y, kr[i].z, kr[i].w };
-        float kf[8];
-        #pragma unroll
-        for (int e = 0; e < 4; e++) { kf[2*e] = h2f((uint16_t) (w[e] & 0xFFFF)); kf[2*e+1] = h2f((uint16_t) (w[e] >> 16)); }
-        float s = 0.0f;
-        #pragma unroll
-        for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[e], s);
-        s = group_sum<8>(s);
-        const float x = s * a.scale + (has_mask ? h2f(mkh[i]) : 0.0f);
-        sc[i] = key < n_kv ? x : -INFINITY;
-    }
-    {
-        float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-        m = stride8_max(m);
-        m = fmaxf(m, -1e30f);
-        float l = 0.0f, o[8];
-        #pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = 0.0f;
-        #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float pk = __expf(sc[i] - m);
-            l += pk;
-            const uint32_t w[4] = { vr[i].x, vr[i].y, vr[i].z, vr[i].w };
+    for (int r = 0; r < ROUNDS; r++) {
+        constexpr int dummy = 0; (void) dummy;
+        const int cur = r & 1, nxt = cur ^ 1;
+        const int kbeg = (r*16 + wave)*32;
+        if (r + 1 < ROUNDS) {
             #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                o[2*e]   = fmaf(pk, h2f((uint16_t) (w[e] & 0xFFFF)), o[2*e]);
-                o[2*e+1] = fmaf(pk, h2f((uint16_t) (w[e] >> 16)),    o[2*e+1]);
+            for (int i = 0; i < 4; i++) {
+                const int key = kbeg + 512 + kg + 8*i, kc = key < n_kv ? key : n_kv - 1;
+                kr[nxt][i] = *(const uint4 *) (kbase + (int64_t) kc*a.k_nb1);
+                vr[nxt][i] = *(const uint4 *) (vbase + (int64_t) kc*a.v_nb1);
+                mkh[nxt][i] = *(const uint16_t *) (mbase + (int64_t) kc*2);
             }
         }
-        l = stride8_sum(l);
+        float sc[4];
         #pragma unroll
-        for (int e = 0; e < 8; e++) o[e] = stride8_sum(o[e]);
-        if (kg == 0) {
-            *(float4 *) &wo[wave][dc*8]     = make_float4(o[0], o[1], o[2], o[3]);
-            *(float4 *) &wo[wave][dc*8 + 4] = make_float4(o[4], o[5], o[6], o[7]);
-            if (dc == 0) { wml[wave][0] = m; wml[wave][1] = l; }
+        for (int i = 0; i < 4; i++) {
+            const int key = kbeg + kg + 8*i;
+            const uint32_t w[4] = { kr[cur][i].x, kr[cur][i].y, kr[cur][i].z, kr[cur][i].w };
+            float kf[8];
+            #pragma unroll
+            for (int e = 0; e < 4; e++) { kf[2*e] = h2f((uint16_t) (w[e] & 0xFFFF)); kf[2*e+1] = h2f((uint16_t) (w[e] >> 16)); }
+            float s = 0.0f;
+            #pragma unroll
+            for (int e = 0; e < 8; e++) s = fmaf(kf[e], qf[e], s);
+            s = group_sum<8>(s);
+            const float x = s * a.scale + (has_mask ? h2f(mkh[cur][i]) : 0.0f);
+            sc[i] = key < n_kv ? x : -INFINITY;
         }
-    }
-    __syncthreads();
-    const int nparts = (n_kv + 127) >> 7;                       // <= 4
-    if (tid < 256) {
-        // chunk p = tid / 64: the merge of its four waves, as at the end of k_fattn_dec
-        const int p = tid >> 6, d = tid & 63, w0i = p*4;
-        const float m0 = wml[w0i][0], m1 = wml[w0i + 1][0], m2 = wml[w0i + 2][0], m3 = wml[w0i + 3][0];
-        const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        const float w0 = __expf(m0 - M), w1 = __expf(m1 - M), w2 = __expf(m2 - M), w3 = __expf(m3 - M);
-        ro[p][d] = fmaf(w3, wo[w0i + 3][d], fmaf(w2, wo[w0i + 2][d], fmaf(w1, wo[w0i + 1][d], w0 * wo[w0i][d])));
-        if (d == 0) {
-            rml[p][0] = M;
-            rml[p][1] = fmaf(w3, wml[w0i + 3][1], fmaf(w2, wml[w0i + 2][1], fmaf(w1, wml[w0i + 1][1], w0 * wml[w0i][1])));
+        {
+            float m = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+            m = stride8_max(m);
+            m = fmaxf(m, -1e30f);
+            float l = 0.0f, o[8];
+            #pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = 0.0f;
+            #pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float pk = __expf(sc[i] - m);
+                l += pk;
+                const uint32_t w[4] = { vr[cur][i].x, vr[cur][i].y, vr[cur][i].z, vr[cur][i].w };
+                #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    o[2*e]   = fmaf(pk, h2f((uint16_t) (w[e] & 0xFFFF)), o[2*e]);
+                    o[2*e+1] = fmaf(pk, h2f((uint16_t) (w[e] >> 16)),    o[2*e+1]);
+                }
+            }
+            l = stride8_sum(l);
+            #pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = stride8_sum(o[e]);
+            if (kg == 0) {
+                *(float4 *) &wo[wave][dc*8]     = make_float4(o[0], o[1], o[2], o[3]);
+                *(float4 *) &wo[wave][dc*8 + 4] = make_float4(o[4], o[5], o[6], o[7]);
+                if (dc == 0) { wml[wave][0] = m; wml[wave][1] = l; }
+            }
         }
+        __syncthreads();
+        if (tid < 256) {
+            // chunk p = tid / 64 of this round: the merge of its four waves, as at the end of k_fattn_dec
+            const int p = tid >> 6, d = tid & 63, w0i = p*4;
+            const float m0 = wml[w0i][0], m1 = wml[w0i + 1][0], m2 = wml[w0i + 2][0], m3 = wml[w0i + 3][0];
+            const float M = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float w0 = __expf(m0 - M), w1 = __expf(m1 - M), w2 = __expf(m2 - M), w3 = __expf(m3 - M);
+            ro[r*4 + p][d] = fmaf(w3, wo[w0i + 3][d], fmaf(w2, wo[w0i + 2][d], fmaf(w1, wo[w0i + 1][d], w0 * wo[w0i][d])));
+            if (d == 0) {
+                rml[r*4 + p][0] = M;
+                rml[r*4 + p][1] = fmaf(w3, wml[w0i + 3][1], fmaf(w2, wml[w0i + 2][1], fmaf(w1, wml[w0i + 1][1], w0 * wml[w0i][1])));
+            }
+        }
+        __syncthreads();                                          // wo / wml are rewritten by the next round; ro / rml are read below
     }
-    __syncthreads();
+    const int nparts = (n_kv + 127) >> 7;                       // <= 4 * ROUNDS
     if (tid < 64) {
         // combine of the chunk records, as k_act_prepare MODE 2 / k_gemv_row MODE 2 do it
         float M = -1e30f, L = 0.0f, o = 0.0f;
@@ -781,7 +878,8 @@ __global__ void __launch_bounds__(1024) k_fattn_self_q(const FDMArgs a) {
     }
 }
 
-// decoder self-attention for T columns (own q / K / V / mask row / key count each) straight into the Q8_0 planes of the output projection
+// decoder attention for T columns (own q / K / V / mask row / key count each; up to 1536 keys: self- and cross-attention) straight into the
+// Q8_0 planes of the output projection
 extern "C" int mi355x_flash_attn_planes(mi355x_ctx * ctx, int T, const mi355x_attn_state * st, const mi355x_tensor * q, const mi355x_tensor * k,
                                         const mi355x_tensor * v, float scale, void * planes) {
     if (T < 1 || T > MI355X_MAX_COLS || !planes || ((uintptr_t) planes % 16)) return MI355X_E_UNSUPPORTED;
@@ -793,8 +891,10 @@ extern "C" int mi355x_flash_attn_planes(mi355x_ctx * ctx, int T, const mi355x_at
     if ((q->nb[2] | k->nb[1] | k->nb[2] | v->nb[1] | v->nb[2]) % 16) return MI355X_E_UNSUPPORTED;
     FDMArgs a; memset(&a, 0, sizeof(a));
     double bytes = 0, flops = 0;
+    int max_kv = 0;
     for (int s = 0; s < T; s++) {
-        if (!st[s].q || !st[s].k || !st[s].v || st[s].n_kv < 1 || st[s].n_kv > 512) return MI355X_E_UNSUPPORTED;
+        if (!st[s].q || !st[s].k || !st[s].v || st[s].n_kv < 1 || st[s].n_kv > 1536) return MI355X_E_UNSUPPORTED;
+        if (st[s].n_kv > max_kv) max_kv = st[s].n_kv;
         if (((uintptr_t) st[s].q | (uintptr_t) st[s].k | (uintptr_t) st[s].v) % 16 || ((uintptr_t) st[s].mask % 2)) return MI355X_E_UNSUPPORTED;
         a.st[s].q = (const char *) st[s].q; a.st[s].k = (const char *) st[s].k; a.st[s].v = (const char *) st[s].v; a.st[s].m = (const char *) st[s].mask;
         a.st[s].n_kv = st[s].n_kv;
@@ -803,7 +903,10 @@ extern "C" int mi355x_flash_attn_planes(mi355x_ctx * ctx, int T, const mi355x_at
     a.q_nb2 = q->nb[2]; a.k_nb1 = k->nb[1]; a.k_nb2 = k->nb[2]; a.v_nb1 = v->nb[1]; a.v_nb2 = v->nb[2];
     a.scale = scale; a.S = T; a.H = H; a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]); a.nparts = 0;
     a.part_o = (float *) planes;            // (the planes travel in the record pointer's slot)
-    return emit(ctx, "fattn_self_q", k_fattn_self_q, dim3(H, T), dim3(1024), 0, a, bytes + (double) T*H*64*1.25, flops);
+    bytes += (double) T*H*64*1.25;
+    if (max_kv <= 512)  return emit(ctx, "fattn_self_q", k_fattn_self_q<1>, dim3(H, T), dim3(1024), 0, a, bytes, flops);
+    if (max_kv <= 1024) return emit(ctx, "fattn_self_q", k_fattn_self_q<2>, dim3(H, T), dim3(1024), 0, a, bytes, flops);
+    return emit(ctx, "fattn_self_q", k_fattn_self_q<3>, dim3(H, T), dim3(1024), 0, a, bytes, flops);
 }
 
 struct HeadArgs {

@@ -362,6 +362,7 @@ extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         const int rc = mi355x_gemv_q(ctx, d);
         return rc != MI355X_E_UNSUPPORTED ? rc : mi355x_gemv8(ctx, d);
     }
+    if (!d->x && d->has_norm && d->cols && d->cols->x[0]) return mi355x_gemv_q(ctx, d);      // the plane kernel's LayerNorm form (no planes in HBM)
     {   // the lean decode kernels (decode.hip) take every quantized shape of the whisper graphs; what is left for k_gemv below:
         // F16 weights (f16 models), LDS-heavy shapes (K*T too large for the 64 KB planes)
         const int rc = mi355x_gemv8(ctx, d);
