@@ -1187,9 +1187,10 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
     }
     end_out = ch[n - 1].end; rc_out = 0;
     if (!k) return true;
-    // LayerNorm in the mat-vec's own prologue (one launch) — or, GGML_MI355X_LN_FUSED=0 / shapes the plane kernel does not take
-    // that way, k_act_prepare -> planes -> mat-vec (two launches)
-    static const bool ln_fused = !getenv("GGML_MI355X_LN_FUSED") || atoi(getenv("GGML_MI355X_LN_FUSED")) != 0;
+    // k_act_prepare -> planes -> mat-vec (two launches), or with GGML_MI355X_LN_FUSED=1 the LayerNorm in the mat-vec's own prologue (one
+    // launch).  The one launch is SLOWER (the normalisation of T columns repeated in 256-768 workgroups is VALU time: LN + Q/K/V 15.7 us
+    // against 4.5 + 7.2; profiles/r03_plane_ln_and_one_launch_cross_attention_ab.txt), so it is off by default.
+    static const bool ln_fused = getenv("GGML_MI355X_LN_FUSED") && atoi(getenv("GGML_MI355X_LN_FUSED")) != 0;
     mi355x_act_desc a; memset(&a, 0, sizeof(a));
     a.K = (int) K; a.T = cs.T; a.wtype = (int32_t) w0->type; a.has_norm = 1; memcpy(&a.eps, ln.norm->op_params, sizeof(float)); a.ln_w = ln.w; a.ln_b = ln.b;
     for (int c = 0; c < cs.T; c++) a.xcol[c] = (const float *) cs_col(cs, c, i, 0);
@@ -1281,10 +1282,11 @@ static bool q_attn_proj(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, in
         }
         max_kv = std::max(max_kv, (int) st[c].n_kv);
     }
-    // ONE launch from q / K / V to the projection's activation planes: self-attention, and cross-attention's 1500 keys
-    // (GGML_MI355X_ATTN_PLANES_MAX_KV=512: cross-attention as partial records + combine, the first form of this pipeline)
+    // ONE launch from q / K / V to the projection's activation planes for self-attention (<= 512 keys).  GGML_MI355X_ATTN_PLANES_MAX_KV=1536
+    // sends cross-attention's 1500 keys the same way (three rounds in one 16-wave workgroup per (head, column)): no gain — 13.5 us against
+    // 6.5 + 6.7 for partial records + combine, 8 streams 9.53 against 9.75 chunks/s (same profile file) — so the default stays 512.
     static const bool self_planes = env_flag("GGML_MI355X_SELF_ATTN_PLANES", true);
-    static const int planes_max_kv = getenv("GGML_MI355X_ATTN_PLANES_MAX_KV") ? atoi(getenv("GGML_MI355X_ATTN_PLANES_MAX_KV")) : 1536;
+    static const int planes_max_kv = getenv("GGML_MI355X_ATTN_PLANES_MAX_KV") ? atoi(getenv("GGML_MI355X_ATTN_PLANES_MAX_KV")) : 512;
     bool have_planes = false;
     if (self_planes && max_kv <= planes_max_kv && w->type != GGML_TYPE_Q4_K && (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2))) {
         rc = mi355x_flash_attn_planes(k, cs.T, st, &mq, &mk, &mv, scale, p0);

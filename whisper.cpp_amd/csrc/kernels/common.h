@@ -79,6 +79,7 @@ static inline int emit(mi355x_ctx * ctx, const char * name, void (*kernel)(Args)
 int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
 // mat-vec over pre-quantized activation planes (decode_q.hip); MI355X_E_UNSUPPORTED => mi355x_gemv8 copies the same planes (k_gemv8)
 int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
+int mi355x_vocab(mi355x_ctx * ctx, const mi355x_gemv_desc * d);       // decode_q.hip: the vocabulary projection (N > 8192)
 
 // ---------------------------------------------------------------------------------------------
 // tensor helpers (host)

@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
         }
     }
     load_chunk(cur, 0);
+    if (total > 1) load_chunk(nxt, 1);
 
     if (a.xq) {
         // activations arrive quantized (decode_q.hip: k_act_prepare / a producer's epilogue): the image of the planes is copied as it is
@@ -201,18 +202,25 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
     #pragma unroll
     for (int t = 0; t < (Q4K ? T : 1); t++) accm[t] = 0.0f;
 
-    for (int it = 0; it < total; it++) {
-        if (it + 1 < total) load_chunk(nxt, it + 1);
+    // two chunks in flight per wave: chunk 0 and chunk 1 were requested BEFORE the prologue, a buffer is refilled with chunk + 2 as soon
+    // as it has been used (in-order return: the wait for buffer A leaves buffer B's loads outstanding)
+    for (int it0 = 0; it0 < total; it0 += 2) {
+      #pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int it = it0 + half;
+        if (it >= total) break;
+        wblk<WT> * buf = half == 0 ? cur : nxt;             // (static after unrolling: no lambda here — capturing acc[] by reference
+                                                            //  sends the (j8 == t) select chain below through scratch memory)
         const int pass = it / nchunks, c = it - pass*nchunks;
         #pragma unroll
         for (int u = 0; u < U; u++) {
             const int g = j8 + LPR*(c*U + u);
             if constexpr (Q4K) {
-                if (g < nb) wblk_dot_q4k<T>(cur[u], g, 1.0f, nb, nsb, alo, dx, sx, acc, accm);
+                if (g < nb) wblk_dot_q4k<T>(buf[u], g, 1.0f, nb, nsb, alo, dx, sx, acc, accm);
             } else if (g < nb) {
                 uint32_t vlo[4], vhi[4];
-                wblk_unpack<WT>(cur[u], vlo, vhi);
-                const float dw = h2f(cur[u].d);
+                wblk_unpack<WT>(buf[u], vlo, vhi);
+                const float dw = h2f(buf[u].d);
                 constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
                 #pragma unroll
                 for (int t = 0; t < T; t++) {
@@ -265,8 +273,8 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
             #pragma unroll
             for (int t = 0; t < T; t++) acc[t] = 0.0f;
         }
-        #pragma unroll
-        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+        if (it + 2 < total) load_chunk(buf, it + 2);
+      }
     }
 }
 

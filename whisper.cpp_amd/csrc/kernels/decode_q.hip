@@ -596,6 +596,242 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// k_vocab: the vocabulary projection (final LayerNorm + [n_vocab x K] mat-vec, src/whisper.cpp:2832-2844), N > 8192 rows
+// ---------------------------------------------------------------------------------------------------
+// The one decode kernel that is bandwidth-bound (45.6 MB for large-v3 Q5_0, read once per step).  k_gemv8 serves it with its generic
+// machinery (segments, passes x chunks with divisions, epilogue options, predicated units: ~3300 instructions); here the same per-row
+// arithmetic — 8 lanes per weight row, lane j takes units j, j + 8, ..., f32 fma chain in unit order, 3-step lane reduction — runs with
+// nothing else around it:
+//   * every wave owns row groups g, g + stride, ... (8 rows each) and has TWO of them in flight (both requested before the prologue,
+//     a buffer is refilled as soon as it has been used); the launch is sized so that two groups per wave cover the matrix: all of it
+//     is requested in the first microsecond;
+//   * per lane one base pointer per plane, the units are immediate offsets, the next group is one scalar add;
+//   * T = 1: the lane's activation blocks (the same for every row) are read from LDS once and kept in registers;
+//   * the prologue is k_act_prepare's LayerNorm (same statements: the planes equal the ones a cross-state batch prepares) or a copy of
+//     prepared planes.
+// K % 256 == 0 (8 | K/32), K <= 2048, one segment, no epilogue options, F32 destinations (per column) + optional mirror.
+struct VArgs {
+    const void * w; int64_t nbt; int N, K, T, has_norm;
+    const float * x; int64_t x_nb1; const float * ln_w; const float * ln_b; float eps; int pad;
+    const void * xq;
+    void * dstcol[MI355X_MAX_COLS]; void * mircol[MI355X_MAX_COLS];
+};
+
+template <int WT, int TMAX, int U>
+__global__ void __launch_bounds__(512) k_vocab(const VArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ float red[2][TMAX][8];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r8 = lane >> 3, j8 = lane & 7;
+    const int K = a.K, T = a.T, N = a.N;
+    constexpr int nb = U * 8;
+    const int ngroups = (N + 7) >> 3;
+    const int stride = gridDim.x * 8;
+    int grp = blockIdx.x * 8 + wave;
+
+    // ---- loads: activations (L2) first, then two row groups of weights (HBM) ----
+    const int K4 = K >> 2, e4c = tid < K4 ? tid : K4 - 1;
+    float4 xr[TMAX], lw, lb;
+    if (a.has_norm) {
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) xr[tt] = *(const float4 *) ((const char *) a.x + (int64_t) (tt < T ? tt : T - 1)*a.x_nb1 + (size_t) e4c*16);
+        lw = *(const float4 *) (a.ln_w + e4c*4); lb = *(const float4 *) (a.ln_b + e4c*4);
+    }
+    wblk<WT> A[U], B[U];
+    auto load_group = [&](wblk<WT> * buf, int g) {
+        const int gc = g < ngroups ? g : ngroups - 1;
+        int row = gc*8 + r8; row = row < N ? row : N - 1;
+        const int64_t ib = (int64_t) row*nb + j8;
+        #pragma unroll
+        for (int u = 0; u < U; u++) wblk_load<WT>(buf[u], (const char *) a.w, a.nbt, ib + 8*u);
+    };
+    load_group(A, grp);
+    load_group(B, grp + stride);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- prologue: activation planes in LDS ----
+    uint32_t * plo, * phi; float * pdx; int * psx;
+    planes_of<false>(smem, K, T, plo, phi, pdx, psx);
+    if (a.has_norm) {
+        // k_act_prepare MODE 1, all columns at once (blockDim 512: waves >= K4/64 contribute zeros)
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) {
+            float p = 0.0f;
+            if (tid < K4) p += (xr[tt].x + xr[tt].y) + (xr[tt].z + xr[tt].w);
+            p = wave_sum(p);
+            if (lane == 0) red[0][tt][wave] = p;
+        }
+        __syncthreads();
+        float mean[TMAX];
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) {
+            float rs = 0.0f;
+            #pragma unroll
+            for (int w = 0; w < 8; w++) rs += red[0][tt][w];
+            mean[tt] = rs / K;
+            float p = 0.0f;
+            if (tid < K4) {
+                const float d0 = xr[tt].x - mean[tt], d1 = xr[tt].y - mean[tt], d2 = xr[tt].z - mean[tt], d3 = xr[tt].w - mean[tt];
+                p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+            }
+            p = wave_sum(p);
+            if (lane == 0) red[1][tt][wave] = p;
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int tt = 0; tt < TMAX; tt++) {
+            float rs = 0.0f;
+            #pragma unroll
+            for (int w = 0; w < 8; w++) rs += red[1][tt][w];
+            const float rstd = 1.0f / sqrtf(rs / K + a.eps);
+            if (tt < T && tid < K4) {
+                float o[4] = { (xr[tt].x - mean[tt]) * rstd, (xr[tt].y - mean[tt]) * rstd, (xr[tt].z - mean[tt]) * rstd, (xr[tt].w - mean[tt]) * rstd };
+                o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
+                o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
+                dg_q8_0_store(o, tid*4, tt, nb, plo, phi, pdx, psx);
+            }
+        }
+    } else {
+        const int n16 = (int) ((dg_act_bytes(WT, K, T) + 15) >> 4);
+        for (int idx = tid; idx < n16; idx += 512) ((u32x4 *) smem)[idx] = ((const u32x4 *) a.xq)[idx];
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4 * alo = (const uint4 *) plo, * ahi = (const uint4 *) phi;
+    constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+
+    // T = 1: this lane's activation blocks never change
+    uint4 ral[TMAX == 1 ? U : 1], rah[TMAX == 1 ? U : 1]; float rdx[TMAX == 1 ? U : 1]; int rsx[TMAX == 1 ? U : 1];
+    if constexpr (TMAX == 1) {
+        #pragma unroll
+        for (int u = 0; u < U; u++) { const int g = j8 + 8*u; ral[u] = alo[g]; rah[u] = ahi[g]; rdx[u] = pdx[g]; rsx[u] = off * psx[g]; }
+    }
+    // this lane's destination column (lane j8 == t finishes column t)
+    float * dcol = (float *) a.dstcol[0]; float * mcol = (float *) a.mircol[0];
+    #pragma unroll
+    for (int t = 1; t < TMAX; t++) { dcol = j8 == t ? (float *) a.dstcol[t] : dcol; mcol = j8 == t ? (float *) a.mircol[t] : mcol; }
+
+    for (; grp < ngroups; grp += 2*stride) {
+      #pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int g_ = grp + half*stride;
+        if (g_ >= ngroups) break;
+        wblk<WT> * buf = half == 0 ? A : B;
+        float acc[TMAX];
+        #pragma unroll
+        for (int t = 0; t < TMAX; t++) acc[t] = 0.0f;
+        #pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int g = j8 + 8*u;
+            uint32_t vlo[4], vhi[4];
+            wblk_unpack<WT>(buf[u], vlo, vhi);
+            const float dw = h2f(buf[u].d);
+            #pragma unroll
+            for (int tt = 0; tt < TMAX; tt++) {
+                uint4 al, ah; float dxv; int sxo;
+                if constexpr (TMAX == 1) { al = ral[u]; ah = rah[u]; dxv = rdx[u]; sxo = rsx[u]; }
+                else { const int t = tt < T ? tt : T - 1; al = alo[(size_t) t*nb + g]; ah = ahi[(size_t) t*nb + g]; dxv = pdx[t*nb + g]; sxo = off ? off * psx[t*nb + g] : 0; }
+                int sum = 0;
+                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
+                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
+                if (off) sum -= sxo;
+                acc[tt] = fmaf(dw * dxv, (float) sum, acc[tt]);
+                if constexpr (TMAX > 2) __builtin_amdgcn_sched_barrier(0);      // (keeps the LDS reads of later columns from being hoisted: registers)
+            }
+            if constexpr (TMAX == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        #pragma unroll
+        for (int t = 0; t < TMAX; t++) acc[t] = group_sum<8>(acc[t]);
+        float v = acc[0];
+        #pragma unroll
+        for (int t = 1; t < TMAX; t++) v = (j8 == t) ? acc[t] : v;
+        const int row = g_*8 + r8;
+        if (row < N && j8 < T) {
+            dcol[row] = v;
+            if (mcol) mcol[row] = v;
+        }
+        load_group(buf, g_ + 2*stride);
+      }
+    }
+}
+
+template <int WT, int TMAX>
+static int launch_vocab_u(mi355x_ctx * ctx, const VArgs & k, int U, dim3 grid, uint32_t lds, double bytes, double flops) {
+    switch (U) {
+        case 2: return emit(ctx, "vocab", k_vocab<WT, TMAX, 2>, grid, dim3(512), lds, k, bytes, flops);
+        case 3: return emit(ctx, "vocab", k_vocab<WT, TMAX, 3>, grid, dim3(512), lds, k, bytes, flops);
+        case 4: return emit(ctx, "vocab", k_vocab<WT, TMAX, 4>, grid, dim3(512), lds, k, bytes, flops);
+        case 5: return emit(ctx, "vocab", k_vocab<WT, TMAX, 5>, grid, dim3(512), lds, k, bytes, flops);
+    }
+    return MI355X_E_UNSUPPORTED;
+}
+template <int WT>
+static int launch_vocab(mi355x_ctx * ctx, const VArgs & k, int U, dim3 grid, uint32_t lds, double bytes, double flops) {
+    if (k.T == 1) return launch_vocab_u<WT, 1>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T == 2) return launch_vocab_u<WT, 2>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T <= 4) return launch_vocab_u<WT, 4>(ctx, k, U, grid, lds, bytes, flops);
+    return launch_vocab_u<WT, 8>(ctx, k, U, grid, lds, bytes, flops);
+}
+
+// the vocabulary projection: MI355X_E_UNSUPPORTED = not this shape (the caller goes on to k_gemv8)
+int mi355x_vocab(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
+    static const bool on = !getenv("GGML_MI355X_VOCAB_KERNEL") || atoi(getenv("GGML_MI355X_VOCAB_KERNEL")) != 0;
+    if (!on || d->nseg != 1 || d->T < 1 || d->T > MI355X_MAX_COLS || d->attn_part_o) return MI355X_E_UNSUPPORTED;
+    const mi355x_gemv_seg & g = d->seg[0];
+    const int wt = g.wtype, K = d->K, T = d->T, N = g.N;
+    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0) return MI355X_E_UNSUPPORTED;
+    if (N <= 8192 || K <= 0 || K % 256 || K > 2048 || K / 256 < 2 || K / 256 > 5) return MI355X_E_UNSUPPORTED;
+    if (g.ep.bias || g.ep.has_scale || g.ep.gelu || g.ep.residual || g.dst_type != MI355X_TYPE_F32 || ((uintptr_t) g.w % 16)) return MI355X_E_UNSUPPORTED;
+    const bool planes = d->x_planes != nullptr;
+    if (planes ? (d->x != nullptr || d->has_norm || ((uintptr_t) d->x_planes % 16)) : (!d->x || !d->has_norm)) return MI355X_E_UNSUPPORTED;
+    VArgs k; memset(&k, 0, sizeof(k));
+    k.w = g.w; k.nbt = (int64_t) N * (K / 32); k.N = N; k.K = K; k.T = T;
+    if (planes) k.xq = d->x_planes;
+    else {
+        if (!d->ln_w || !d->ln_b || (((uintptr_t) d->x | (uintptr_t) d->ln_w | (uintptr_t) d->ln_b) % 16) || (d->x_nb1 % 16)) return MI355X_E_UNSUPPORTED;
+        k.has_norm = 1; k.x = d->x; k.x_nb1 = d->x_nb1; k.ln_w = d->ln_w; k.ln_b = d->ln_b; k.eps = d->eps;
+    }
+    const bool cols = planes && d->cols;
+    bool mirror = d->cols && d->cols->mirror[0];
+    for (int t = 0; t < MI355X_MAX_COLS; t++) {
+        const int tc = t < T ? t : T - 1;
+        k.dstcol[t] = cols ? d->cols->dst[0][tc] : (g.dst ? (char *) g.dst + (int64_t) tc*g.dst_nb1 : nullptr);
+        k.mircol[t] = mirror ? d->cols->mirror[tc] : nullptr;
+        if (!k.dstcol[t] || ((uintptr_t) k.dstcol[t] % 4) || (mirror && !k.mircol[t])) return MI355X_E_UNSUPPORTED;
+    }
+    const size_t lds = ((dg_act_bytes(wt, K, T) + 15) & ~(size_t) 15) + 16;
+    if (lds > 64 * 1024) return MI355X_E_UNSUPPORTED;
+    // 8-wave workgroups, every wave walking 4 row groups with two of them in flight (measured, large-v3 Q5_0, HBM-cold, rocprofv3:
+    // 4 groups per wave = 203 workgroups 11.1 us, one workgroup per CU 11.6, 2 groups per wave 12.3, 1 per wave 14.1, 8 per wave 15.2;
+    // k_gemv8 17.9; a read-once stream of the same bytes 9.0 — profiles/r03_vocab_kernel.txt).
+    // GGML_MI355X_VOCAB_GROUPS=n: n groups per wave; GGML_MI355X_VOCAB_WGS_PER_CU=m: m workgroups per CU instead.
+    static const int env_gpw = getenv("GGML_MI355X_VOCAB_GROUPS") ? atoi(getenv("GGML_MI355X_VOCAB_GROUPS")) : 4;
+    static const int env_wpc = getenv("GGML_MI355X_VOCAB_WGS_PER_CU") ? atoi(getenv("GGML_MI355X_VOCAB_WGS_PER_CU")) : 0;
+    const int ngroups = (N + 7) / 8;
+    int nwg = ((ngroups + 3) / 4 + 7) / 8;
+    if (env_gpw >= 1 && env_gpw <= 64) nwg = ((ngroups + env_gpw - 1) / env_gpw + 7) / 8;
+    if (env_wpc >= 1 && env_wpc <= 8) nwg = ctx->n_cu * env_wpc;
+    if (nwg > (ngroups + 7) / 8) nwg = (ngroups + 7) / 8;
+    const dim3 grid(nwg);
+    const double bytes = (double) mi355x_type_row_bytes(wt, K) * N + (double) K*T*4 + (double) N*T*4;
+    const double flops = 2.0 * N * K * T;
+    int rc;
+    switch (wt) {
+        case MI355X_TYPE_Q4_0: rc = launch_vocab<MI355X_TYPE_Q4_0>(ctx, k, K / 256, grid, (uint32_t) lds, bytes, flops); break;
+        case MI355X_TYPE_Q5_0: rc = launch_vocab<MI355X_TYPE_Q5_0>(ctx, k, K / 256, grid, (uint32_t) lds, bytes, flops); break;
+        default:               rc = launch_vocab<MI355X_TYPE_Q8_0>(ctx, k, K / 256, grid, (uint32_t) lds, bytes, flops); break;
+    }
+    if (rc == 0 && mirror) ctx->last_mirrored = 1;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // cross-state batches: attention and step head for S single-token states in one launch
 // ---------------------------------------------------------------------------------------------------
 struct FDMState { const char * q; const char * k; const char * v; const char * m; int n_kv; int pad; };

@@ -358,6 +358,10 @@ static int launch_gemv_T(mi355x_ctx * ctx, const GemvArgs & k, int T, dim3 grid,
 extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     ctx->last_mirrored = 0;
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
+    {   // the vocabulary projection has its own kernel (LayerNorm form or prepared planes)
+        const int rc = mi355x_vocab(ctx, d);
+        if (rc != MI355X_E_UNSUPPORTED) return rc;
+    }
     if (d->x_planes) {   // activations already quantized (decode_q.hip pipeline): lean plane kernel, else the generic k_gemv8 on the same planes
         const int rc = mi355x_gemv_q(ctx, d);
         return rc != MI355X_E_UNSUPPORTED ? rc : mi355x_gemv8(ctx, d);
