@@ -42,7 +42,7 @@ typedef struct mi355x_host_config {
     int32_t device_greedy;         /* 1 (GPU only): every stream decodes FREE-RUNNING — the token fed to step i + 1 is the arg-max of step i's logits, taken ON
                                     * THE DEVICE by ggml_backend_mi355x_argmax_last (16 bytes back instead of a host scan of n_vocab floats) and checked
                                     * against the host scan of the row whisper_decode returned (result: greedy_checked / greedy_mismatches) */
-    int32_t batching;              /* cross-state batching in the plugin (ggml_backend_mi355x_set_batching): 1 on, 0 off, -1 leave as it is.  With
+    int32_t batching;              /* cross-state batching in the plugin (ggml_backend_mi355x_set_batching): 1 on (merged chains from 5 states on), n >= 2 on from n states, 0 off, -1 leave as it is.  With
                                     * it the states of one device that decode at the same time run as the columns of ONE launch chain */
 } mi355x_host_config;
 

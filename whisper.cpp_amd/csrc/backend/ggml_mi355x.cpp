@@ -1635,11 +1635,20 @@ struct mi_batch_group {
     uint64_t    n_batches = 0, n_columns = 0, n_solo = 0, n_fallback = 0, n_timeouts = 0;
 };
 static mi_batch_group     g_batch[MI_MAX_DEVICES];
-static std::atomic<int>   g_batching{-1};            // -1: not decided yet (environment), 0 off, 1 on
+static std::atomic<int>   g_batching{-1};            // -1: not decided yet (environment), 0 off, 1 on (from mi_batch_min_states() states), n >= 2: on from n states
 static bool mi_batching_on() {
     int v = g_batching.load();
-    if (v < 0) { v = env_flag("GGML_MI355X_BATCH", false) ? 1 : 0; g_batching.store(v); }
+    if (v < 0) { const char * e = getenv("GGML_MI355X_BATCH"); v = e ? std::max(0, atoi(e)) : 0; g_batching.store(v); }
     return v != 0;
+}
+// Fewer decoding states than this run their own chains side by side (states-on-streams) although batching is on: a merged chain costs
+// 12 launches per layer against 8 and moves the states in lockstep (their host phases no longer hide behind each other's GPU work) —
+// measured large-v3 Q5_0: 2 / 4 states 3.35 / 5.96 chunks/s merged against 4.1 / 7.5 on their own streams, 8 states 9.75 against 2.8
+// (profiles/r03_stream_scaling_*).  ggml_backend_mi355x_set_batching(n >= 2) / GGML_MI355X_BATCH=n sets the threshold to n.
+static int mi_batch_min_states() {
+    static const int env_min = getenv("GGML_MI355X_BATCH_MIN_STREAMS") ? std::max(2, atoi(getenv("GGML_MI355X_BATCH_MIN_STREAMS"))) : 5;
+    const int v = g_batching.load();
+    return v >= 2 ? v : env_min;
 }
 
 // a single-token decoder step?  (cheap signature; whether every node fits is decided once per graph shape by the dry walk)
@@ -1729,6 +1738,12 @@ static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
     std::unique_lock<std::mutex> lk(grp.m);
     if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
+    if ((int) grp.members.size() < mi_batch_min_states()) {
+        // too few decoding states for a merged chain to pay: this step runs on the state's own stream (it stays counted)
+        bool idle = true;
+        for (int i = 0; i < MI_BATCH_LANES; i++) idle = idle && !grp.lanes[i].busy;
+        if (idle && grp.waiting.empty()) { grp.n_solo++; lk.unlock(); return mi_compute_own(b, cgraph); }
+    }
     grp.waiting.push_back(&me);
     const double arrived = now_ms();
     grp.cv.notify_all();                                      // a waiter may now have its full set
@@ -2017,7 +2032,7 @@ int ggml_backend_mi355x_argmax_last(int row, float * top1, float * margin) {
 }
 
 // cross-state batching (mi_batch_group): on = 1 / 0 at run time (the environment's GGML_MI355X_BATCH is only the initial value)
-void ggml_backend_mi355x_set_batching(int on) { g_batching.store(on ? 1 : 0); }
+void ggml_backend_mi355x_set_batching(int on) { g_batching.store(on > 0 ? on : 0); }
 // out[0..4] of `device`: merged launch chains, columns they carried, steps a state ran alone, groups that fell back to one launch chain
 // per state (graphs did not fit), windows that closed on an absent state
 void ggml_backend_mi355x_batch_stats(int device, uint64_t * out5) {
