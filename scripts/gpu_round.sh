@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call: GPU pytest, bench, rocprofv3 kernel trace (+ optional PMC passes).  Logs land in gpurun_out/.
-# usage: scripts/gpu_round.sh [stage ...]    stages: pytest bench prof pmc wbench   (default: pytest bench prof)
+# usage: scripts/gpu_round.sh [stage ...]    stages: pytest bench prof pmc wbench kbench   (default: pytest bench prof)
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
@@ -49,15 +49,6 @@ pmc)
         python3 scripts/summarize_pmc.py "$OUT/pmc_$tag" > "$OUT/pmc_$tag.summary.txt" 2>&1; head -30 "$OUT/pmc_$tag.summary.txt"
         find "$OUT/pmc_$tag" -name "*.csv" -size +20M -delete
     done
-    ;;
-eager)
-    stage "bench.py with GGML_MI355X_GRAPHS=0 (eager launches) under rocprofv3"
-    rm -rf "$OUT/prof_eager"
-    ( cd /tmp && GGML_MI355X_GRAPHS=0 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_eager" -o bench -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 1 --no-cpu-baseline --no-profile --multi-stream 0 \
-        > "$OUT/prof_eager.json" 2> "$OUT/prof_eager.err" )
-    echo "exit=$?"; cat "$OUT/prof_eager.json" | cut -c1-900
-    python3 scripts/summarize_trace.py "$OUT/prof_eager" > "$OUT/kernel_trace_summary_eager.txt" 2>&1; grep -v "at::\|rocclr" "$OUT/kernel_trace_summary_eager.txt" | head -12; sed -n '/decode-step anatomy/,$p' "$OUT/kernel_trace_summary_eager.txt" | head -50
-    find "$OUT/prof_eager" -name "*kernel_trace.csv" -size +20M -delete
     ;;
 kbench)
     stage "kernel micro-benchmarks under rocprofv3 (variants: $KB_VARIANTS)"

@@ -1,0 +1,58 @@
+#!/bin/bash
+# Round-3 closing GPU call: full GPU suite, headline bench (with roofline, cpu_baseline, multi_stream), rocprofv3 kernel trace + stats, PMC passes,
+# stock whisper-bench + plugin, the other BASELINE configs, per-step host timeline, stream-scaling tables.  Everything lands in gpurun_out/.
+cd "$(dirname "$0")/.."
+ROOT=$PWD; OUT=$ROOT/gpurun_out; mkdir -p "$OUT"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 GPU_MAX_HW_QUEUES=8
+export GGML_MI355X_PLUGIN=$ROOT/whisper.cpp_amd/lib/libggml-mi355x.so
+STAGES=${*:-main configs trace scaling}
+stage() { echo; echo "=== $1 === $(date +%T)"; }
+for s in $STAGES; do case $s in
+main)
+    PYTEST_ARGS="--timeout 900 --timeout-method=thread" bash scripts/gpu_round.sh pytest bench prof pmc wbench > "$OUT/round_full.log" 2>&1
+    grep -E "passed|failed|^FAILED|^ERROR" "$OUT/pytest_gpu.txt" | tail -8
+    cut -c1-900 "$OUT/bench_large-v3_q5_0.json"
+    grep -E "time =" "$OUT/wbench_gpu_large-v3_q5_0.log"
+    ;;
+configs)
+    stage "other configurations of BASELINE.json (3 steps each, no CPU leg)"
+    for spec in "large-v3-turbo q8_0" "large-v3 q4_k" "large-v3 q8_0" "base.en q5_0" "tiny.en q5_0" "tiny.en f16"; do
+        set -- $spec
+        timeout 400 python3 bench.py --arch "$1" --qtype "$2" --steps 3 --warmup 1 --no-cpu-baseline --multi-stream 0 > "$OUT/bench_$1_$2.json" 2> "$OUT/bench_$1_$2.err"
+        python3 -c "
+import json
+try:
+    d=json.load(open('$OUT/bench_$1_$2.json')); r=d.get('roofline') or {}
+    print('$1 $2: ms/chunk', d['value'], 'encode', d['encode_ms'], 'decode ms/token', d['decode_ms_per_token'], 'batchd', d['batchd_ms_per_token'], 'prompt', d['prompt_ms_per_token'], '| roofline', r.get('kernel'), r.get('frac'))
+except Exception as e: print('$1 $2: failed', e)"
+    done
+    ;;
+trace)
+    stage "per-step host timeline (tests/native/bin/step_trace), traced and untraced"
+    export LD_LIBRARY_PATH=$ROOT/whisper.cpp_amd/host/_whisper:$ROOT/whisper.cpp_amd/lib:${LD_LIBRARY_PATH:-}
+    for spec in "large-v3 q5_0" "large-v3-turbo q8_0" "base.en q5_0"; do
+        set -- $spec
+        m=$(python3 scripts/synth_model.py --arch "$1" --qtype "$2")
+        GGML_MI355X_TRACE=1 GGML_MI355X_STRICT=1 timeout 300 tests/native/bin/step_trace "$m" 256 32 > "$OUT/r03_step_trace_$1_$2.json" 2> "$OUT/r03_step_trace_$1_$2.err"
+        GGML_MI355X_STRICT=1 timeout 300 tests/native/bin/step_trace "$m" 256 32 > "$OUT/r03_step_trace_untraced_$1_$2.json" 2>> "$OUT/r03_step_trace_$1_$2.err"
+        python3 -c "
+import json
+for f in ('$OUT/r03_step_trace_$1_$2.json', '$OUT/r03_step_trace_untraced_$1_$2.json'):
+    try:
+        d=json.load(open(f)); print('$1 $2', 'traced' if d['plugin_side'].get('tracing') else 'untraced', 'whisper_decode', d['whisper_decode'], 'reference', d['reference_side'], 'derived', d.get('derived'))
+    except Exception as e: print(f, 'failed', e)"
+    done
+    ;;
+scaling)
+    stage "concurrent streams on one GPU: own chains | merged chains"
+    timeout 900 python3 scripts/stream_scaling.py --arch large-v3 --qtype q5_0 --streams 1,2,4,6,8 --batching 0 --n-decode 256 --steps 2 > "$OUT/r03_stream_scaling_unbatched.txt" 2>&1
+    grep -v '"rows"' "$OUT/r03_stream_scaling_unbatched.txt" | cut -c1-130
+    timeout 900 python3 scripts/stream_scaling.py --arch large-v3 --qtype q5_0 --streams 2,4 --batching 2 --n-decode 256 --steps 2 > "$OUT/r03_stream_scaling_merged_from2.txt" 2>&1
+    grep -v '"rows"' "$OUT/r03_stream_scaling_merged_from2.txt" | cut -c1-130
+    timeout 900 python3 scripts/stream_scaling.py --arch large-v3 --qtype q5_0 --streams 4,6,8,12,16 --batching 1 --n-decode 256 --steps 2 > "$OUT/r03_stream_scaling_batched.txt" 2>&1
+    grep -v '"rows"' "$OUT/r03_stream_scaling_batched.txt" | cut -c1-130
+    timeout 600 python3 scripts/stream_scaling.py --arch large-v3-turbo --qtype q8_0 --streams 1,4,8,16 --batching 0,1 --n-decode 256 --steps 2 > "$OUT/r03_stream_scaling_turbo.txt" 2>&1
+    grep -v '"rows"' "$OUT/r03_stream_scaling_turbo.txt" | cut -c1-130
+    ;;
+esac; done
+echo; echo "=== done $(date +%T)"
