@@ -821,6 +821,20 @@ def test_planted_large_margin_model_is_transcribed_token_for_token(plugin_env, a
     assert d["greedy"]["min_margin"] > 5.0, d["greedy"]          # the margins really are large (random-weight models: ~0.01)
 
 
+@pytest.mark.parametrize("n_tokens,flash_attn", [(5, 1), (3, 1), (8, 1), (5, 0), (2, 1)])
+def test_first_multi_token_step_of_a_process_equals_every_later_one(plugin_env, n_tokens, flash_attn):
+    """the same whisper_decode(n tokens) issued 24 times in a FRESH process: every run's logits equal the first run's bit for bit
+    (tests/native/repeat_check.cpp).  Round 3 found the first one off at random: the activation planes' zero-fill ran on the null stream,
+    unordered with the backend's stream, and could land inside the first chain that used the planes."""
+    from synth_model import make_model
+    m = make_model("base.en", "q5_0")
+    r = subprocess.run([str(_native("repeat_check")), str(m), str(n_tokens), "24", str(flash_attn), "3"], env=dict(plugin_env, GGML_MI355X_STRICT="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode in (0, 1), r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["reps"] == 24 and d["mismatching_runs"] == 0, d
+
+
 def test_whisper_full_with_batching_switched_on_and_one_state(plugin_env):
     """GGML_MI355X_BATCH=1 with a single whisper_state: every decoder step joins the device's group alone and must take exactly the
     ordinary path (prompt and beam-search graphs leave the group) — the planted transcript comes out for both samplers"""

@@ -333,6 +333,48 @@ def test_vocabulary_projection_over_planes_with_per_state_destinations(gpu, orac
         assert np.array_equal(outs[c].cpu().numpy().view(np.uint32), ref.view(np.uint32)), c
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("t,K,T", [("q5_0", 1280, 5), ("q5_0", 512, 3), ("q8_0", 1280, 5), ("q4_0", 768, 7), ("q5_0", 1280, 8), ("q5_0", 512, 2), ("q5_0", 1280, 1)])
+def test_vocabulary_projection_mirror_rows_equal_the_destination_rows(gpu, oracle, t, K, T, pinned):
+    """k_vocab with a second (mirror) destination per column — the host-visible copy whisper's logits read-back is served from — for every
+    column count incl. those below the kernel's built-in maximum (T = 3, 5, 7), planes form and LayerNorm form (T <= 2)"""
+    ctx, ka, torch = gpu
+    tid = QT[t]
+    N = 51864 if K == 512 else 51866
+    rng = np.random.default_rng(K + T + tid)
+    x = (rng.standard_normal((T, K)) * 2).astype(np.float32)
+    lw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
+    lb = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    _, planar = quantize(oracle, ka, tid, (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
+    x_d, lw_d, lb_d, w_d = dev(torch, x), dev(torch, lw), dev(torch, lb), dev(torch, planar)
+    y = torch.zeros((T, N), dtype=torch.float32, device="cuda:0")
+    # pinned: the mirror lives in page-locked HOST memory (what the backend uses), written by the kernel across PCIe
+    mir = torch.full((T, N), -7.0, dtype=torch.float32).pin_memory() if pinned else torch.full((T, N), -7.0, dtype=torch.float32, device="cuda:0")
+    cols = ka.GemvCols()
+    for c in range(T):
+        cols.dst[0][c] = y.data_ptr() + c * N * 4
+        cols.mirror[c] = mir.data_ptr() + c * N * 4
+    d = ka.GemvDesc()
+    d.K, d.T, d.nseg, d.cols = K, T, 1, C.addressof(cols)
+    _seg(ka, d, 0, w_d, tid, N, y)
+    if T <= 2:
+        d.x, d.x_nb1, d.has_norm, d.eps, d.ln_w, d.ln_b = x_d.data_ptr(), K * 4, 1, 1e-5, lw_d.data_ptr(), lb_d.data_ptr()
+    else:
+        planes = _planes(ctx, ka)
+        a = ka.ActDesc()
+        a.x, a.x_nb1, a.K, a.T, a.wtype, a.has_norm, a.eps, a.ln_w, a.ln_b = x_d.data_ptr(), K * 4, K, T, tid, 1, 1e-5, lw_d.data_ptr(), lb_d.data_ptr()
+        ctx.check(ka.lib().mi355x_act_prepare(ctx.h, C.byref(a), planes), "act_prepare")
+        d.x_planes = planes
+    torch.cuda.synchronize()
+    ctx.check(ka.lib().mi355x_gemv_fused(ctx.h, C.byref(d)), "logits with mirror")
+    assert ka.lib().mi355x_last_launch_mirrored(ctx.h) == 1
+    ctx.sync()
+    got, m = y.cpu().numpy(), mir.cpu().numpy().copy()
+    assert np.isfinite(got).all() and np.abs(got).max() > 0.1
+    for c in range(T):
+        assert np.array_equal(got[c].view(np.uint32), m[c].view(np.uint32)), (t, K, T, c, int((got[c] != m[c]).sum()))
+
+
 @pytest.mark.parametrize("S,H,kvs,masked", [(8, 20, (1, 17, 128, 129, 200, 255, 256, 77), True), (3, 8, (1536, 1536, 1536), False), (2, 6, (300, 5), True)])
 def test_multi_state_attention_is_bit_identical_to_one_launch_per_state(gpu, S, H, kvs, masked):
     ctx, ka, torch = gpu

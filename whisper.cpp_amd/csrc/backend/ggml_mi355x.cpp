@@ -320,7 +320,19 @@ static void mi_buffer_set_tensor(ggml_backend_buffer_t buffer, ggml_tensor * ten
 static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     io_timer tm(1);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
-    if (!is_quant_type(tensor->type) && mi_mirror_read(ctx->device, (const char *) tensor->data + offset, data, size)) return;     // logits: already in host memory
+    if (!is_quant_type(tensor->type) && mi_mirror_read(ctx->device, (const char *) tensor->data + offset, data, size)) {          // logits: already in host memory
+        static const bool check = env_flag("GGML_MI355X_MIRROR_CHECK", false);       // debugging aid: the mirror against the device copy it shadows
+        if (check) {
+            std::vector<char> devc(size);
+            (void) hipSetDevice(ctx->device);
+            (void) hipDeviceSynchronize();
+            (void) hipMemcpy(devc.data(), (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost);
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i + 4 <= size; i += 4) if (memcmp(devc.data() + i, (const char *) data + i, 4) != 0) { if (!bad) first = i / 4; bad++; }
+            if (bad) GGML_LOG_ERROR("ggml-mi355x: MIRROR_CHECK: %zu of %zu words of '%s' (offset %zu) differ between the host mirror and the device, first at %zu\n", bad, size / 4, tensor->name, offset, first);
+        }
+        return;
+    }
     (void) hipSetDevice(ctx->device);
     mi_io_drain(ctx->device);
     MI_REQUIRE_WHOLE_QUANT(tensor, "get_tensor");

@@ -116,7 +116,7 @@ extern "C" int mi355x_wake(void * stream, int nblocks) {
 void * mi355x_debug_stamps(mi355x_ctx * ctx) {
     static const bool on = getenv("GGML_MI355X_KTIME") && atoi(getenv("GGML_MI355X_KTIME"));
     if (!on) return nullptr;
-    if (!ctx->dbg_stamps && hipMalloc(&ctx->dbg_stamps, 16*8) == hipSuccess) (void) hipMemset(ctx->dbg_stamps, 0, 16*8);
+    if (!ctx->dbg_stamps && hipMalloc(&ctx->dbg_stamps, 16*8) == hipSuccess) (void) hipMemsetAsync(ctx->dbg_stamps, 0, 16*8, ctx->stream);
     return ctx->dbg_stamps;
 }
 extern "C" int mi355x_debug_read_stamps(mi355x_ctx * ctx, unsigned long long * out16) {

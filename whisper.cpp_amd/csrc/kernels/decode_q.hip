@@ -142,7 +142,9 @@ extern "C" void * mi355x_act_scratch(mi355x_ctx * ctx, int which) {
     if (!ctx->qact) {
         (void) hipSetDevice(ctx->device);
         if (hipMalloc(&ctx->qact, 2 * each) != hipSuccess) { (void) hipGetLastError(); ctx->qact = nullptr; return nullptr; }
-        (void) hipMemset(ctx->qact, 0, 2 * each);
+        // zero-fill ON THE KERNELS' STREAM: a hipMemset on the null stream is not ordered with this (non-blocking) stream and may land while
+        // the first chain already uses the planes (round 3: the first multi-token step of a process came out wrong at random)
+        (void) hipMemsetAsync(ctx->qact, 0, 2 * each, ctx->stream);
     }
     return (char *) ctx->qact + (which & 1) * each;
 }

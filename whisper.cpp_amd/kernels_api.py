@@ -102,7 +102,7 @@ def lib() -> C.CDLL:
         L.mi355x_last_error.restype = C.c_char_p
         L.mi355x_type_row_bytes.restype = C.c_size_t
         L.mi355x_type_row_bytes.argtypes = [C.c_int, C.c_int64]
-        for name in ("mi355x_ctx_destroy", "mi355x_ctx_synchronize", "mi355x_ctx_stream", "mi355x_prof_reset", "mi355x_flush", "mi355x_eager_count"):
+        for name in ("mi355x_ctx_destroy", "mi355x_ctx_synchronize", "mi355x_ctx_stream", "mi355x_prof_reset", "mi355x_flush", "mi355x_eager_count", "mi355x_last_launch_mirrored"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.mi355x_eager_count.restype = C.c_uint64
         L.mi355x_prof_enable.argtypes = [C.c_void_p, C.c_int]
