@@ -286,8 +286,9 @@ def main():
             from whisper_cpp_amd import host_api
             figs_ms = algorithmic_figures(a.arch, a.qtype)
             multi_stream = {"streams": a.multi_stream, "harness": "mi355x_host_run (C++ threads, one whisper_state each, one whisper_context, weights shared)"}
-            for label, batching, ns in (("batched", 1, a.multi_stream), ("unbatched", 0, min(a.multi_stream, 4))):
-                r = host_api.run(model, use_gpu=True, n_devices=1, streams=ns, n_decode=a.n_decode, steps=2, warmup=1, n_threads=2, batching=batching)
+            # (own chains first: the merged leg creates the plugin's lane streams, which then share hardware queues with the states' streams)
+            for label, batching, ns in (("unbatched", 0, min(a.multi_stream, 4)), ("batched", 1, a.multi_stream)):
+                r = host_api.run(model, use_gpu=True, n_devices=1, streams=ns, n_decode=a.n_decode, steps=2, warmup=1, batching=batching)
                 if r["rc"] != 0:
                     multi_stream[label] = {"streams": ns, "error": r["error"]}
                     continue

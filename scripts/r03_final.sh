@@ -9,7 +9,7 @@ STAGES=${*:-main configs trace scaling}
 stage() { echo; echo "=== $1 === $(date +%T)"; }
 for s in $STAGES; do case $s in
 main)
-    PYTEST_ARGS="--timeout 900 --timeout-method=thread" bash scripts/gpu_round.sh pytest bench prof pmc wbench > "$OUT/round_full.log" 2>&1
+    PYTEST_ARGS="--timeout 900 --timeout-method=thread" bash scripts/gpu_round.sh pytest bench prof ${MAIN_STAGES:-pmc} wbench > "$OUT/round_full.log" 2>&1
     grep -E "passed|failed|^FAILED|^ERROR" "$OUT/pytest_gpu.txt" | tail -8
     cut -c1-900 "$OUT/bench_large-v3_q5_0.json"
     grep -E "time =" "$OUT/wbench_gpu_large-v3_q5_0.log"

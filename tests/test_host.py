@@ -188,8 +188,8 @@ def test_pmc_traffic_json_applies_the_gfx950_corrections(tmp_path):
 def test_committed_pmc_traffic_covers_the_benchmarked_kernels():
     """bench.py looks the dominant kernel up in profiles/pmc_traffic.json by its demangled name without the argument list"""
     k = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["kernels"]
-    for name in ("void k_fattn_dec<1>", "void k_gemv_row<6, 1, 1, 2, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 1>", "void k_gemv8<6, 1, 8>",
-                 "void k_gemm_f16_ring<64, 4>"):
+    for name in ("void k_fattn_dec<1>", "void k_gemv_row<6, 1, 1, 2, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 4>",
+                 "void k_vocab<6, 1, 5>", "void k_gemv_q<6, 8, 1, true, 1, false, false>", "void k_gemm_f16_ring<64, 4>"):
         assert name in k and k[name]["hbm_bytes_per_launch"] > 0, name
 
 
