@@ -136,6 +136,7 @@ def main():
                          "heat-up rounds); bounded: 1 cold encode + 16 decodes through oracle/cpu_baseline.cpp, extrapolated (for very slow hosts)")
     ap.add_argument("--profile-only", action="store_true", help="print the per-kernel hipEvent profile of one chunk and exit")
     ap.add_argument("--profile-what", default="chunk", choices=["chunk", "batchd", "prompt"], help="what --profile-only measures")
+    ap.add_argument("--py-loop", action="store_true", help="issue every whisper_decode from Python (ctypes) instead of the native chunk loop")
     ap.add_argument("--no-profile", action="store_true", help="skip the hipEvent per-kernel pass (no roofline object; used under rocprofv3 --pmc)")
     a = ap.parse_args()
 
@@ -148,6 +149,24 @@ def main():
     # one hardware queue per concurrent stream (+ the upload stream): with ROCm's default of 4, two of the 4 + 1 HIP streams of
     # the multi-stream pass share a queue and serialize (measured 4.7 -> 5.8 chunks/s at 4 streams; no effect on one stream)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+    # ONE HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (ROCm 7.0, no SONAME) while the plugin links the
+    # image's /opt/rocm libamdhip64.so.7 (ROCm 7.2); loaded side by side both runtimes initialise the device and every decode step of the
+    # plugin gets slower (measured on the same box: 362 vs 348 ms/chunk; the stock whisper-bench process, which has only the system runtime,
+    # 339).  Bringing the system runtime into the global symbol scope BEFORE torch is imported makes torch's HIP calls resolve to it as well
+    # (what LD_PRELOAD does).  Single-process runs only: under torchrun the wheel's RCCL stays with the runtime it was built against.
+    # BENCH_SYSTEM_HIP=0 switches this off, =1 forces it.
+    sys_hip = os.environ.get("BENCH_SYSTEM_HIP", "1" if not under_torchrun else "0")
+    hip_runtime = "pytorch wheel's libamdhip64 next to the system one"
+    if sys_hip == "1":
+        for cand in ("/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
+            if os.path.exists(cand):
+                try:
+                    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                    hip_runtime = cand + " for the whole process"
+                except OSError:
+                    pass
+                break
 
     import numpy as np
     import torch
@@ -213,10 +232,18 @@ def main():
         return Streams(w, ctx, n, mels)
 
     multi = make_streams(a.streams) if a.streams > 1 else None
+    from whisper_cpp_amd import host_api as _host_api
+    native_chunk = _host_api.lib().mi355x_host_chunk
+    native_chunk.argtypes = [C.c_void_p, C.c_int, C.c_int]
 
     def chunk():
         if multi is not None:                 # --streams S: S states on this GPU, one host thread each, all process one chunk
             multi.chunk_all(a.n_decode)
+            return
+        if not a.py_loop:                     # the bench protocol's loop in native code (include/mi355x_host.h): no Python call per token
+            rc = native_chunk(ctx, a.n_decode, n_threads)
+            if rc != 0:
+                raise RuntimeError(f"mi355x_host_chunk failed: rc={rc}")
             return
         if w.whisper_encode(ctx, 0, n_threads) != 0:
             raise RuntimeError("whisper_encode failed")
@@ -326,7 +353,7 @@ def main():
             "encode_ms": round(encode_ms, 3), "decode_ms_per_token": round(decode_ms, 4),
             "batchd_ms_per_token": round(batchd_ms, 4), "prompt_ms_per_token": round(prompt_ms, 4),
             "weight_broadcast": bcast, "multi_stream": multi_stream,
-            "launch_mode": "plain launches on the backend's stream",
+            "launch_mode": "plain launches on the backend's stream", "hip_runtime": hip_runtime,
             "backend": {"graph_computes": int(stats[0]),
                         "host_ms_in_timed_region": {"graph_compute": round(host_ms[3], 2),
                                             "set_tensor": round(host_ms[4], 2), "get_tensor": round(host_ms[5], 2), "cpy_tensor": round(host_ms[6], 2), "synchronize": round(host_ms[7], 2),

@@ -76,6 +76,9 @@ MI355X_HOST_API void * mi355x_host_open(const char * model_path, int use_gpu, in
 
 /* rows of every stream's last logits (n_vocab floats each) after a run, for bit-identity checks between arrangements */
 MI355X_HOST_API int mi355x_host_last_logits(float * dst, int64_t cap_floats);
+/* one step of the whisper-bench protocol (examples/bench/bench.cpp:124-136) on an open whisper_context: whisper_encode + n_decode x
+ * whisper_decode(1 token, n_past = i); 0, or 1 / 2 if the encode / a decode failed.  What bench.py times (no host-language call per token). */
+MI355X_HOST_API int mi355x_host_chunk(void * whisper_ctx, int n_decode, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,17 @@ extern "C" void * mi355x_host_open(const char * model_path, int use_gpu, int gpu
     return ctx;
 }
 
+// one step of the bench protocol on an open context, in native code: 1 x whisper_encode + n_decode x whisper_decode(1 token) — the loop of
+// examples/bench/bench.cpp:124-136 without a host-language call per token
+extern "C" int mi355x_host_chunk(void * ctx_, int n_decode, int n_threads) {
+    whisper_context * ctx = (whisper_context *) ctx_;
+    if (!ctx) return -1;
+    if (whisper_encode(ctx, 0, n_threads) != 0) return 1;
+    whisper_token tok[8] = { 0 };
+    for (int i = 0; i < n_decode; i++) if (whisper_decode(ctx, tok, 1, i, n_threads) != 0) return 2;
+    return 0;
+}
+
 extern "C" int mi355x_host_last_logits(float * dst, int64_t cap) {
     std::lock_guard<std::mutex> lk(g_last_mtx);
     const int64_t n = std::min<int64_t>(cap, (int64_t) g_last_logits.size());
