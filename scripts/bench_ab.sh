@@ -17,7 +17,7 @@ d = json.loads(sys.argv[1]); k = d.get("kernel_time_ms_per_chunk") or {}
 if sys.argv[3] == "encode":
     g = sum(v for n, v in k.items() if "ring_group" in n); s = sum(v for n, v in k.items() if "k_gemm_f16_ring<" in n)
     print(f"{sys.argv[2]:48s} encode {d['encode_ms']:.3f} ms  prompt {d['prompt_ms_per_token']:.4f}  group {g:.3f} single {s:.3f} "
-          f"fattn {k.get('k_fattn_mfma(FattnArgs)', 0):.3f} norm {k.get('k_norm_v4(NormArgs)', 0):.3f} prep {k.get('k_prep_act(PrepArgs)', 0):.3f}")
+          f"fattn {sum(v for n, v in k.items() if 'k_fattn_mfma' in n):.3f} norm {k.get('k_norm_v4(NormArgs)', 0):.3f} prep {k.get('k_prep_act(PrepArgs)', 0):.3f}")
 else:
     h = d["hip_graph"]["host_ms_in_timed_region"]
     print(f"{sys.argv[2]:40s} value {d['value']:.2f} encode {d['encode_ms']:.3f} decode {d['decode_ms_per_token']:.4f} batchd {d['batchd_ms_per_token']:.4f} "

@@ -2,7 +2,8 @@
 //     dst[:, h, t] = softmax_k( scale * <f16(q[:, t, h]), k[:, k, h]> + mask[k, t] ) . v[:, k, h]
 // q F32 (rounded to f16 like the CPU's q_to_vec_dot), k/v F16, mask F16 or none, f32 accumulation throughout.
 //
-//   k_fattn_mfma : T > 8 (encoder 1500 x 1536, prompt).  128 queries x 1 head per workgroup, 4 waves x 32 queries,
+//   k_fattn_mfma : T > 8 (encoder 1500 x 1536, prompt).  128 queries x 1 head per workgroup, 4 waves x 32 queries per key group
+//                  (r03: NG key groups per workgroup, merged through LDS — see the kernel),
 //                  64-key tiles staged once per workgroup in LDS (K row-major XOR-swizzled, V transposed with a
 //                  conflict-free 136-byte row pitch).  S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x16_f16, so a
 //                  lane owns ONE query column: softmax statistics are per-lane scalars (one shuffle with lane^32),
@@ -30,15 +31,26 @@ struct FattnArgs {
 
 __device__ __forceinline__ int k_off(int row, int slot) { return row*128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-__global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
-    __shared__ __attribute__((aligned(16))) char lds[KT*128 + FA_D*VT_PITCH];
-    char * ldsK = lds; char * ldsV = lds + KT*128;
+// NG key groups of 4 waves each share the 128 queries of the workgroup: group g walks the contiguous tile range
+// [g*tpg, (g+1)*tpg) of the keys with its own LDS tile pair, and the groups' (m, l, O) records are merged through LDS at the end
+// (group 0 writes the result).  1500 queries x 20 heads are only 938 waves of 32 queries for 1024 SIMDs: with one group every
+// SIMD runs ONE wave whose LDS reads, MFMAs and softmax VALU work are strictly serial; with NG groups a SIMD holds NG waves
+// whose MFMA and VALU segments overlap.  MASK = false (the encoder) folds scale and log2(e) into one fma per score:
+// p = exp2(s*c - m*c), c = scale*log2(e), running maximum kept on the raw scores (scale > 0 is checked on the host).
+template <int NG, bool MASK>
+__global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
+    constexpr int TILE_LDS = KT*128 + FA_D*VT_PITCH;
+    constexpr int COMB_LDS = (NG - 1)*34*256*4;
+    __shared__ __attribute__((aligned(16))) char lds[NG*TILE_LDS > COMB_LDS ? NG*TILE_LDS : COMB_LDS];
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int grp = NG > 1 ? __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 8)) : 0;
+    const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
+    char * ldsK = lds + grp*TILE_LDS; char * ldsV = ldsK + KT*128;
     const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2;
     const int qi = blockIdx.x*128 + wave*32 + (lane & 31);          // this lane's query
     const int hf = lane >> 5;
     const bool q_ok = qi < a.T;
+    const float c2 = a.scale * 1.4426950408889634f;                 // MASK = false: exponent scale in the exp2 domain
 
     // Q^T fragments (B operand): lane (query, hf) holds d = 16*kk + 8*hf + e
     half8_t qf[4];
@@ -62,7 +74,7 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
 
     const char * kbase = a.k.data + (int64_t) hk*a.k.nb[2];
     const char * vbase = a.v.data + (int64_t) hv*a.v.nb[2];
-    const char * mrow  = a.has_mask && q_ok ? a.m.data + (int64_t) qi*a.m.nb[1] : nullptr;
+    const char * mrow  = MASK && a.has_mask && q_ok ? a.m.data + (int64_t) qi*a.m.nb[1] : nullptr;
 
     // staging: thread -> (key = tid>>3 [+32], chunk = tid&7): 16 bytes = 8 d-values
     const int skey = tid >> 3, sch = tid & 7;
@@ -76,22 +88,29 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
         kr0 = *(const uint4 *) (kbase + (int64_t) key0_*a.k.nb[1] + sch*16); vr0 = *(const uint4 *) (vbase + (int64_t) key0_*a.v.nb[1] + sch*16); \
         kr1 = *(const uint4 *) (kbase + (int64_t) key1_*a.k.nb[1] + sch*16); vr1 = *(const uint4 *) (vbase + (int64_t) key1_*a.v.nb[1] + sch*16); \
     } while (0)
-    FA_FETCH(0);
-    for (int k0 = 0; k0 < a.n_kv; k0 += KT) {
-        __syncthreads();                                      // previous tile fully consumed
-        #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int kl = skey + 32*i;
-            const uint4 kq = i ? kr1 : kr0, vq = i ? vr1 : vr0;
-            *(uint4 *) (ldsK + k_off(kl, sch)) = kq;
-            const uint32_t w[4] = { vq.x, vq.y, vq.z, vq.w };
+    const int nt = (a.n_kv + KT - 1) / KT, tpg = (nt + NG - 1) / NG;
+    const int t_begin = grp*tpg, t_end = min(nt, t_begin + tpg);
+    FA_FETCH(t_begin*KT);
+    for (int it = 0; it < tpg; it++) {                            // every group makes the same number of barrier visits
+        const int k0 = (t_begin + it)*KT;
+        const bool live = t_begin + it < t_end;                   // uniform per group (a whole number of waves)
+        __syncthreads();                                          // previous tile fully consumed
+        if (live) {
             #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const uint16_t hv16 = (uint16_t) ((w[e >> 1] >> (16*(e & 1))) & 0xFFFF);
-                *(uint16_t *) (ldsV + (sch*8 + e)*VT_PITCH + kl*2) = hv16;
+            for (int i = 0; i < 2; i++) {
+                const int kl = skey + 32*i;
+                const uint4 kq = i ? kr1 : kr0, vq = i ? vr1 : vr0;
+                *(uint4 *) (ldsK + k_off(kl, sch)) = kq;
+                const uint32_t w[4] = { vq.x, vq.y, vq.z, vq.w };
+                #pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint16_t hv16 = (uint16_t) ((w[e >> 1] >> (16*(e & 1))) & 0xFFFF);
+                    *(uint16_t *) (ldsV + (sch*8 + e)*VT_PITCH + kl*2) = hv16;
+                }
             }
         }
         __syncthreads();
+        if (!live) continue;
         // the next tile's loads are in flight while this one is computed (clamped past the end: harmless re-read of the last keys)
         FA_FETCH(k0 + KT);
 
@@ -107,34 +126,49 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
                 s[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[b], 0, 0, 0);
             }
         }
-        // scale, mask, running max.  register r of block b <-> key k0 + 32b + (r&3) + 8*(r>>2) + 4*hf
+        // running max.  register r of block b <-> key k0 + 32b + (r&3) + 8*(r>>2) + 4*hf
         float tmax = -INFINITY;
-        #pragma unroll
-        for (int b = 0; b < 2; b++) {
+        if (MASK) {
             #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int key = k0 + 32*b + 8*g + 4*hf;
-                float mv[4] = { 0, 0, 0, 0 };
-                if (mrow && key < a.n_kv) {
-                    if (key + 3 < a.n_kv && ((a.m.nb[1] | (uintptr_t) a.m.data) % 8 == 0)) {
-                        const uint2 mm = *(const uint2 *) (mrow + key*2);
-                        mv[0] = h2f((uint16_t) (mm.x & 0xFFFF)); mv[1] = h2f((uint16_t) (mm.x >> 16)); mv[2] = h2f((uint16_t) (mm.y & 0xFFFF)); mv[3] = h2f((uint16_t) (mm.y >> 16));
-                    } else {
-                        for (int e = 0; e < 4 && key + e < a.n_kv; e++) mv[e] = h2f(*(const uint16_t *) (mrow + (key + e)*2));
+            for (int b = 0; b < 2; b++) {
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int key = k0 + 32*b + 8*g + 4*hf;
+                    float mv[4] = { 0, 0, 0, 0 };
+                    if (mrow && key < a.n_kv) {
+                        if (key + 3 < a.n_kv && ((a.m.nb[1] | (uintptr_t) a.m.data) % 8 == 0)) {
+                            const uint2 mm = *(const uint2 *) (mrow + key*2);
+                            mv[0] = h2f((uint16_t) (mm.x & 0xFFFF)); mv[1] = h2f((uint16_t) (mm.x >> 16)); mv[2] = h2f((uint16_t) (mm.y & 0xFFFF)); mv[3] = h2f((uint16_t) (mm.y >> 16));
+                        } else {
+                            for (int e = 0; e < 4 && key + e < a.n_kv; e++) mv[e] = h2f(*(const uint16_t *) (mrow + (key + e)*2));
+                        }
+                    }
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float x = s[b][4*g + e] * a.scale + mv[e];
+                        if (key + e >= a.n_kv) x = -INFINITY;
+                        s[b][4*g + e] = x;
+                        tmax = fmaxf(tmax, x);
                     }
                 }
-                #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float x = s[b][4*g + e] * a.scale + mv[e];
-                    if (key + e >= a.n_kv) x = -INFINITY;
-                    s[b][4*g + e] = x;
-                    tmax = fmaxf(tmax, x);
-                }
             }
+        } else {
+            if (k0 + KT > a.n_kv) {                               // the last tile only: keys past the end never count
+                #pragma unroll
+                for (int b = 0; b < 2; b++)
+                    #pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (k0 + 32*b + (r & 3) + 8*(r >> 2) + 4*hf >= a.n_kv) s[b][r] = -INFINITY;
+            }
+            #pragma unroll
+            for (int b = 0; b < 2; b++)
+                #pragma unroll
+                for (int r = 0; r < 16; r++) tmax = fmaxf(tmax, s[b][r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);
+        const float mc = m_new*c2;                               // the shift every p of this tile is taken against
+        const float alpha = MASK ? __expf(m_run - m_new) : __builtin_amdgcn_exp2f(m_run*c2 - mc);
         m_run = m_new;
         float psum = 0.0f;
         half8_t pf[4];                                         // B operand of P^T: pf[2b + kk'][e] <-> register 8kk'+e of block b
@@ -142,7 +176,7 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
         for (int b = 0; b < 2; b++) {
             #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float p = __expf(s[b][r] - m_new);
+                const float p = MASK ? __expf(s[b][r] - m_new) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][r], c2, -mc));
                 psum += p;
                 pf[2*b + (r >> 3)][r & 7] = (half_t) p;
             }
@@ -165,6 +199,37 @@ __global__ void __launch_bounds__(256) k_fattn_mfma(const FattnArgs a) {
                 __builtin_memcpy(&vf, vw, 16);
                 o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], o[i], 0, 0, 0);
             }
+        }
+    }
+#undef FA_FETCH
+
+    if (NG > 1) {
+        // merge the key groups' records: comb[g-1][field][tid], field 0 = m, 1 = l, 2 + 16i + r = o[i][r] (the tile buffers are dead)
+        float * comb = (float *) lds;
+        __syncthreads();
+        if (grp > 0) {
+            float * rec = comb + (grp - 1)*34*256 + tid;
+            rec[0] = m_run; rec[256] = l_run;
+            #pragma unroll
+            for (int i = 0; i < 2; i++)
+                #pragma unroll
+                for (int r = 0; r < 16; r++) rec[(2 + 16*i + r)*256] = o[i][r];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+        #pragma unroll
+        for (int g = 1; g < NG; g++) {
+            const float * rec = comb + (g - 1)*34*256 + tid;
+            const float m_g = rec[0], l_g = rec[256];
+            const float m_new = fmaxf(m_run, m_g);
+            const float a0 = MASK ? __expf(m_run - m_new) : __builtin_amdgcn_exp2f(m_run*c2 - m_new*c2);
+            const float a1 = MASK ? __expf(m_g - m_new)   : __builtin_amdgcn_exp2f(m_g*c2 - m_new*c2);
+            m_run = m_new;
+            l_run = l_run*a0 + l_g*a1;
+            #pragma unroll
+            for (int i = 0; i < 2; i++)
+                #pragma unroll
+                for (int r = 0; r < 16; r++) o[i][r] = o[i][r]*a0 + rec[(2 + 16*i + r)*256]*a1;
         }
     }
 
@@ -255,5 +320,21 @@ static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi35
         if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
     const double bytes = kv_bytes * ((T + 127) / 128) + (double) T*H*FA_D*8;
-    return emit(ctx, "fattn_mfma", k_fattn_mfma, dim3((T + 127) / 128, H), dim3(256), 0, a, bytes, flops);
+    // key groups per workgroup (waves per SIMD): 3 from 12 key tiles on, 2 from 4 on (GGML_MI355X_FATTN_NG=1..4 forces one)
+    const int ng_env = getenv("GGML_MI355X_FATTN_NG") ? atoi(getenv("GGML_MI355X_FATTN_NG")) : 0;
+    const int ntiles = (n_kv + KT - 1) / KT;
+    const bool folded = !mask && scale > 0.0f;                  // the running maximum on raw scores needs a positive scale
+    int ng = ng_env >= 1 && ng_env <= 4 ? ng_env : (ntiles >= 4 ? 2 : 1);
+    if (ng > ntiles) ng = ntiles;
+    if (!folded && ng > 3) ng = 3;                              // the masked form needs 166 VGPRs: three waves per SIMD at most
+    const dim3 grid((T + 127) / 128, H);
+#define FA_LAUNCH(NG_) (folded ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false>, grid, dim3(256*NG_), 0, a, bytes, flops) \
+                               : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true>,  grid, dim3(256*NG_), 0, a, bytes, flops))
+    switch (ng) {
+        case 4:  return emit(ctx, "fattn_mfma", k_fattn_mfma<4, false>, grid, dim3(1024), 0, a, bytes, flops);
+        case 3:  return FA_LAUNCH(3);
+        case 2:  return FA_LAUNCH(2);
+        default: return FA_LAUNCH(1);
+    }
+#undef FA_LAUNCH
 }

@@ -448,12 +448,17 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(const GemmArgs a) {
 // -------------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int BN, int NST>
+// TM = rows of A per tile: 128 (4 waves, 2 x 2) or 256 (8 waves, 4 x 2: r03 — twice the arithmetic per byte the LDS-DMA has to
+// deliver, two waves per SIMD inside ONE workgroup; for products with enough 256-row tiles to cover the chip).  Every wave owns a
+// 64 x BN/2 piece whatever TM is, so fragments, MFMA order and epilogue are the same code: results are bit-identical across TM.
+template <int TM, int BN, int NST>
 __device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int tile, char * ring) {
+    constexpr int NW = TM / 32;                       // waves per workgroup
     constexpr int WN = BN / 2, NT = WN / 32;
-    constexpr int STAGE = (BM + BN) * 128;            // bytes per stage: A tile [128][64] f16, B tile [BN][64] f16
-    constexpr int GA = BM / 32, GB = BN / 32;         // LDS-DMA instructions per wave and stage: 8 rows each
+    constexpr int STAGE = (TM + BN) * 128;            // bytes per stage: A tile [TM][64] f16, B tile [BN][64] f16
+    constexpr int GA = TM / NW / 8, GB = BN / NW / 8; // LDS-DMA instructions per wave and stage: 8 rows each
     constexpr int G = GA + GB;
+    static_assert(GA >= 1 && GB >= 1, "every wave moves at least one 8-row group of each operand");
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -464,7 +469,7 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int til
     // whichever moves fewer bytes, chosen on the host).
     const int mi = a.m_major ? tile / a.nt : tile % a.mt;
     const int ni = a.m_major ? tile % a.nt : tile / a.mt;
-    const int m0 = mi * BM;
+    const int m0 = mi * TM;
     const int64_t n0 = (int64_t) ni * BN;
     const int nk = a.K / BK;
 
@@ -474,13 +479,13 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int til
     const char * ga[GA]; const char * gb[GB];
     #pragma unroll
     for (int i = 0; i < GA; i++) {
-        const int r = wave * (BM / 4) + i * 8 + (lane >> 3);
+        const int r = wave * (TM / NW) + i * 8 + (lane >> 3);
         const int mr = m0 + r < a.M ? m0 + r : a.M - 1;
         ga[i] = a.A + (int64_t) mr * a.a_nb1 + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
     }
     #pragma unroll
     for (int i = 0; i < GB; i++) {
-        const int r = wave * (BN / 4) + i * 8 + (lane >> 3);
+        const int r = wave * (BN / NW) + i * 8 + (lane >> 3);
         const int64_t tr = n0 + r < a.T ? n0 + r : a.T - 1;
         gb[i] = (const char *) (a.B + tr * a.ldb) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
     }
@@ -490,11 +495,11 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int til
         #pragma unroll
         for (int i = 0; i < GA; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (ga[i] + koff),
-                                             (__attribute__((address_space(3))) void *) (st + (wave * (BM / 4) + i * 8) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *) (st + (wave * (TM / NW) + i * 8) * 128), 16, 0, 0);
         #pragma unroll
         for (int i = 0; i < GB; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (gb[i] + koff),
-                                             (__attribute__((address_space(3))) void *) (st + BM*128 + (wave * (BN / 4) + i * 8) * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *) (st + TM*128 + (wave * (BN / NW) + i * 8) * 128), 16, 0, 0);
     };
 
     floatx16 acc[2][NT];
@@ -518,7 +523,7 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int til
         if (kt + NST - 1 < nk) issue(kt + NST - 1);    // refill the slot of stage kt-1
 
         const char * ldsA = ring + (kt % NST) * STAGE;
-        const char * ldsB = ldsA + BM*128;
+        const char * ldsB = ldsA + TM*128;
         #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             half8_t af[2], bf[NT];
@@ -537,13 +542,13 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int til
     gemm_epilogue<NT>(a, acc, m0, n0, wm, wn, WN, lane);
 }
 
-template <int BN, int NST>
-__global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
+template <int BN, int NST, int TM>
+__global__ void __launch_bounds__(TM * 2) k_gemm_f16_ring(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int tile = xcd * a.per + idx;
     if (tile >= a.mt * a.nt) return;                  // padding blocks of the last XCD range (uniform exit, before any barrier)
-    gemm_ring_tile<BN, NST>(a, tile, ring);
+    gemm_ring_tile<TM, BN, NST>(a, tile, ring);
 }
 
 // Grouped form: up to GEMM_GROUP_MAX independent products with the SAME activation matrix B and the same shape (the Q / K / V
@@ -555,24 +560,24 @@ __global__ void __launch_bounds__(256) k_gemm_f16_ring(const GemmArgs a) {
 #define GEMM_GROUP_MAX 8
 struct GemmGroupArgs { GemmArgs g[GEMM_GROUP_MAX]; int n, tiles_per_member, per; };
 
-template <int BN, int NST>
-__global__ void __launch_bounds__(256) k_gemm_f16_ring_group(const GemmGroupArgs ga) {
+template <int BN, int NST, int TM>
+__global__ void __launch_bounds__(TM * 2) k_gemm_f16_ring_group(const GemmGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char ring[];
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int t = xcd * ga.per + idx;
     if (t >= ga.n * ga.tiles_per_member) return;
     const int gi = t / ga.tiles_per_member;
-    gemm_ring_tile<BN, NST>(ga.g[gi], t - gi * ga.tiles_per_member, ring);
+    gemm_ring_tile<TM, BN, NST>(ga.g[gi], t - gi * ga.tiles_per_member, ring);
 }
 
 // tile counts of one member + the XCD-aware tile order for ranges of `per` consecutive tiles
-template <int BN>
+template <int TM, int BN>
 static void ring_tiling(GemmArgs & k, int64_t per) {
-    k.mt = (int) ((k.M + BM - 1) / BM); k.nt = (int) ((k.T + BN - 1) / BN);
+    k.mt = (int) ((k.M + TM - 1) / TM); k.nt = (int) ((k.T + BN - 1) / BN);
     const int64_t ntiles = (int64_t) k.mt * k.nt;
     k.per = (int) (per < ntiles ? per : ntiles);
     // bytes each XCD pulls through its L2 for its `per` consecutive tiles, column-major vs row-major tile order
-    const double a_tile = (double) BM * k.K * 2, b_tile = (double) BN * k.K * 2;
+    const double a_tile = (double) TM * k.K * 2, b_tile = (double) BN * k.K * 2;
     const double col_major = a_tile * (k.per < k.mt ? k.per : k.mt) + b_tile * ((k.per + k.mt - 1) / k.mt + (k.per % k.mt ? 1 : 0));
     const double row_major = b_tile * (k.per < k.nt ? k.per : k.nt) + a_tile * ((k.per + k.nt - 1) / k.nt + (k.per % k.nt ? 1 : 0));
     static const int force = getenv("GGML_MI355X_GEMM_XCD_ORDER") ? atoi(getenv("GGML_MI355X_GEMM_XCD_ORDER")) : -1;
@@ -592,29 +597,29 @@ static int ring_lds_attr(mi355x_ctx * ctx, F func, uint32_t lds, std::atomic<boo
     return 0;
 }
 
-template <int BN, int NST>
+template <int BN, int NST, int TM = BM>
 static int launch_ring(mi355x_ctx * ctx, const GemmArgs & k0, double bytes, double flops) {
-    constexpr uint32_t lds = (uint32_t) NST * (BM + BN) * 128;
+    constexpr uint32_t lds = (uint32_t) NST * (TM + BN) * 128;
     GemmArgs k = k0;
-    const int64_t ntiles = ((k.M + BM - 1) / BM) * ((k.T + BN - 1) / BN);
-    ring_tiling<BN>(k, (ntiles + 7) / 8);
+    const int64_t ntiles = ((k.M + TM - 1) / TM) * ((k.T + BN - 1) / BN);
+    ring_tiling<TM, BN>(k, (ntiles + 7) / 8);
     k.per = (int) ((ntiles + 7) / 8);
     static std::atomic<bool> attr_set[64];
-    if (ring_lds_attr(ctx, k_gemm_f16_ring<BN, NST>, lds, attr_set) != 0) return MI355X_E_UNSUPPORTED;
-    return emit(ctx, "gemm_f16_ring", k_gemm_f16_ring<BN, NST>, dim3((uint32_t) (8 * k.per)), dim3(256), lds, k, bytes, flops);
+    if (ring_lds_attr(ctx, k_gemm_f16_ring<BN, NST, TM>, lds, attr_set) != 0) return MI355X_E_UNSUPPORTED;
+    return emit(ctx, "gemm_f16_ring", k_gemm_f16_ring<BN, NST, TM>, dim3((uint32_t) (8 * k.per)), dim3(TM * 2), lds, k, bytes, flops);
 }
 
-template <int BN, int NST>
+template <int BN, int NST, int TM = BM>
 static int launch_ring_group(mi355x_ctx * ctx, const GemmArgs * members, int n, double bytes, double flops) {
-    constexpr uint32_t lds = (uint32_t) NST * (BM + BN) * 128;
+    constexpr uint32_t lds = (uint32_t) NST * (TM + BN) * 128;
     GemmGroupArgs ga; memset(&ga, 0, sizeof(ga));
-    const int64_t tiles = ((members[0].M + BM - 1) / BM) * ((members[0].T + BN - 1) / BN);
+    const int64_t tiles = ((members[0].M + TM - 1) / TM) * ((members[0].T + BN - 1) / BN);
     const int64_t per = (n * tiles + 7) / 8;
-    for (int i = 0; i < n; i++) { ga.g[i] = members[i]; ring_tiling<BN>(ga.g[i], per); }
+    for (int i = 0; i < n; i++) { ga.g[i] = members[i]; ring_tiling<TM, BN>(ga.g[i], per); }
     ga.n = n; ga.tiles_per_member = (int) tiles; ga.per = (int) per;
     static std::atomic<bool> attr_set[64];
-    if (ring_lds_attr(ctx, k_gemm_f16_ring_group<BN, NST>, lds, attr_set) != 0) return MI355X_E_UNSUPPORTED;
-    return emit(ctx, "gemm_f16_ring_group", k_gemm_f16_ring_group<BN, NST>, dim3((uint32_t) (8 * per)), dim3(256), lds, ga, bytes, flops);
+    if (ring_lds_attr(ctx, k_gemm_f16_ring_group<BN, NST, TM>, lds, attr_set) != 0) return MI355X_E_UNSUPPORTED;
+    return emit(ctx, "gemm_f16_ring_group", k_gemm_f16_ring_group<BN, NST, TM>, dim3((uint32_t) (8 * per)), dim3(TM * 2), lds, ga, bytes, flops);
 }
 
 // ---- held-back ring GEMMs (mi355x_ctx::pending_*) ---------------------------------------------------------------------------
@@ -670,6 +675,17 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
         static const int nst64  = getenv("GGML_MI355X_GEMM_RING_NST64")  ? atoi(getenv("GGML_MI355X_GEMM_RING_NST64"))  : 4;
         // GGML_MI355X_GEMM_RING_BIG=<BN><stages> (e.g. 642): A-B override of the tile width / depth for products that cover the chip
         static const int big = getenv("GGML_MI355X_GEMM_RING_BIG") ? atoi(getenv("GGML_MI355X_GEMM_RING_BIG")) : 0;
+        // GGML_MI355X_GEMM_RING_TM256=<BN><stages> (1282, 1283, 642, 643): 256-row tiles (8 waves) for products with at least
+        // GGML_MI355X_GEMM_RING_TM256_MIN (default 200) such tiles
+        // (read at every flush — a few hundred per encode — so that a test can switch them inside one process)
+        const int tm256 = getenv("GGML_MI355X_GEMM_RING_TM256") ? atoi(getenv("GGML_MI355X_GEMM_RING_TM256")) : 0;
+        const int tm256_min = getenv("GGML_MI355X_GEMM_RING_TM256_MIN") ? atoi(getenv("GGML_MI355X_GEMM_RING_TM256_MIN")) : 200;
+        const int64_t mt256 = (k.M + 255) / 256, nt64 = (k.T + 63) / 64;
+        if (tm256 / 10 == 128 && mt256 * nt128 >= tm256_min)
+            rc = tm256 == 1283 ? launch_ring<128, 3, 256>(ctx, k, P.bytes, P.flops) : launch_ring<128, 2, 256>(ctx, k, P.bytes, P.flops);
+        else if (tm256 / 10 == 64 && mt256 * nt64 >= tm256_min)
+            rc = tm256 == 643 ? launch_ring<64, 3, 256>(ctx, k, P.bytes, P.flops) : launch_ring<64, 2, 256>(ctx, k, P.bytes, P.flops);
+        else
         if (mt * nt128 >= ctx->n_cu && big == 642)      rc = launch_ring<64, 2>(ctx, k, P.bytes, P.flops);
         else if (mt * nt128 >= ctx->n_cu && big == 643) rc = launch_ring<64, 3>(ctx, k, P.bytes, P.flops);
         else if (mt * nt128 >= ctx->n_cu && big == 644) rc = launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
@@ -684,13 +700,17 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
                                                      : launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
     } else {
         // (GGML_MI355X_GEMM_GROUP_CFG=<BN><stages>, e.g. 643: A-B measurements of the tile width / ring depth of the grouped form)
-        static const int cfg = getenv("GGML_MI355X_GEMM_GROUP_CFG") ? atoi(getenv("GGML_MI355X_GEMM_GROUP_CFG")) : 0;
+        const int cfg = getenv("GGML_MI355X_GEMM_GROUP_CFG") ? atoi(getenv("GGML_MI355X_GEMM_GROUP_CFG")) : 0;
         switch (cfg) {
             case 642:  rc = launch_ring_group<64, 2>(ctx, P.k, n, P.bytes, P.flops); break;
             case 643:  rc = launch_ring_group<64, 3>(ctx, P.k, n, P.bytes, P.flops); break;
             case 644:  rc = launch_ring_group<64, 4>(ctx, P.k, n, P.bytes, P.flops); break;
             case 1282: rc = launch_ring_group<128, 2>(ctx, P.k, n, P.bytes, P.flops); break;
             case 1283: rc = launch_ring_group<128, 3>(ctx, P.k, n, P.bytes, P.flops); break;
+            case 2561282: rc = launch_ring_group<128, 2, 256>(ctx, P.k, n, P.bytes, P.flops); break;   // 256-row tiles, 8 waves
+            case 2561283: rc = launch_ring_group<128, 3, 256>(ctx, P.k, n, P.bytes, P.flops); break;
+            case 256642:  rc = launch_ring_group<64, 2, 256>(ctx, P.k, n, P.bytes, P.flops); break;
+            case 256643:  rc = launch_ring_group<64, 3, 256>(ctx, P.k, n, P.bytes, P.flops); break;
             default:
                 // measured on large-v3 encode (32 Q/K/V groups + 8 cross-K/V groups of 8, profiles/r02_encoder_ab.txt): 64-wide tiles
                 // with a 2-stage ring (48 KB: three workgroups co-resident per CU, each other's DMA waits hidden) 2.13 ms;
