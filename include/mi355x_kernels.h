@@ -110,6 +110,9 @@ typedef struct mi355x_epilogue {
     float         scale;           /* used when has_scale */
     int32_t       has_scale;
     int32_t       gelu;            /* 1: ggml_gelu (f16-table GELU, ggml-cpu/vec.h:987-1000) */
+    int32_t       bias_per_col;    /* 1: bias is [T], one value per COLUMN of dst (ggml_add with a [1,T] src1: the conv bias of
+                                    * src/whisper.cpp:2013-2020, whose mul_mat has the im2col rows as src0).  MFMA path (T > 8) only;
+                                    * every other kernel answers MI355X_E_UNSUPPORTED.  (fills the struct's former padding) */
     const float * residual;        /* [N,T] f32, same strides as dst; NULL = none */
     int64_t       residual_nb1;    /* byte stride between columns of residual */
 } mi355x_epilogue;

@@ -115,6 +115,27 @@ def main():
             timed("fc1", name, e, fc1, 2.0 * T * n * 4 * n, a.iters)
         del ws
 
+    # ---- fc1 again, by epilogue: what the f16-table GELU and the Q8_0 rounding for fc2 cost on top of the product
+    if "fc1ep" in what:
+        ws = pool(4 * n, n, 24)
+        for name, gelu, mode in (("no epilogue, F32 store", 0, "plain0"), ("bias, F32 store", 0, "plain"), ("bias + GELU, F32 store", 1, "plain"),
+                                 ("bias + GELU, F32 + prepared", 1, "both"), ("bias + GELU, prepared only", 1, "only"), ("bias, prepared only", 0, "only")):
+            epx = ka.Epilogue()
+            epx.bias, epx.gelu = bias.data_ptr(), gelu
+
+            def fc1x(i, epx=epx, mode=mode):
+                tw = ka.tensor(ws[i % len(ws)].data_ptr(), ka.F16, [n, 4 * n])
+                if mode == "plain0":
+                    rc = L.mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), n, T, y.data_ptr(), 4 * n * 4, ka.F32, None)
+                elif mode == "plain":
+                    rc = L.mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), n, T, y.data_ptr(), 4 * n * 4, ka.F32, C.byref(epx))
+                else:
+                    rc = L.mi355x_gemm_f16act_prep(ctx.h, C.byref(tw), act.data_ptr(), n, T, y.data_ptr() if mode == "both" else None, 4 * n * 4 if mode == "both" else 0,
+                                                   C.byref(epx), prep.data_ptr())
+                return rc or L.mi355x_flush(ctx.h)
+            timed("fc1", name, {}, fc1x, 2.0 * T * n * 4 * n, a.iters)
+        del ws
+
     # ---- fc2: 5120 -> 1280, bias + residual
     if "fc2" in what:
         ws = pool(n, 4 * n, 24)

@@ -179,3 +179,59 @@ def test_grouped_ring_gemm_with_256_row_tiles_is_bit_identical(gpu, cfg):
     b = run(GGML_MI355X_GEMM_GROUP_CFG=cfg)
     for x, y in zip(a, b):
         assert np.abs(x).max() > 0.1 and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+@pytest.mark.parametrize("n0,n1,ld", [(1280, 1500, 1500), (384, 1500, 1500), (100, 77, 80), (64, 64, 64), (1280, 1500, 1504)])
+def test_transposing_copy_is_exact(gpu, n0, n1, ld):
+    """ggml_cont(ggml_transpose(x)) (src/whisper.cpp:2069): dst[i1][i0] = src[i0][i1], through the LDS-tile kernel"""
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(n0 + n1)
+    a = rng.standard_normal((n0, ld)).astype(np.float32)
+    a_d = dev(torch, a)
+    d = torch.zeros((n1, n0), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    ts = ka.tensor(a_d.data_ptr(), ka.F32, [n0, n1], [ld * 4, 4, n0 * ld * 4, n0 * ld * 4])       # the transposed view
+    td = ka.tensor(d.data_ptr(), ka.F32, [n0, n1])
+    n_before = ka.lib().mi355x_eager_count(ctx.h)
+    ctx.check(ka.lib().mi355x_cpy(ctx.h, C.byref(ts), C.byref(td)), "cpy")
+    ctx.sync()
+    assert ka.lib().mi355x_eager_count(ctx.h) - n_before == 1
+    assert np.array_equal(d.cpu().numpy(), a[:, :n1].T)
+
+
+@pytest.mark.parametrize("M,K,T", [(3000, 384, 1280), (1500, 3840, 1280), (300, 192, 40)])
+def test_gemm_epilogue_with_a_bias_per_column_and_gelu_equals_the_separate_ops(gpu, M, K, T):
+    """the conv front end (src/whisper.cpp:2013-2020): mul_mat(im2col rows, kernel) + [1, OC] bias + GELU in the product's epilogue —
+    word for word the f16-table GELU of (product + bias[column]) computed from the plain product"""
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(M + T)
+    w = dev(torch, (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float16))
+    act = dev(torch, rng.standard_normal((T, K)).astype(np.float16))
+    bias = rng.standard_normal(T).astype(np.float32)
+    bias_d = dev(torch, bias)
+    tw = ka.tensor(w.data_ptr(), ka.F16, [K, M])
+    y0 = torch.zeros((T, M), dtype=torch.float32, device="cuda:0")
+    y1 = torch.zeros((T, M), dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), K, T, y0.data_ptr(), M * 4, ka.F32, None), "gemm")
+    ep = ka.Epilogue()
+    ep.bias, ep.bias_per_col, ep.gelu = bias_d.data_ptr(), 1, 1
+    ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), K, T, y1.data_ptr(), M * 4, ka.F32, C.byref(ep)), "gemm+ep")
+    ctx.sync()
+    tab = np.empty(65536, dtype=np.uint16)
+    ka.lib().mi355x_gelu_table_host(tab.ctypes.data_as(C.c_void_p))
+    x = y0.cpu().numpy() + bias[:, None]
+    want = tab[x.astype(np.float16).view(np.uint16)].view(np.float16).astype(np.float32)
+    want = np.where(x <= -10.0, 0.0, np.where(x >= 10.0, x, want)).astype(np.float32)
+    got = y1.cpu().numpy()
+    assert np.abs(got).max() > 0.1 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # a per-column bias on the mat-vec paths is refused, not mis-applied
+    x8 = dev(torch, rng.standard_normal((4, K)).astype(np.float32))
+    y8 = torch.zeros((4, M), dtype=torch.float32, device="cuda:0")
+    rc = ka.lib().mi355x_mul_mat(ctx.h, C.byref(tw), C.byref(ka.tensor(x8.data_ptr(), ka.F32, [K, 4])), C.byref(ka.tensor(y8.data_ptr(), ka.F32, [M, 4])), C.byref(ep))
+    assert rc in (-1, 0)
+    if rc == 0:                     # served by the MFMA path (the mat-vec kernels refuse the flag): right values
+        ctx.sync()
+        acc = x8.cpu().numpy().astype(np.float16).astype(np.float64) @ w.cpu().numpy().astype(np.float64).T + bias[:4, None]
+        ref = 0.5 * acc * (1.0 + np.tanh(0.7978845608028654 * acc * (1.0 + 0.044715 * acc * acc)))
+        assert np.abs(y8.cpu().numpy() - ref).max() < 5e-3

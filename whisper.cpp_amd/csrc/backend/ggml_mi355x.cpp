@@ -627,6 +627,22 @@ static bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c
     const ggml_tensor * cur = mm;
     int stage = 0;   // 0: bias allowed, 1: scale, 2: gelu, 3: residual, 4: cpy
     int j = next_real(g, i);
+    // ggml_conv_1d (ggml.c:4537-4554) puts a RESHAPE between its mul_mat and the bias add (src/whisper.cpp:2013-2020): the add reads the
+    // product through a same-shape contiguous view, and its bias has one value per COLUMN of the product ([1, OC] against [OL, OC])
+    if (j < g->n_nodes && g->nodes[j]->op == GGML_OP_ADD && can_elide(g, mm, 1) && mm->ne[2] == 1 && mm->ne[3] == 1) {
+        const ggml_tensor * n = g->nodes[j];
+        for (int sl = 0; sl < 2; sl++) {
+            const ggml_tensor * v = n->src[sl], * o = n->src[1 - sl];
+            if (v->op == GGML_OP_RESHAPE && v->src[0] == mm && v->data == mm->data && ggml_are_same_shape(v, mm) && ggml_is_contiguous(v) &&
+                use_count(g, v) == 1 && !(v->flags & GGML_TENSOR_FLAG_OUTPUT) && ggml_are_same_shape(n, mm) && n->type == GGML_TYPE_F32 &&
+                o->type == GGML_TYPE_F32 && o->ne[0] == 1 && o->ne[1] == mm->ne[1] && ggml_nelements(o) == mm->ne[1] && o->nb[1] == 4 && mm->ne[1] > 8) {
+                c.ep.bias = (const float *) o->data; c.ep.bias_per_col = 1;
+                stage = 1; cur = n; c.last = n; c.end = j;
+                j = next_real(g, j);
+                break;
+            }
+        }
+    }
     while (j < g->n_nodes && stage < 5) {
         const ggml_tensor * n = g->nodes[j];
         if (!can_elide(g, cur, 1)) break;
@@ -660,7 +676,7 @@ static bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c
             const size_t rn = (size_t) c.ep.residual_nb1 * (size_t) mm->ne[1];
             if (overlap(c.last->data, ggml_nbytes(c.last), r, rn) && !(r == (const char *) c.last->data && c.ep.residual_nb1 == (int64_t) c.last->nb[1])) bad = true;
         }
-        if (c.ep.bias && overlap(c.last->data, ggml_nbytes(c.last), c.ep.bias, N*4)) bad = true;
+        if (c.ep.bias && overlap(c.last->data, ggml_nbytes(c.last), c.ep.bias, (c.ep.bias_per_col ? mm->ne[1] : N)*4)) bad = true;
         (void) res_t;
         if (bad) { c = mm_chain(); c.mm = mm; c.last = mm; c.end = i; }
     }
@@ -745,6 +761,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             sd.data = (char *) md.data + t0 * md.nb[1]; sd.ne[1] = nt;
             mi355x_epilogue ep = c.ep;
             if (ep.residual) ep.residual = (const float *) ((const char *) ep.residual + t0 * ep.residual_nb1);
+            if (ep.bias && ep.bias_per_col) ep.bias += t0;
             const int rc = mi355x_mul_mat(b->k, &mw, &sx, &sd, has_ep ? &ep : nullptr);
             if (rc) return rc;
         }

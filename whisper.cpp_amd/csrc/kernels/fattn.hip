@@ -320,11 +320,13 @@ static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi35
         if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
     const double bytes = kv_bytes * ((T + 127) / 128) + (double) T*H*FA_D*8;
-    // key groups per workgroup (waves per SIMD): 3 from 12 key tiles on, 2 from 4 on (GGML_MI355X_FATTN_NG=1..4 forces one)
+    // key groups per workgroup (waves per SIMD): 3 from 12 key tiles on, 2 from 4 on (GGML_MI355X_FATTN_NG=1..4 forces one).
+    // Encoder size, 1500 x 1500 x 20 heads, hipEvent means (profiles/r03b_encoder_kernel_variants.txt): 1 group 40.2 us (r02's kernel: 49),
+    // 2 groups 33.6, 3 groups 32.4, 4 groups 33.3
     const int ng_env = getenv("GGML_MI355X_FATTN_NG") ? atoi(getenv("GGML_MI355X_FATTN_NG")) : 0;
     const int ntiles = (n_kv + KT - 1) / KT;
     const bool folded = !mask && scale > 0.0f;                  // the running maximum on raw scores needs a positive scale
-    int ng = ng_env >= 1 && ng_env <= 4 ? ng_env : (ntiles >= 4 ? 2 : 1);
+    int ng = ng_env >= 1 && ng_env <= 4 ? ng_env : (ntiles >= 12 ? 3 : ntiles >= 4 ? 2 : 1);
     if (ng > ntiles) ng = ntiles;
     if (!folded && ng > 3) ng = 3;                              // the masked form needs 166 VGPRs: three waves per SIMD at most
     const dim3 grid((T + 127) / 128, H);

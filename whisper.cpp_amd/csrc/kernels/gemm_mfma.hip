@@ -96,7 +96,7 @@ struct GemmArgs {
     const uint16_t * B; int64_t ldb;                    // f16 [T][ldb]
     int M, K; int64_t T;
     char * dst; int64_t dst_nb1; int dst_f16;
-    const float * bias; float scale; int has_scale; int gelu;
+    const float * bias; float scale; int has_scale; int gelu; int bias_t;   // bias_t: bias is per column t (mi355x_epilogue::bias_per_col)
     const char * residual; int64_t res_nb1;
     const uint16_t * gelu_tab;
     int mt, nt, per, m_major;                           // k_gemm_f16_ring: tile counts and the XCD-aware tile order (launch_ring)
@@ -284,7 +284,7 @@ template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc)[2][NT], int m0, int64_t n0, int wm, int wn, int WN, int lane) {
     // epilogue: C[i = A row][j = B row]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) && !a.dst_f16 &&
-                        (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || ((uintptr_t) a.bias % 16 == 0));
+                        (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || a.bias_t || ((uintptr_t) a.bias % 16 == 0));
     if (a.prep) {
         // The result is the activation matrix of the NEXT GEMM (fc1 + GELU -> fc2, src/whisper.cpp:2224-2238): write what k_prep_act
         // (mode 1) would make of it — the reference's Q8_0 rounding of every 32 consecutive features of a token, stored as f16(d*q) —
@@ -303,7 +303,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc
                 for (int g = 0; g < 4; g++) {
                     const int m = mb + 8*g + 4*(lane >> 5);
                     float x[4] = { acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3] };
-                    if (a.bias) { const float4 b = *(const float4 *) (a.bias + m); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+                    if (a.bias) {
+                        if (a.bias_t) { const float b = a.bias[t]; x[0] += b; x[1] += b; x[2] += b; x[3] += b; }
+                        else { const float4 b = *(const float4 *) (a.bias + m); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+                    }
                     if (a.has_scale) { x[0] *= a.scale; x[1] *= a.scale; x[2] *= a.scale; x[3] *= a.scale; }
                     if (a.gelu) { x[0] = gelu_lut(x[0], a.gelu_tab); x[1] = gelu_lut(x[1], a.gelu_tab); x[2] = gelu_lut(x[2], a.gelu_tab); x[3] = gelu_lut(x[3], a.gelu_tab); }
                     if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w; }
@@ -338,7 +341,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc
                 if (m >= a.M) continue;
                 float v[4] = { acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3] };
                 if (vec_ok) {                                   // m % 4 == 0 and M % 4 == 0  =>  m+3 < M
-                    if (a.bias) { const float4 b = *(const float4 *) (a.bias + m); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (a.bias) {
+                        if (a.bias_t) { const float b = a.bias[t]; v[0] += b; v[1] += b; v[2] += b; v[3] += b; }
+                        else { const float4 b = *(const float4 *) (a.bias + m); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    }
                     if (a.has_scale) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
                     if (a.gelu) { v[0] = gelu_lut(v[0], a.gelu_tab); v[1] = gelu_lut(v[1], a.gelu_tab); v[2] = gelu_lut(v[2], a.gelu_tab); v[3] = gelu_lut(v[3], a.gelu_tab); }
                     if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
@@ -348,7 +354,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc
                     for (int e = 0; e < 4; e++) {
                         if (m + e >= a.M) break;
                         float x = v[e];
-                        if (a.bias) x += a.bias[m + e];
+                        if (a.bias) x += a.bias[a.bias_t ? t : (int64_t) (m + e)];
                         if (a.has_scale) x *= a.scale;
                         if (a.gelu) x = gelu_lut(x, a.gelu_tab);
                         if (a.residual) x += *(const float *) (a.residual + t*a.res_nb1 + (int64_t) (m + e)*4);
@@ -524,6 +530,9 @@ __device__ __forceinline__ void gemm_ring_tile(const GemmArgs & a, const int til
 
         const char * ldsA = ring + (kt % NST) * STAGE;
         const char * ldsB = ldsA + TM*128;
+        // (r03: requesting the fragment reads two slices ahead of their MFMAs, in registers of their own and with the order pinned by
+        // sched_barrier, moved nothing — 32.3 vs 31.4 us for the fc1 product, profiles/r03b_gemm_pipelined_v1.txt: a K-step is bound by
+        // what the LDS-DMA delivers, see DESIGN.md §5 — so the slice loop is left to the compiler)
         #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
             half8_t af[2], bf[NT];
@@ -645,7 +654,7 @@ static bool gemm_mergeable(const PendingGemms & P, int n, const GemmArgs & k) {
         if (mem_overlap(k.dst, kd, e.dst, ed)) return false;
         if (mem_overlap(k.residual, gemm_res_bytes(k), e.dst, ed) || mem_overlap(e.residual, gemm_res_bytes(e), k.dst, kd)) return false;
         if (mem_overlap(k.A, (int64_t) k.M * k.a_nb1, e.dst, ed) || mem_overlap(e.A, (int64_t) e.M * e.a_nb1, k.dst, kd)) return false;
-        if (mem_overlap(k.bias, (int64_t) k.M * 4, e.dst, ed) || mem_overlap(e.bias, (int64_t) e.M * 4, k.dst, kd)) return false;
+        if (mem_overlap(k.bias, (k.bias_t ? k.T : (int64_t) k.M) * 4, e.dst, ed) || mem_overlap(e.bias, (e.bias_t ? e.T : (int64_t) e.M) * 4, k.dst, kd)) return false;
     }
     return true;
 }
@@ -779,7 +788,7 @@ extern "C" int mi355x_gemm_f16act_prep(mi355x_ctx * ctx, const mi355x_tensor * A
     const int64_t M = A->ne[1];
     if (!prep_out || ((uintptr_t) prep_out % 16) || M % 32) return MI355X_E_UNSUPPORTED;
     if (dst && (((uintptr_t) dst % 16) || (dst_nb1 % 16))) return MI355X_E_UNSUPPORTED;
-    if (ep && ((ep->bias && ((uintptr_t) ep->bias % 16)) || (ep->residual && (((uintptr_t) ep->residual % 16) || (ep->residual_nb1 % 16))))) return MI355X_E_UNSUPPORTED;
+    if (ep && ((ep->bias && !ep->bias_per_col && ((uintptr_t) ep->bias % 16)) || (ep->residual && (((uintptr_t) ep->residual % 16) || (ep->residual_nb1 % 16))))) return MI355X_E_UNSUPPORTED;
     return gemm_f16act_impl(ctx, A, act, ldb, T, dst ? dst : prep_out, dst ? dst_nb1 : M*4, MI355X_TYPE_F32, ep, prep_out, dst ? 0 : 1);
 }
 
@@ -792,7 +801,7 @@ static int gemm_f16act_impl(mi355x_ctx * ctx, const mi355x_tensor * A, const voi
     const int K = (int) A->ne[0], M = (int) A->ne[1];
     k.A = (const char *) A->data; k.a_nb1 = A->nb[1]; k.B = Bf16; k.ldb = ldb; k.M = M; k.K = K; k.T = T;
     k.dst = (char *) dst; k.dst_nb1 = dst_nb1; k.dst_f16 = dst_f16; k.gelu_tab = ctx->gelu_tab;
-    if (ep) { k.bias = ep->bias; k.scale = ep->scale; k.has_scale = ep->has_scale; k.gelu = ep->gelu; k.residual = (const char *) ep->residual; k.res_nb1 = ep->residual_nb1; }
+    if (ep) { k.bias_t = ep->bias && ep->bias_per_col; k.bias = ep->bias; k.scale = ep->scale; k.has_scale = ep->has_scale; k.gelu = ep->gelu; k.residual = (const char *) ep->residual; k.res_nb1 = ep->residual_nb1; }
     if (M <= 0 || T <= 0 || K <= 0 || K % 8 || ldb % 8 || ((uintptr_t) Bf16 % 16)) return MI355X_E_UNSUPPORTED;
     const double flops = 2.0 * M * (double) K * (double) T;
     double abytes;

@@ -358,6 +358,7 @@ static int launch_gemv_T(mi355x_ctx * ctx, const GemvArgs & k, int T, dim3 grid,
 extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     ctx->last_mirrored = 0;
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
+    for (int s = 0; s < d->nseg; s++) if (d->seg[s].ep.bias_per_col) return MI355X_E_UNSUPPORTED;      // (MFMA path only)
     {   // the vocabulary projection has its own kernel (LayerNorm form or prepared planes)
         const int rc = mi355x_vocab(ctx, d);
         if (rc != MI355X_E_UNSUPPORTED) return rc;

@@ -33,7 +33,7 @@ class Tensor(C.Structure):
 
 
 class Epilogue(C.Structure):
-    _fields_ = [("bias", C.c_void_p), ("scale", C.c_float), ("has_scale", C.c_int32), ("gelu", C.c_int32),
+    _fields_ = [("bias", C.c_void_p), ("scale", C.c_float), ("has_scale", C.c_int32), ("gelu", C.c_int32), ("bias_per_col", C.c_int32),
                 ("residual", C.c_void_p), ("residual_nb1", C.c_int64)]
 
 
