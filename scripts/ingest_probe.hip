@@ -1,0 +1,58 @@
+// Probe: how long does it take G workgroups to pull a fixed 3.4 MB (one decoder layer's Q / K / V weights, Q5_0) out of HBM when every load
+// is in flight at once?  The fused "LN + Q/K/V + self-attention, one workgroup per head" kernel would use 20 workgroups of 16 waves
+// (170 KB each) where the mat-vec today uses 240 workgroups of 5 waves (14 KB each).  Buffers rotate through 64 copies (HBM-cold).
+//   hipcc --offload-arch=gfx950 -O3 scripts/ingest_probe.hip -o /tmp/ingest_probe && /tmp/ingest_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NL>          // 16-byte loads per lane
+__global__ void __launch_bounds__(1024) k_pull(const u32x4 * __restrict__ src, unsigned * out, int nthreads_total) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 v[NL];
+    #pragma unroll
+    for (int i = 0; i < NL; i++) v[i] = __builtin_nontemporal_load(src + (size_t) i * nthreads_total + gid);
+    unsigned s = 0;
+    #pragma unroll
+    for (int i = 0; i < NL; i++) s += v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    if (s == 0x12345678u) out[gid] = s;      // never true on the fill pattern: keeps the loads alive without a store stream
+}
+
+template <int NL>
+static void run(const char * label, int grid, int block, const u32x4 * pool, size_t copy_elems, unsigned * out, hipStream_t st) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int n = grid * block, iters = 64;
+    for (int i = 0; i < 4; i++) hipLaunchKernelGGL((k_pull<NL>), dim3(grid), dim3(block), 0, st, pool + (size_t) (i % 64) * copy_elems, out, n);
+    CK(hipStreamSynchronize(st));
+    float tot = 0;
+    for (int i = 0; i < iters; i++) {
+        CK(hipEventRecord(e0, st));
+        hipLaunchKernelGGL((k_pull<NL>), dim3(grid), dim3(block), 0, st, pool + (size_t) (i % 64) * copy_elems, out, n);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
+    }
+    printf("%-44s grid %4d x %4d threads, %2d x 16 B per lane = %7.1f KB per workgroup, %6.2f MB total: %6.2f us per launch (event pair)\n",
+           label, grid, block, NL, block * NL * 16 / 1024.0, (double) n * NL * 16 / 1e6, tot * 1e3 / iters);
+}
+
+int main() {
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const size_t copy_bytes = 8u << 20, copy_elems = copy_bytes / 16;
+    u32x4 * pool; CK(hipMalloc(&pool, copy_bytes * 64)); CK(hipMemset(pool, 0x5a, copy_bytes * 64));
+    unsigned * out; CK(hipMalloc(&out, 1 << 22));
+    // ~3.4 MB per launch in every shape
+    run<3>("mat-vec today (Q/K/V, 5 waves x 3 loads)", 240, 320, pool, copy_elems, out, st);          // 240*320*3*16 = 3.7 MB
+    run<11>("one workgroup per head, 16 waves", 20, 1024, pool, copy_elems, out, st);                 // 20*1024*11*16 = 3.6 MB
+    run<11>("two workgroups per head, 8 waves", 40, 512, pool, copy_elems, out, st);
+    run<6>("two workgroups per head, 16 waves", 40, 1024, pool, copy_elems, out, st);
+    run<3>("four workgroups per head, 16 waves", 80, 1024, pool, copy_elems, out, st);
+    run<1>("empty-ish (one load per lane, 20 workgroups)", 20, 1024, pool, copy_elems, out, st);
+    run<1>("empty-ish (one load per lane, 240 workgroups)", 240, 320, pool, copy_elems, out, st);
+    // cross-attention size: 20 heads x 384 KB of K/V
+    run<24>("cross-attention K/V, one workgroup per head", 20, 1024, pool, copy_elems, out, st);       // 20*1024*24*16 = 7.9 MB
+    run<2>("cross-attention K/V today (12 x 20 workgroups)", 240, 1024, pool, copy_elems, out, st);    // 7.9 MB
+    return 0;
+}
