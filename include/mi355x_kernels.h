@@ -253,15 +253,6 @@ typedef struct mi355x_attn_partials {
 MI355X_API int mi355x_flash_attn_partial(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                                          const mi355x_tensor * mask /* nullable */, float scale, mi355x_attn_partials * out);
 MI355X_API int mi355x_flash_attn_combine(mi355x_ctx * ctx, const mi355x_attn_partials * p, const mi355x_tensor * dst);
-/* One launch for a single-token step's  LayerNorm -> Q / K / V projections (+ bias / scale) -> KV-cache store -> self-attention
- * (src/whisper.cpp:2550-2660), one workgroup per head.  d: what mi355x_gemv_fused takes for the LayerNorm + three projections
- * (T = 1; seg[qi] the query projection, F32 destination or NULL; seg[ki] / seg[vi] storing this step's F16 rows into the caches);
- * k / v / mask / scale: the operands of the ggml_flash_attn_ext that follows, k and v being [64, n_kv, H] views of the caches in
- * which the step's rows are key `new_key`.  Leaves the 128-key partial records of mi355x_flash_attn_partial, bit for bit, and the
- * same cache rows.  n_kv <= 512, a multiple of 32; Q4_0 / Q5_0 / Q8_0 weights; K <= 2048.  MI355X_E_UNSUPPORTED otherwise. */
-MI355X_API int mi355x_self_attn_head(mi355x_ctx * ctx, const mi355x_gemv_desc * d, int qi, int ki, int vi, const mi355x_tensor * k,
-                                     const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */, float scale, int new_key,
-                                     mi355x_attn_partials * out);
 /* decode attention for S single-query states in ONE launch (cross-state batch): state s has its own q [64, 1, H], K / V caches
  * (shapes and strides of k0 / v0, n_kv[s] keys) and mask row; records land as column s of a T = S partial set with
  * nparts = max_s ceil(n_kv[s] / 128) (chunks beyond a state's keys are empty records: weight 0 in the combine). */

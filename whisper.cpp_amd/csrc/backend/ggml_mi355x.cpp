@@ -928,38 +928,10 @@ static bool try_ln_gemv(mi_backend_ctx * b, const ggml_cgraph * g, const ln_chai
     // (A one-launch "LN + Q projection + cross-attention" kernel existed in round 1.  Re-measured with plain launches it LOSES to the
     //  two launches it replaced, 1.478 -> 1.435 ms/token with it switched off (profiles/r02_decode_env_sweep_final.txt): 64 rows of
     //  W_q per workgroup serialise what 256 workgroups otherwise do in parallel, and a dependent boundary costs only ~1.5 us.  Removed.)
-    // Single-token step, the three projections of a self-attention block (src/whisper.cpp:2550-2660): LayerNorm, Q / K / V, the cache
-    // stores AND the flash_attn_ext that follows leave as ONE launch with a workgroup per head (decode_head.hip); the attention's
-    // partial records go to the output projection as before.  One dependent launch less per decoder layer.
-    if (n == 3 && T == 1 && j < g->n_nodes && g->nodes[j]->op == GGML_OP_FLASH_ATTN_EXT) {
-        const ggml_tensor * fa = g->nodes[j];
-        const ggml_tensor * q = fa->src[0], * k = fa->src[1], * v = fa->src[2], * m = fa->src[3];
-        int qi = -1, ki = -1, vi = -1; int64_t nk = -1, nv = -1;
-        for (int s = 0; s < 3; s++) {
-            const ggml_tensor * l = ch[s].last;
-            if (l->type == GGML_TYPE_F32) {
-                const ggml_tensor * r = q; while (r->view_src) r = r->view_src;
-                if (r == l && q->data == l->data) qi = s;
-            } else if (l->type == GGML_TYPE_F16 && k->nb[1] > 0 && v->nb[1] > 0) {
-                const int64_t ok = (const char *) l->data - (const char *) k->data, ov = (const char *) l->data - (const char *) v->data;
-                if (ok >= 0 && ok % (int64_t) k->nb[1] == 0 && ok / (int64_t) k->nb[1] < k->ne[1] && ki < 0) { ki = s; nk = ok / (int64_t) k->nb[1]; }
-                else if (ov >= 0 && ov % (int64_t) v->nb[1] == 0 && ov / (int64_t) v->nb[1] < v->ne[1]) { vi = s; nv = ov / (int64_t) v->nb[1]; }
-            }
-        }
-        if (qi >= 0 && ki >= 0 && vi >= 0 && nk == nv && q->ne[1] == 1 && q->ne[3] == 1 && q->nb[0] == 4 && q->nb[2] == 256 && fa->type == GGML_TYPE_F32 &&
-            ggml_is_contiguous(fa) && !t_overlap(fa, x)) {
-            mi355x_tensor mk = to_mt(k), mv = to_mt(v), mmk;
-            if (m) mmk = to_mt(m);
-            float scale; memcpy(&scale, fa->op_params, 4);
-            mi355x_attn_partials parts;
-            const int rc = mi355x_self_attn_head(b->k, &d, qi, ki, vi, &mk, &mv, m ? &mmk : nullptr, scale, (int) nk, &parts);
-            if (rc != MI355X_E_UNSUPPORTED) {
-                rc_out = rc; end_out = j;
-                if (rc == 0) attn_consume(b, g, j, parts, end_out, rc_out);
-                return true;
-            }
-        }
-    }
+    // (r03 experiment, removed again: LayerNorm + Q/K/V + cache stores + the flash_attn_ext that follows as ONE launch with a workgroup
+    //  per head — no hand-off between workgroups, bit-identical records, one dependent launch less per layer.  It LOST: 13.9 us against
+    //  4.4 + 4.3 us stand-alone, 351-353 vs 349 ms per chunk (profiles/r03b_head_kbench.txt, r03b_head_check.txt): a head's 192 rows of
+    //  integer dots are VALU-bound on ONE CU, ~3 us where 240 workgroups need 0.2.  The kernel is commit 0693a28.)
     mi355x_gemv_cols mcols;
     if (n == 1 && mirror_wanted(g, ch[0], T)) {
         if (char * md = mi_mirror_dev(b)) {

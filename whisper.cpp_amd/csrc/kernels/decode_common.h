@@ -207,7 +207,7 @@ static inline __host__ __device__ size_t dg_act_bytes(int wt, int K, int T) {
 
 
 // waves (= rows) per workgroup of k_gemv_row: enough threads for one float4 activation slot each when K <= 2048
-static inline __host__ __device__ int gemv_row_waves(int K) {
+static inline int gemv_row_waves(int K) {
     if (K > 2048) return 4;
     const int w = (K/4 + 63) / 64;
     return w < 4 ? 4 : (w > 8 ? 8 : w);

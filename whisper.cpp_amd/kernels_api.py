@@ -22,7 +22,7 @@ SYMBOLS = [
     "mi355x_last_error", "mi355x_eager_count", "mi355x_prof_enable", "mi355x_prof_report",
     "mi355x_prof_reset", "mi355x_type_is_quantized", "mi355x_type_row_bytes", "mi355x_repack_to_planar",
     "mi355x_repack_from_planar", "mi355x_mul_mat", "mi355x_prep_act", "mi355x_gemm_f16act", "mi355x_dequant_f16", "mi355x_gemv_fused",
-    "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_combine", "mi355x_self_attn_head", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
+    "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_combine", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
     "mi355x_last_launch_mirrored", "mi355x_act_planes_bytes", "mi355x_act_prepare", "mi355x_act_scratch", "mi355x_flash_attn_partial_multi", "mi355x_flash_attn_planes", "mi355x_decode_head_multi",
     "mi355x_argmax_top2", "mi355x_unary", "mi355x_pad_reflect_1d", "mi355x_get_rows", "mi355x_get_rows_add", "mi355x_im2col_1d", "mi355x_soft_max", "mi355x_rope", "mi355x_concat", "mi355x_memset", "mi355x_checksum", "mi355x_log_mel", "mi355x_log_mel_n_len", "mi355x_debug_read_stamps", "mi355x_wake",
 ]
@@ -121,7 +121,6 @@ def lib() -> C.CDLL:
         L.mi355x_flash_attn_ext_exact.argtypes = [C.c_void_p, TP, TP, TP, TP, TP, C.c_float, C.c_int]
         L.mi355x_flash_attn_partial.argtypes = [C.c_void_p, TP, TP, TP, TP, C.c_float, C.POINTER(AttnPartials)]
         L.mi355x_flash_attn_combine.argtypes = [C.c_void_p, C.POINTER(AttnPartials), TP]
-        L.mi355x_self_attn_head.argtypes = [C.c_void_p, C.POINTER(GemvDesc), C.c_int, C.c_int, C.c_int, TP, TP, TP, C.c_float, C.c_int, C.POINTER(AttnPartials)]
         L.mi355x_act_planes_bytes.restype = C.c_size_t
         L.mi355x_act_planes_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
         L.mi355x_act_prepare.argtypes = [C.c_void_p, C.POINTER(ActDesc), C.c_void_p]
