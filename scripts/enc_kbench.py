@@ -77,8 +77,8 @@ def main():
         tv = ka.tensor(v.data_ptr(), ka.F16, [D, T, H], [2, H * D * 2, D * 2, T * H * D * 2])
         to = ka.tensor(o.data_ptr(), ka.F32, [D, H, T])
         torch.cuda.synchronize()
-        for ng in (1, 2, 3, 4):
-            timed("attention", f"key groups {ng}", {"GGML_MI355X_FATTN_NG": ng},
+        for ng, tr in ((1, 1), (2, 1), (3, 1), (4, 1), (1, 0), (3, 0)):
+            timed("attention", f"key groups {ng}" + ("" if tr else ", V transposed into LDS"), {"GGML_MI355X_FATTN_NG": ng, "GGML_MI355X_FATTN_TR": tr},
                   lambda i: L.mi355x_flash_attn_ext_prep(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), None, C.byref(to), 0.125, p.data_ptr()),
                   4.0 * T * T * D * H, a.iters)
 

@@ -37,9 +37,17 @@ __device__ __forceinline__ int k_off(int row, int slot) { return row*128 + ((slo
 // SIMD runs ONE wave whose LDS reads, MFMAs and softmax VALU work are strictly serial; with NG groups a SIMD holds NG waves
 // whose MFMA and VALU segments overlap.  MASK = false (the encoder) folds scale and log2(e) into one fma per score:
 // p = exp2(s*c - m*c), c = scale*log2(e), running maximum kept on the raw scores (scale > 0 is checked on the host).
-template <int NG, bool MASK>
+// VTR: the V tile stays ROW-major in LDS ([key][64 d], 192-byte pitch, two ds_write_b128 per thread and tile) and the P.V fragment
+// is gathered by ds_read_b64_tr_b16, gfx950's transposing LDS read: lane i of a 16-lane group supplies the 8-byte chunk
+// (row i/4, columns 4(i%4)...) of a 4 x 16 block at any row pitch and receives column i of it (scripts/tr_b16_probe.hip,
+// profiles/r03b_tr_b16_probe.txt) — the two 4-key column segments per lane the fragment consists of.  The 192-byte pitch puts the
+// four rows of a 32-lane half on disjoint bank spans (0 / 48 / 32 / 16 dwords mod 64).  !VTR: V transposed on its way into LDS by
+// 16 ds_write_b16 per thread and tile (136-byte pitch), plain ds_read_b64 of the fragment.
+typedef short short4_t __attribute__((ext_vector_type(4)));
+#define V_PITCH_TR 192
+template <int NG, bool MASK, bool VTR>
 __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
-    constexpr int TILE_LDS = KT*128 + FA_D*VT_PITCH;
+    constexpr int TILE_LDS = KT*128 + (VTR ? KT*V_PITCH_TR : FA_D*VT_PITCH);
     constexpr int COMB_LDS = (NG - 1)*34*256*4;
     __shared__ __attribute__((aligned(16))) char lds[NG*TILE_LDS > COMB_LDS ? NG*TILE_LDS : COMB_LDS];
 
@@ -101,11 +109,15 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
                 const int kl = skey + 32*i;
                 const uint4 kq = i ? kr1 : kr0, vq = i ? vr1 : vr0;
                 *(uint4 *) (ldsK + k_off(kl, sch)) = kq;
-                const uint32_t w[4] = { vq.x, vq.y, vq.z, vq.w };
-                #pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    const uint16_t hv16 = (uint16_t) ((w[e >> 1] >> (16*(e & 1))) & 0xFFFF);
-                    *(uint16_t *) (ldsV + (sch*8 + e)*VT_PITCH + kl*2) = hv16;
+                if constexpr (VTR) {
+                    *(uint4 *) (ldsV + kl*V_PITCH_TR + sch*16) = vq;
+                } else {
+                    const uint32_t w[4] = { vq.x, vq.y, vq.z, vq.w };
+                    #pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const uint16_t hv16 = (uint16_t) ((w[e >> 1] >> (16*(e & 1))) & 0xFFFF);
+                        *(uint16_t *) (ldsV + (sch*8 + e)*VT_PITCH + kl*2) = hv16;
+                    }
                 }
             }
         }
@@ -192,11 +204,21 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
             const int kb = 16*c + 4*hf;
             #pragma unroll
             for (int i = 0; i < 2; i++) {
-                const char * vp = ldsV + (i*32 + (lane & 31))*VT_PITCH + kb*2;
-                const uint2 v0 = *(const uint2 *) vp, v1 = *(const uint2 *) (vp + 16);
                 half8_t vf;
-                const uint32_t vw[4] = { v0.x, v0.y, v1.x, v1.y };
-                __builtin_memcpy(&vf, vw, 16);
+                if constexpr (VTR) {
+                    // this lane's 16-lane group reads the block rows (keys) 16c + 4hf + {0..3} [+ 8], columns (dims) 32i + 16(group & 1) + {0..15}
+                    const int li = lane & 15;
+                    const char * vb = ldsV + (16*c + 4*hf + (li >> 2))*V_PITCH_TR + (32*i + 16*((lane >> 4) & 1) + 4*(li & 3))*2;
+                    const short4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *) vb);
+                    const short4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *) (vb + 8*V_PITCH_TR));
+                    __builtin_memcpy(&vf, &r0, 8);
+                    __builtin_memcpy((char *) &vf + 8, &r1, 8);
+                } else {
+                    const char * vp = ldsV + (i*32 + (lane & 31))*VT_PITCH + kb*2;
+                    const uint2 v0 = *(const uint2 *) vp, v1 = *(const uint2 *) (vp + 16);
+                    const uint32_t vw[4] = { v0.x, v0.y, v1.x, v1.y };
+                    __builtin_memcpy(&vf, vw, 16);
+                }
                 o[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[c], o[i], 0, 0, 0);
             }
         }
@@ -330,10 +352,15 @@ static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi35
     if (ng > ntiles) ng = ntiles;
     if (!folded && ng > 3) ng = 3;                              // the masked form needs 166 VGPRs: three waves per SIMD at most
     const dim3 grid((T + 127) / 128, H);
-#define FA_LAUNCH(NG_) (folded ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false>, grid, dim3(256*NG_), 0, a, bytes, flops) \
-                               : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true>,  grid, dim3(256*NG_), 0, a, bytes, flops))
+    // V through the transposing LDS read (GGML_MI355X_FATTN_TR=0: transposed on the way into LDS, the r02 layout)
+    const bool vtr = !(getenv("GGML_MI355X_FATTN_TR") && !atoi(getenv("GGML_MI355X_FATTN_TR")));
+#define FA_LAUNCH(NG_) (folded ? (vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, true>, grid, dim3(256*NG_), 0, a, bytes, flops) \
+                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, false>, grid, dim3(256*NG_), 0, a, bytes, flops)) \
+                               : (vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, true>,  grid, dim3(256*NG_), 0, a, bytes, flops) \
+                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, false>,  grid, dim3(256*NG_), 0, a, bytes, flops)))
     switch (ng) {
-        case 4:  return emit(ctx, "fattn_mfma", k_fattn_mfma<4, false>, grid, dim3(1024), 0, a, bytes, flops);
+        case 4:  return vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, true>, grid, dim3(1024), 0, a, bytes, flops)
+                            : emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, false>, grid, dim3(1024), 0, a, bytes, flops);
         case 3:  return FA_LAUNCH(3);
         case 2:  return FA_LAUNCH(2);
         default: return FA_LAUNCH(1);

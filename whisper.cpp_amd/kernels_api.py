@@ -36,6 +36,13 @@ class Epilogue(C.Structure):
     _fields_ = [("bias", C.c_void_p), ("scale", C.c_float), ("has_scale", C.c_int32), ("gelu", C.c_int32), ("bias_per_col", C.c_int32),
                 ("residual", C.c_void_p), ("residual_nb1", C.c_int64)]
 
+    def __init__(self, bias=None, scale=0.0, has_scale=0, gelu=0, residual=None, residual_nb1=0, bias_per_col=0):
+        # positional order of the struct BEFORE bias_per_col took the padding slot behind `gelu` (round 3): callers that fill the
+        # struct positionally keep meaning what they meant
+        super().__init__()
+        self.bias, self.scale, self.has_scale, self.gelu = bias or None, scale, has_scale, gelu
+        self.residual, self.residual_nb1, self.bias_per_col = residual or None, residual_nb1, bias_per_col
+
 
 class GemvSeg(C.Structure):
     _fields_ = [("w", C.c_void_p), ("wtype", C.c_int32), ("N", C.c_int32), ("ep", Epilogue), ("dst", C.c_void_p),
