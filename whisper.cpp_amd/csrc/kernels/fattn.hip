@@ -166,11 +166,12 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
             }
         } else {
             if (k0 + KT > a.n_kv) {                               // the last tile only: keys past the end never count
+                const int lim = a.n_kv - k0 - 4*hf;               // (hipcc if-converts this block: one compare against a constant + one select per score)
                 #pragma unroll
                 for (int b = 0; b < 2; b++)
                     #pragma unroll
                     for (int r = 0; r < 16; r++)
-                        if (k0 + 32*b + (r & 3) + 8*(r >> 2) + 4*hf >= a.n_kv) s[b][r] = -INFINITY;
+                        if (32*b + (r & 3) + 8*(r >> 2) >= lim) s[b][r] = -INFINITY;
             }
             #pragma unroll
             for (int b = 0; b < 2; b++)
