@@ -36,7 +36,6 @@ def main():
         return (torch.randn(shape, device="cuda:0", generator=g) * scale).to(dtype)
 
     def timed(label, variant, envs, fn, flops, iters):
-        variant = variant[:44]
         old = {k: os.environ.get(k) for k in envs}
         for k, v in envs.items():
             os.environ[k] = str(v)
@@ -44,7 +43,7 @@ def main():
             for i in range(3):
                 rc = fn(i)
                 if rc:
-                    print(f"{label:10s} {variant:44s} rc={rc} {L.mi355x_last_error()}")
+                    print(f"{label:10s} {variant:28s} rc={rc} {L.mi355x_last_error()}")
                     return
             ctx.sync()
             ctx.prof(True)
@@ -64,7 +63,7 @@ def main():
         calls = sum(r["calls"] for r in rows)
         us = tot * 1e3 / iters
         names = ",".join(sorted({r["name"] for r in rows}))
-        print(f"{label:10s} {variant:44s} {us:8.2f} us per step  {flops / us / 1e6:7.1f} TFLOP/s  ({calls // iters} launches: {names})", flush=True)
+        print(f"{label:10s} {variant:28s} {us:8.2f} us per step  {flops / us / 1e6:7.1f} TFLOP/s  ({calls // iters} launches: {names})", flush=True)
 
     # ---- attention: 1500 queries x 1500 keys x 20 heads, result + the O-projection's prepared activations
     if "attn" in what:
@@ -78,9 +77,8 @@ def main():
         tv = ka.tensor(v.data_ptr(), ka.F16, [D, T, H], [2, H * D * 2, D * 2, T * H * D * 2])
         to = ka.tensor(o.data_ptr(), ka.F32, [D, H, T])
         torch.cuda.synchronize()
-        for ng, tr, dma in ((1, 1, 1), (2, 1, 1), (3, 1, 1), (1, 1, 0), (2, 1, 0), (3, 1, 0), (4, 1, 0), (1, 0, 0), (3, 0, 0)):
-            timed("attention", f"key groups {ng}" + (", tiles by LDS-DMA" if dma else "") + ("" if tr else ", V transposed into LDS"),
-                  {"GGML_MI355X_FATTN_NG": ng, "GGML_MI355X_FATTN_TR": tr, "GGML_MI355X_FATTN_DMA": dma},
+        for ng, tr in ((1, 1), (2, 1), (3, 1), (4, 1), (1, 0), (3, 0)):
+            timed("attention", f"key groups {ng}" + ("" if tr else ", V transposed into LDS"), {"GGML_MI355X_FATTN_NG": ng, "GGML_MI355X_FATTN_TR": tr},
                   lambda i: L.mi355x_flash_attn_ext_prep(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), None, C.byref(to), 0.125, p.data_ptr()),
                   4.0 * T * T * D * H, a.iters)
 

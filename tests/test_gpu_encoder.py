@@ -86,14 +86,12 @@ def test_attention_key_groups_agree_with_exact_attention_and_with_each_other(gpu
     pr /= pr.sum(axis=-1, keepdims=True)
     exact = np.einsum("htk,khd->thd", pr, v.astype(np.float64))
     got = {}
-    # ng: 1..4 = key groups, default layout (tiles by LDS-DMA, V by the transposing read); 1x: V transposed on its way into LDS (r02 layout);
-    # 2x: register-staged tiles + transposing read
-    for ng in (1, 2, 3, 4, 11, 13, 21, 22, 23):
+    for ng in (1, 2, 3, 4, 11, 13):                       # 11, 13: one / three key groups with V transposed on its way into LDS (r02 layout)
         o_d = torch.full((T, H, D), 7.0, dtype=torch.float32, device="cuda:0")
         p_d = torch.zeros((T, H * D), dtype=torch.float16, device="cuda:0")
         p2_d = torch.zeros((T, H * D), dtype=torch.float16, device="cuda:0")
         torch.cuda.synchronize()
-        with env(GGML_MI355X_FATTN_NG=ng % 10, GGML_MI355X_FATTN_TR=0 if 10 < ng < 20 else 1, GGML_MI355X_FATTN_DMA=0 if ng > 20 else 1):
+        with env(GGML_MI355X_FATTN_NG=ng % 10, GGML_MI355X_FATTN_TR=0 if ng > 10 else 1):
             ctx.check(ka.lib().mi355x_flash_attn_ext_prep(ctx.h, C.byref(tq), C.byref(tk), C.byref(tv), tm, C.byref(ka.tensor(o_d.data_ptr(), ka.F32, [D, H, T])), 0.125, p_d.data_ptr()), "flash_attn_prep")
             ctx.sync()
         got[ng] = o_d.cpu().numpy()
@@ -106,8 +104,6 @@ def test_attention_key_groups_agree_with_exact_attention_and_with_each_other(gpu
         assert np.array_equal(p_d.cpu().numpy().view(np.uint16), p2_d.cpu().numpy().view(np.uint16)), ng
     # the V layout changes nothing but where the same f16 values are read from: bit-identical
     assert np.array_equal(got[1].view(np.uint32), got[11].view(np.uint32)) and np.array_equal(got[3].view(np.uint32), got[13].view(np.uint32))
-    for n in (1, 2, 3):
-        assert np.array_equal(got[n].view(np.uint32), got[20 + n].view(np.uint32)), n
     for ng in (2, 3, 4):
         # between the forms only the f16 rounding of P differs (it is taken against another running maximum): 2^-11 relative per weight
         assert nmse(got[1], got[ng]) < 1e-6, (ng, nmse(got[1], got[ng]))

@@ -43,23 +43,21 @@ __device__ __forceinline__ int k_off(int row, int slot) { return row*128 + ((slo
 // profiles/r03b_tr_b16_probe.txt) — the two 4-key column segments per lane the fragment consists of.  The 192-byte pitch puts the
 // four rows of a 32-lane half on disjoint bank spans (0 / 48 / 32 / 16 dwords mod 64).  !VTR: V transposed on its way into LDS by
 // 16 ds_write_b16 per thread and tile (136-byte pitch), plain ds_read_b64 of the fragment.
+// (r03 experiment, not kept: K / V tiles by LDS-DMA into a two-stage ring per key group with the V fragments read by inline-asm
+//  ds_read_b64_tr_b16 — through the builtin hipcc waits vmcnt(0), i.e. for the NEXT tile's transfer, in front of the P.V MFMAs —
+//  measured 28.2 against 28.2 us with three key groups, 28.0 against 28.6 with two, and failed its parity test;
+//  profiles/r03b_attn_dma_experiment.txt, commit 5eabd95.)
 typedef short short4_t __attribute__((ext_vector_type(4)));
 #define V_PITCH_TR 192
-// DMA (needs VTR, no mask): K and V tiles travel global -> LDS by LDS-DMA into a two-stage ring per key group — no staging registers, no
-// ds_write at all, ONE barrier per tile, and no ordinary global load inside the loop (which would make hipcc drain the DMA queue).
-// The K swizzle (k_off) and V's (the two 64-byte halves of a 128-byte row trade places on rows with bit 1 set: the four rows of a
-// 32-lane half of the transposing read then sit on disjoint bank spans at a 128-byte pitch) are applied to the per-lane GLOBAL
-// address, the LDS side of an LDS-DMA being lane-linear.
-template <int NG, bool MASK, bool VTR, bool DMA>
+template <int NG, bool MASK, bool VTR>
 __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
-    static_assert(!DMA || (VTR && !MASK), "the LDS-DMA form exists for the unmasked transposing-read layout");
-    constexpr int TILE_LDS = DMA ? 2*(KT*128 + KT*128) : KT*128 + (VTR ? KT*V_PITCH_TR : FA_D*VT_PITCH);
+    constexpr int TILE_LDS = KT*128 + (VTR ? KT*V_PITCH_TR : FA_D*VT_PITCH);
     constexpr int COMB_LDS = (NG - 1)*34*256*4;
-    __shared__ __attribute__((aligned(1024))) char lds[NG*TILE_LDS > COMB_LDS ? NG*TILE_LDS : COMB_LDS];
+    __shared__ __attribute__((aligned(16))) char lds[NG*TILE_LDS > COMB_LDS ? NG*TILE_LDS : COMB_LDS];
 
     const int grp = NG > 1 ? __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 8)) : 0;
     const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;
-    char * ldsK = lds + grp*TILE_LDS; char * ldsV = ldsK + KT*128;          // (DMA: stage 0; stage 1 is 2*KT*128 bytes further)
+    char * ldsK = lds + grp*TILE_LDS; char * ldsV = ldsK + KT*128;
     const int hq = blockIdx.y, hk = hq / a.rk2, hv = hq / a.rv2;
     const int qi = blockIdx.x*128 + wave*32 + (lane & 31);          // this lane's query
     const int hf = lane >> 5;
@@ -104,31 +102,10 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
     } while (0)
     const int nt = (a.n_kv + KT - 1) / KT, tpg = (nt + NG - 1) / NG;
     const int t_begin = grp*tpg, t_end = min(nt, t_begin + tpg);
-    // LDS-DMA form: instruction j of a tile (8 per operand, two per wave) moves rows 8j .. 8j+7: lane -> row 8j + lane/8, physical chunk lane%8
-    auto dma_tile = [&](int k0_, int stage) {
-        char * sK = ldsK + stage*(2*KT*128); char * sV = sK + KT*128;
-        #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int j = wave*2 + u, r = 8*j + (lane >> 3), p = lane & 7;
-            const int key = min(k0_ + r, a.n_kv - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (kbase + (int64_t) key*a.k.nb[1] + ((p ^ ((r >> 1) & 7)) << 4)),
-                                             (__attribute__((address_space(3))) void *) (sK + j*1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (vbase + (int64_t) key*a.v.nb[1] + ((p ^ (((r >> 1) & 1) << 2)) << 4)),
-                                             (__attribute__((address_space(3))) void *) (sV + j*1024), 16, 0, 0);
-        }
-    };
-    if constexpr (DMA) { if (t_begin < t_end) dma_tile(t_begin*KT, 0); }
-    else FA_FETCH(t_begin*KT);
+    FA_FETCH(t_begin*KT);
     for (int it = 0; it < tpg; it++) {                            // every group makes the same number of barrier visits
         const int k0 = (t_begin + it)*KT;
         const bool live = t_begin + it < t_end;                   // uniform per group (a whole number of waves)
-        if constexpr (DMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of tile `it` has landed
-            __builtin_amdgcn_s_barrier();                         // ... everyone's; and everyone is done reading the other stage
-            if (live && t_begin + it + 1 < t_end) dma_tile(k0 + KT, (it + 1) & 1);
-            if (!live) continue;
-            ldsK = lds + grp*TILE_LDS + (it & 1)*(2*KT*128); ldsV = ldsK + KT*128;
-        } else {
         __syncthreads();                                          // previous tile fully consumed
         if (live) {
             #pragma unroll
@@ -152,7 +129,6 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
         if (!live) continue;
         // the next tile's loads are in flight while this one is computed (clamped past the end: harmless re-read of the last keys)
         FA_FETCH(k0 + KT);
-        }
 
         // S^T[key][query] for the two 32-key blocks of the tile
         floatx16 s[2];
@@ -167,23 +143,6 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
             }
         }
         // running max.  register r of block b <-> key k0 + 32b + (r&3) + 8*(r>>2) + 4*hf
-        // DMA form: the V fragments are requested HERE, by inline asm, and waited for in front of the P.V MFMAs.  Through the builtin,
-        // hipcc waits vmcnt(0) in front of them (a ds op without memory operand info may alias the LDS-DMA in flight: the next tile's),
-        // which serialises tile i's arithmetic behind tile i+1's transfer; asm reads are outside that bookkeeping, and issued this
-        // early their latency passes under the softmax.
-        u32x2_t vfr[4][2][2];
-        if constexpr (DMA) {
-            const int li = lane & 15;
-            #pragma unroll
-            for (int c = 0; c < 4; c++)
-                #pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    const int vrow = 16*c + 4*hf + (li >> 2), vcol = (32*i + 16*((lane >> 4) & 1) + 4*(li & 3))*2;
-                    const unsigned ad = (unsigned) (size_t) (ldsV + vrow*128 + (vcol ^ (((vrow >> 1) & 1) << 6)));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vfr[c][i][0]) : "v"(ad) : "memory");
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(vfr[c][i][1]) : "v"(ad) : "memory");     // rows + 8: same swizzle bit
-                }
-        }
         float tmax = -INFINITY;
         if (MASK) {
             #pragma unroll
@@ -245,28 +204,16 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
             #pragma unroll
             for (int r = 0; r < 16; r++) o[i][r] *= alpha;
         // O^T[d][query] += V^T[d][key] * P^T[key][query]
-        if constexpr (DMA) {
-            // the wait names every destination: no use of a fragment register is scheduled above it
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfr[0][0][0]), "+v"(vfr[0][0][1]), "+v"(vfr[0][1][0]), "+v"(vfr[0][1][1]),
-                                                   "+v"(vfr[1][0][0]), "+v"(vfr[1][0][1]), "+v"(vfr[1][1][0]), "+v"(vfr[1][1][1]) :: "memory");
-            asm volatile("" : "+v"(vfr[2][0][0]), "+v"(vfr[2][0][1]), "+v"(vfr[2][1][0]), "+v"(vfr[2][1][1]),
-                              "+v"(vfr[3][0][0]), "+v"(vfr[3][0][1]), "+v"(vfr[3][1][0]), "+v"(vfr[3][1][1]) :: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
         #pragma unroll
         for (int c = 0; c < 4; c++) {                          // c = 2b + kk': keys 32b + 16kk' + {(e&3) + 8(e>>2) + 4hf}
             const int kb = 16*c + 4*hf;
             #pragma unroll
             for (int i = 0; i < 2; i++) {
                 half8_t vf;
-                if constexpr (DMA) {
-                    __builtin_memcpy(&vf, &vfr[c][i][0], 8);
-                    __builtin_memcpy((char *) &vf + 8, &vfr[c][i][1], 8);
-                } else if constexpr (VTR) {
+                if constexpr (VTR) {
                     // this lane's 16-lane group reads the block rows (keys) 16c + 4hf + {0..3} [+ 8], columns (dims) 32i + 16(group & 1) + {0..15}
                     const int li = lane & 15;
-                    const int vrow = 16*c + 4*hf + (li >> 2), vcol = (32*i + 16*((lane >> 4) & 1) + 4*(li & 3))*2;
-                    const char * vb = ldsV + vrow*V_PITCH_TR + vcol;
+                    const char * vb = ldsV + (16*c + 4*hf + (li >> 2))*V_PITCH_TR + (32*i + 16*((lane >> 4) & 1) + 4*(li & 3))*2;
                     const short4_t r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *) vb);
                     const short4_t r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t *) (vb + 8*V_PITCH_TR));
                     __builtin_memcpy(&vf, &r0, 8);
@@ -412,16 +359,13 @@ static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi35
     const dim3 grid((T + 127) / 128, H);
     // V through the transposing LDS read (GGML_MI355X_FATTN_TR=0: transposed on the way into LDS, the r02 layout)
     const bool vtr = !(getenv("GGML_MI355X_FATTN_TR") && !atoi(getenv("GGML_MI355X_FATTN_TR")));
-    // K / V tiles by LDS-DMA (unmasked transposing-read form only; needs 16-byte aligned key rows, which the checks above guarantee)
-    const bool dma = vtr && folded && !(getenv("GGML_MI355X_FATTN_DMA") && !atoi(getenv("GGML_MI355X_FATTN_DMA")));
-#define FA_LAUNCH(NG_) (folded ? (dma ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, true, true>, grid, dim3(256*NG_), 0, a, bytes, flops) \
-                                : vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, true, false>, grid, dim3(256*NG_), 0, a, bytes, flops) \
-                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, false, false>, grid, dim3(256*NG_), 0, a, bytes, flops)) \
-                               : (vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, true, false>,  grid, dim3(256*NG_), 0, a, bytes, flops) \
-                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, false, false>,  grid, dim3(256*NG_), 0, a, bytes, flops)))
+#define FA_LAUNCH(NG_) (folded ? (vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, true>, grid, dim3(256*NG_), 0, a, bytes, flops) \
+                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, false>, grid, dim3(256*NG_), 0, a, bytes, flops)) \
+                               : (vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, true>,  grid, dim3(256*NG_), 0, a, bytes, flops) \
+                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, false>,  grid, dim3(256*NG_), 0, a, bytes, flops)))
     switch (ng) {
-        case 4:  return vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, true, false>, grid, dim3(1024), 0, a, bytes, flops)      // (no LDS-DMA form: 128 registers)
-                            : emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, false, false>, grid, dim3(1024), 0, a, bytes, flops);
+        case 4:  return vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, true>, grid, dim3(1024), 0, a, bytes, flops)
+                            : emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, false>, grid, dim3(1024), 0, a, bytes, flops);
         case 3:  return FA_LAUNCH(3);
         case 2:  return FA_LAUNCH(2);
         default: return FA_LAUNCH(1);
