@@ -237,3 +237,27 @@ def test_gemm_epilogue_with_a_bias_per_column_and_gelu_equals_the_separate_ops(g
         acc = x8.cpu().numpy().astype(np.float16).astype(np.float64) @ w.cpu().numpy().astype(np.float64).T + bias[:4, None]
         ref = 0.5 * acc * (1.0 + np.tanh(0.7978845608028654 * acc * (1.0 + 0.044715 * acc * acc)))
         assert np.abs(y8.cpu().numpy() - ref).max() < 5e-3
+
+
+@pytest.mark.parametrize("M,K,T", [(1280, 1280, 1500), (384, 384, 200), (516, 256, 77)])
+def test_gemm_with_an_f16_destination_equals_the_rounded_f32_result(gpu, M, K, T):
+    """the K / V projections write F16 (ggml_cpy folded into the product): four halves per store on the vector path, the same
+    round-to-nearest-even of the same f32 values as the F32 product followed by a cast (M = 516: the scalar path, M % 4 == 0 but rows not 16-byte aligned)"""
+    ctx, ka, torch = gpu
+    rng = np.random.default_rng(M + T)
+    w = dev(torch, (rng.standard_normal((M, K)) / np.sqrt(K)).astype(np.float16))
+    act = dev(torch, rng.standard_normal((T, K)).astype(np.float16))
+    bias = dev(torch, rng.standard_normal(M).astype(np.float32))
+    ep = ka.Epilogue()
+    ep.bias, ep.scale, ep.has_scale = bias.data_ptr(), 0.35, 1
+    tw = ka.tensor(w.data_ptr(), ka.F16, [K, M])
+    y32 = torch.zeros((T, M), dtype=torch.float32, device="cuda:0")
+    y16 = torch.zeros((T, M), dtype=torch.float16, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), K, T, y32.data_ptr(), M * 4, ka.F32, C.byref(ep)), "gemm f32")
+    ctx.sync()
+    ctx.check(ka.lib().mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), K, T, y16.data_ptr(), M * 2, ka.F16, C.byref(ep)), "gemm f16")
+    ctx.sync()
+    want = y32.cpu().numpy().astype(np.float16)
+    got = y16.cpu().numpy()
+    assert np.abs(want.astype(np.float32)).max() > 0.1 and np.array_equal(got.view(np.uint16), want.view(np.uint16))

@@ -283,7 +283,9 @@ extern "C" int mi355x_dequant_f16(mi355x_ctx * ctx, const mi355x_tensor * A, voi
 template <int NT>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc)[2][NT], int m0, int64_t n0, int wm, int wn, int WN, int lane) {
     // epilogue: C[i = A row][j = B row]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) && !a.dst_f16 &&
+    // (F16 destinations — the K / V projections whose ggml_cpy into an F16 tensor is folded in — take the vector path too since r03:
+    //  four halves per 8-byte store instead of four 2-byte stores)
+    const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) &&
                         (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || a.bias_t || ((uintptr_t) a.bias % 16 == 0));
     if (a.prep) {
         // The result is the activation matrix of the NEXT GEMM (fc1 + GELU -> fc2, src/whisper.cpp:2224-2238): write what k_prep_act
@@ -348,7 +350,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc
                     if (a.has_scale) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
                     if (a.gelu) { v[0] = gelu_lut(v[0], a.gelu_tab); v[1] = gelu_lut(v[1], a.gelu_tab); v[2] = gelu_lut(v[2], a.gelu_tab); v[3] = gelu_lut(v[3], a.gelu_tab); }
                     if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w; }
-                    *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.dst_f16) *(uint2 *) (a.dst + t*a.dst_nb1 + (int64_t) m*2) = make_uint2(pack_h2(v[0], v[1]), pack_h2(v[2], v[3]));
+                    else           *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     #pragma unroll
                     for (int e = 0; e < 4; e++) {
