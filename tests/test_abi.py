@@ -57,3 +57,41 @@ def test_reference_loader_accepts_or_skips_plugin(plugin_env):
     r = subprocess.run([str(exe), "-m", "/nonexistent.bin"], env=plugin_env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
     assert "load_backend" in r.stdout                       # the loader saw the plugin
     assert ("not supported on this system" in r.stdout) != has_gpu()
+
+
+def test_ctypes_mirrors_have_the_layout_of_the_c_structs(tmp_path):
+    """the ctypes structures of whisper.cpp_amd/kernels_api.py against sizeof / offsetof of include/mi355x_kernels.h as gcc lays them
+    out, and positional construction of the epilogue in its documented order (round 3: `bias_per_col` took the padding slot behind
+    `gelu`; a mirror that had shifted `residual` by one position crashed the GPU suite)"""
+    import subprocess
+    from whisper_cpp_amd import kernels_api as ka
+    probes = {
+        "mi355x_epilogue": ["bias", "scale", "has_scale", "gelu", "bias_per_col", "residual", "residual_nb1"],
+        "mi355x_tensor": ["data", "type", "ne", "nb"],
+        "mi355x_gemv_seg": ["w", "wtype", "N", "ep", "dst", "dst_type", "dst_nb1"],
+        "mi355x_gemv_desc": ["x", "x_nb1", "K", "T", "has_norm", "eps", "ln_w", "ln_b", "nseg", "seg", "attn_part_o", "attn_part_ml", "attn_nparts", "x_planes", "planes_out", "planes_out_only", "cols"],
+        "mi355x_attn_partials": ["part_o", "part_ml", "nparts", "T", "H"],
+    }
+    mirrors = {"mi355x_epilogue": ka.Epilogue, "mi355x_tensor": ka.Tensor, "mi355x_gemv_seg": ka.GemvSeg, "mi355x_gemv_desc": ka.GemvDesc, "mi355x_attn_partials": ka.AttnPartials}
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "mi355x_kernels.h"', "int main(void) {"]
+    for s, fields in probes.items():
+        src.append(f'  printf("{s} %zu", sizeof({s}));')
+        for f in fields:
+            src.append(f'  printf(" %zu", offsetof({s}, {f}));')
+        src.append('  printf("\\n");')
+    src += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", f"-I{ROOT / 'include'}", str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout
+    for line in out.strip().splitlines():
+        name, size, *offs = line.split()
+        m = mirrors[name]
+        assert C.sizeof(m) == int(size), (name, C.sizeof(m), size)
+        for f, o in zip(probes[name], offs):
+            assert getattr(m, f).offset == int(o), (name, f, getattr(m, f).offset, o)
+    e = ka.Epilogue(11, 0.5, 1, 1, 22, 33)                                  # bias, scale, has_scale, gelu, residual, residual_nb1
+    assert (e.bias, e.scale, e.has_scale, e.gelu, e.bias_per_col, e.residual, e.residual_nb1) == (11, 0.5, 1, 1, 0, 22, 33)
+    e = ka.Epilogue(bias=5, bias_per_col=1)
+    assert e.bias == 5 and e.bias_per_col == 1 and e.residual is None
