@@ -130,7 +130,9 @@ MI355X_API int mi355x_mul_mat(mi355x_ctx * ctx, const mi355x_tensor * w, const m
 /* Two-step form of mul_mat for T > 8 (lets the caller share one prepared activation between several
  * weights, e.g. Q/K/V): mi355x_prep_act rounds x [K,T] (F32 or F16, row stride x_nb1 bytes) to the weight
  * type's vec_dot_type and stores it as f16 [T][K]: mode 0 = F16 weights (plain f16), 1 = Q4_0/Q5_0/Q8_0
- * weights (Q8_0 round trip), 2 = Q4_K weights (Q8_K round trip).  mi355x_gemm_f16act is the MFMA GEMM. */
+ * weights (Q8_0 round trip), 2 = Q4_K weights (Q8_K round trip).  mi355x_gemm_f16act is the MFMA GEMM.
+ * Modes 3 / 4 write the activation ROWS of the int8 tile GEMM instead (Q8_0 / Q8_K blocks as integers + scales, see mi355x_gemm_q8act;
+ * act_f16 then points to mi355x_act_rows_bytes(...) bytes; K % 128 == 0). */
 MI355X_API int mi355x_prep_act(mi355x_ctx * ctx, const void * x, int64_t x_nb1, int x_is_f16, void * act_f16, int K, int64_t T, int mode);
 MI355X_API int mi355x_gemm_f16act(mi355x_ctx * ctx, const mi355x_tensor * w, const void * act_f16, int64_t ld, int64_t T,
                                   void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep /* nullable */);
@@ -139,6 +141,26 @@ MI355X_API int mi355x_gemm_f16act(mi355x_ctx * ctx, const mi355x_tensor * w, con
  * mi355x_prep_act pass over dst.  dst may be NULL when nothing else reads the F32 result (then only prep_out is written). */
 MI355X_API int mi355x_gemm_f16act_prep(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act_f16, int64_t ldb, int64_t T,
                                        void * dst, int64_t dst_nb1, const mi355x_epilogue * ep, void * prep_out);
+
+/* ---- the int8 tile GEMM over the QUANTIZED operands (T > 8; csrc/kernels/mmq.hip) ---------------------------------------------
+ * The reference quantizes src1 to the weight type's vec_dot_type and runs integer block dots for EVERY column count
+ * (ggml-cpu/ggml-cpu.c:1322-1357; arch/x86/quants.c:1142-1181 ...).  Here the same integers go through v_mfma_i32_32x32x32_i8 (one
+ * instruction = one 32-element block of a 32 x 32 tile) and each block's sums are folded into F32 with fma(float(sum), dw*dx, acc):
+ * the CPU's own integer sums, f32 summation in ascending block order.  The weight is read in its block-quantized planar layout and
+ * unpacked per workgroup into an LDS int8 tile; no f16 / int8 copy of a weight exists.
+ *
+ * Activation ROWS of x [K, T] (csrc/kernels/qrows.h): q[T][K] int8 | d[T][K/32] f32 for Q4_0 / Q5_0 / Q8_0 weights (Q8_0 blocks,
+ * arch/x86/quants.c:302-398), q[T][K] int8 | d[T][K/256] f32 | bsum[T][K/32] i32 for Q4_K weights (Q8_K blocks, ggml-quants.c:2768-2805);
+ * mi355x_act_rows_bytes gives the size.  Producers: mi355x_prep_act / mi355x_norm_prep with mode 3 (Q8_0 rows) or 4 (Q8_K rows),
+ * mi355x_flash_attn_ext_prep_rows, mi355x_gemm_q8act_prep (the epilogue of the GEMM that produces x).  K % 128 == 0.
+ * mi355x_gemm_q8act_prep: the epilogue ALSO leaves the Q8_0 rows of the F32 result (K' = M, M % 128 == 0) in prep_rows_out — the
+ * activations of the next quantized GEMM (fc1 + GELU -> fc2, src/whisper.cpp:2224-2238); dst may be NULL when nothing else reads the
+ * F32 result.  Bit-identical to mi355x_prep_act(mode 3) on dst. */
+MI355X_API size_t mi355x_act_rows_bytes(int wtype, int64_t K, int64_t T);
+MI355X_API int mi355x_gemm_q8act(mi355x_ctx * ctx, const mi355x_tensor * w, const void * act_rows, int64_t T,
+                                 void * dst, int64_t dst_nb1, int dst_type, const mi355x_epilogue * ep /* nullable */);
+MI355X_API int mi355x_gemm_q8act_prep(mi355x_ctx * ctx, const mi355x_tensor * w, const void * act_rows, int64_t T,
+                                      void * dst, int64_t dst_nb1, const mi355x_epilogue * ep, void * prep_rows_out);
 
 /* One-time preparation of a quantized weight for the MFMA path: writes dst_f16[M][K] = f16(dequantized w), the
  * exact values mi355x_gemm_f16act feeds the matrix cores when given the quantized tensor.  A caller that keeps
@@ -279,6 +301,12 @@ MI355X_API int mi355x_flash_attn_ext(mi355x_ctx * ctx, const mi355x_tensor * q, 
 MI355X_API int mi355x_flash_attn_ext_prep(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k,
                                           const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */,
                                           const mi355x_tensor * dst, float scale, void * prep_out);
+
+/* T > 8: the same, leaving the Q8_0 ROWS (mi355x_prep_act mode 3, see mi355x_gemm_q8act) of dst seen as [T][H*64] in rows_out — the
+ * activations of the int8 tile GEMM that is the output projection; H*64 % 128 == 0 */
+MI355X_API int mi355x_flash_attn_ext_prep_rows(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k,
+                                               const mi355x_tensor * v, const mi355x_tensor * mask /* nullable */,
+                                               const mi355x_tensor * dst, float scale, void * rows_out);
 
 /* ggml_flash_attn_ext with the ARITHMETIC of the reference CPU dispatcher (ggml-cpu/ops.cpp:9077-9230), opt-in: split-KV over
  * `nth` chunks for T == 1 && n_kv >= 512 (the CPU's result depends on its thread count), the F32 tiled path with ggml_v_expf for

@@ -103,7 +103,9 @@ def test_mul_mat_vs_oracle(gpu, oracle, t, K, N, T):
     ref = np.empty((T, N), dtype=np.float32)
     oracle.oracle_mul_mat(tid, ptr(blocks), ptr(x), ptr(ref), K, N, T)
     got = run_mul_mat(gpu, tid, planar, x, K, N, T)
-    tol = 1e-10 if T <= 8 else 2e-6
+    # T > 8 with K in whole 128-element steps (every Whisper width) runs the int8 tile GEMM over the quantized operands (mmq.hip): the
+    # CPU's own integer block sums, held to the mat-vec bar; other K fall back to the f16 MFMA path (f16-rounded d*q products)
+    tol = 1e-10 if (T <= 8 or K % 128 == 0) else 2e-6
     e = nmse(ref, got)
     assert e < tol, f"{t} K={K} N={N} T={T}: NMSE {e:.3e} >= {tol}"
 

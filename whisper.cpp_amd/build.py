@@ -22,11 +22,14 @@ BUILD = ROOT / "build"
 REF = Path(os.environ.get("WHISPER_REF", "/root/reference"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-KERNEL_SRCS = ["ctx.hip", "elementwise.hip", "gemv.hip", "decode.hip", "decode_q.hip", "gemm_mfma.hip", "fattn.hip", "fattn_exact.hip", "mel.hip", "mul_mat.hip"]
+KERNEL_SRCS = ["ctx.hip", "elementwise.hip", "gemv.hip", "decode.hip", "decode_q.hip", "gemm_mfma.hip", "fattn.hip", "fattn_exact.hip", "mel.hip", "mul_mat.hip", "mmq.hip"]
 BACKEND_SRCS = ["ggml_mi355x.cpp"]
 
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
             "-Wall", "-Wno-unused-function", "-Wno-unused-variable", f"-I{ROOT / 'include'}", f"-I{CSRC / 'kernels'}"]
+# mmq.hip: hipcc SLP-packs the fix-up's independent fma chains into v_pk_fma_f32, which costs more than the two scalar operations in the
+# gaps between MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+EXTRA_FLAGS = {"mmq.hip": ["-fno-slp-vectorize"]}
 if os.environ.get("MI355X_KTIME_BUILD") == "1":      # kernel-anatomy stamps (GGML_MI355X_KTIME=1 at run time, scripts/kbench.py)
     HIPFLAGS.append("-DMI355X_KTIME")
 
@@ -49,14 +52,14 @@ def _stale(out: Path, deps):
 def build_kernels(verbose=False):
     LIB.mkdir(exist_ok=True)
     (BUILD / "kernels").mkdir(parents=True, exist_ok=True)
-    hdrs = [CSRC / "kernels" / "common.h", CSRC / "kernels" / "decode_common.h", ROOT / "include" / "mi355x_kernels.h"]
+    hdrs = [CSRC / "kernels" / "common.h", CSRC / "kernels" / "decode_common.h", CSRC / "kernels" / "qrows.h", ROOT / "include" / "mi355x_kernels.h"]
     objs, jobs = [], []
     for s in KERNEL_SRCS:
         src = CSRC / "kernels" / s
         obj = BUILD / "kernels" / (s + ".o")
         objs.append(obj)
         if _stale(obj, [src] + hdrs):
-            jobs.append([HIPCC, *HIPFLAGS, "-c", str(src), "-o", str(obj)])
+            jobs.append([HIPCC, *HIPFLAGS, *EXTRA_FLAGS.get(s, []), "-c", str(src), "-o", str(obj)])
     with ThreadPoolExecutor(max_workers=8) as ex:
         for out in ex.map(_run, jobs):
             if verbose and out.strip():

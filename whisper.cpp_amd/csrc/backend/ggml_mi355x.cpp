@@ -684,6 +684,15 @@ static bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c
 }
 
 static int mode_for(ggml_type t) { return t == GGML_TYPE_Q4_K ? 2 : (is_quant_type(t) ? 1 : 0); }
+// The int8 tile GEMM over the quantized operands (csrc/kernels/mmq.hip) takes every product of a quantized weight with more than 8
+// columns whose K it can tile: its activations are the reference's Q8_0 / Q8_K blocks as integers ("rows", prep modes 3 / 4) and its
+// A operand the planar quantized weight itself — no f16 copy of a weight is made or read.  GGML_MI355X_MMQ=0 brings back the f16 MFMA
+// path (f16(d*q) activations, f16 weight copies).
+static bool mi_mmq_on() { static const bool on = env_flag("GGML_MI355X_MMQ", true); return on; }
+static int rows_mode_for(const ggml_tensor * w, int64_t K) {
+    if (!mi_mmq_on() || !is_quant_type(w->type) || K % 128 != 0) return 0;
+    return w->type == GGML_TYPE_Q4_K ? (K % 256 == 0 ? 4 : 0) : 3;
+}
 
 // f16 copy of a quantized weight for the MFMA path (nullptr: not eligible / over budget -> the GEMM dequantizes in its loop)
 static const void * mi_shadow_get(mi_backend_ctx * b, const ggml_tensor * w, const mi355x_tensor & mw) {
@@ -735,7 +744,8 @@ static bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, 
     if (!((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && w->nb[0] == 2 && w->nb[1] % 16 == 0))) return false;
     const int mode = mode_for(w->type);
     if ((mode == 1 && K % 32) || (mode == 2 && K % 256)) return false;
-    mode_out = mode;
+    const int rmode = rows_mode_for(w, K);
+    mode_out = rmode ? rmode : mode;
     return true;
 }
 
@@ -773,6 +783,41 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
         (x->type == GGML_TYPE_F32 || x->type == GGML_TYPE_F16) &&
         ((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && w->nb[0] == 2 && w->nb[1] % 16 == 0))) {
         const int mode = mode_for(w->type);
+        const int rmode = rows_mode_for(w, K);
+        if (rmode && ggml_is_contiguous(w)) {
+            // the int8 tile GEMM on the quantized weight and the activation rows
+            const int rr = mi_act_reserve(b, (size_t) T * K * 2);          // (rows need 1.25 bytes per element: the f16 size covers them)
+            if (rr != 0) return rr;
+            if (!(b->act_src == x->data && b->act_K == K && b->act_T == T && b->act_mode == rmode && b->act_nb1 == (int64_t) x->nb[1])) {
+                const int rc = mi355x_prep_act(b->k, x->data, (int64_t) x->nb[1], x->type == GGML_TYPE_F16, b->act, (int) K, T, rmode);
+                if (rc && rc != MI355X_E_UNSUPPORTED) return rc;
+                if (rc == 0) { b->act_src = x->data; b->act_K = K; b->act_T = T; b->act_mode = rmode; b->act_nb1 = (int64_t) x->nb[1]; }
+                else b->act_src = nullptr;
+            }
+            if (b->act_src == x->data && b->act_mode == rmode) {
+                // fc1 + GELU -> fc2: the epilogue writes the next product's rows (second scratch), and the F32 result only if somebody reads it
+                static const bool prep_out_on = env_flag("GGML_MI355X_GEMM_PREP_OUT", true);
+                const int64_t M = mm->ne[0];
+                int rc = MI355X_E_UNSUPPORTED;
+                if (g && b->fuse && prep_out_on && c.last->type == GGML_TYPE_F32 && M % 128 == 0 && M <= 8192 &&
+                    c.last->nb[0] == 4 && (int64_t) c.last->nb[1] == M*4 && c.last->ne[1] == T && c.last->ne[2] == 1 && c.last->ne[3] == 1) {
+                    const int j = next_real(g, c.end);
+                    int mode2 = -1;
+                    if (j < g->n_nodes && mm_takes_prepared(b, g->nodes[j], c.last, mode2) && mode2 == 3 && mi_act_reserve(b, (size_t) T * M * 2, true) == 0) {
+                        const bool only = can_elide(g, c.last, 1);
+                        rc = mi355x_gemm_q8act_prep(b->k, &mw, b->act, T, only ? nullptr : md.data, md.nb[1], has_ep ? &c.ep : nullptr, b->act_alt);
+                        if (rc == 0) {
+                            std::swap(b->act, b->act_alt); std::swap(b->act_size, b->act_alt_size);
+                            b->act_src = c.last->data; b->act_K = M; b->act_T = T; b->act_mode = 3; b->act_nb1 = M*4;
+                            return 0;
+                        }
+                        if (rc != MI355X_E_UNSUPPORTED) return rc;
+                    }
+                }
+                rc = mi355x_gemm_q8act(b->k, &mw, b->act, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
+                if (rc != MI355X_E_UNSUPPORTED) return rc;
+            }
+        }
         if (!((mode == 1 && K % 32) || (mode == 2 && K % 256))) {
             const void * act; int64_t ld;
             if (x->type == GGML_TYPE_F16 && mode == 0) { act = x->data; ld = (int64_t) x->nb[1] / 2; }
@@ -1545,12 +1590,13 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
             if (on && j < g->n_nodes && g->nodes[j]->op == GGML_OP_MUL_MAT) {
                 const ggml_tensor * x = g->nodes[j]->src[1];
                 if (x->data == n->data && x->ne[0] == NS && x->ne[1] == T && (int64_t) x->nb[1] == NS*4 && ggml_is_contiguous(n) &&
-                    mm_takes_prepared(b, g->nodes[j], x, mode) && mode == 1 && mi_act_reserve(b, (size_t) T * NS * 2) == 0) {
+                    mm_takes_prepared(b, g->nodes[j], x, mode) && (mode == 1 || mode == 3) && mi_act_reserve(b, (size_t) T * NS * 2) == 0) {
                     mi355x_tensor q = to_mt(n->src[0]), kk = to_mt(n->src[1]), v = to_mt(n->src[2]), d = to_mt(n), m;
                     if (n->src[3]) m = to_mt(n->src[3]);
                     float scale; memcpy(&scale, n->op_params, 4);
-                    rc = mi355x_flash_attn_ext_prep(b->k, &q, &kk, &v, n->src[3] ? &m : nullptr, &d, scale, b->act);
-                    if (rc == 0) { b->act_src = x->data; b->act_K = NS; b->act_T = T; b->act_mode = 1; b->act_nb1 = NS*4; }
+                    rc = mode == 3 ? mi355x_flash_attn_ext_prep_rows(b->k, &q, &kk, &v, n->src[3] ? &m : nullptr, &d, scale, b->act)
+                                   : mi355x_flash_attn_ext_prep(b->k, &q, &kk, &v, n->src[3] ? &m : nullptr, &d, scale, b->act);
+                    if (rc == 0) { b->act_src = x->data; b->act_K = NS; b->act_T = T; b->act_mode = mode; b->act_nb1 = NS*4; }
                 }
             }
             if (rc == MI355X_E_UNSUPPORTED) { rc = run_node(b, n); b->act_src = nullptr; }

@@ -2,6 +2,7 @@
 // get_rows, im2col(1-D), soft_max, rope, concat.  All HBM/L2-bound: coalesced 16-byte accesses on the
 // contiguous fast paths, wave64 reductions, no LDS except block reductions.
 #include "common.h"
+#include "qrows.h"
 #include <math.h>
 
 // -------------------------------------------------------------------------------------------------
@@ -141,7 +142,7 @@ extern "C" int mi355x_pad_reflect_1d(mi355x_ctx * ctx, const mi355x_tensor * x, 
 // norm (+ optional affine): one wave per row (ggml-cpu/ops.cpp:3698-3765)
 //   mean = sum/n ; var = sum((x-mean)^2)/n ; y = (x-mean) * (1/sqrtf(var+eps)) [* w + b as separate roundings]
 // -------------------------------------------------------------------------------------------------
-struct NormArgs { dtensor x, y; float eps; const float * w; const float * b; int64_t nrows; uint16_t * prep; int prep_mode; };
+struct NormArgs { dtensor x, y; float eps; const float * w; const float * b; int64_t nrows; uint16_t * prep; int prep_mode; int8_t * rq; float * rd; int * rs; };
 __global__ void __launch_bounds__(256) k_norm(const NormArgs a) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t) blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -210,7 +211,43 @@ __global__ void __launch_bounds__(256) k_norm_v4(const NormArgs a) {
         if (a.w) { const float4 w = wr[i]; r[0] = r[0]*w.x; r[1] = r[1]*w.y; r[2] = r[2]*w.z; r[3] = r[3]*w.w; }
         if (a.b) { const float4 b = br[i]; r[0] = r[0]+b.x; r[1] = r[1]+b.y; r[2] = r[2]+b.z; r[3] = r[3]+b.w; }
         if (e4 < n4) *(float4 *) (y + (size_t) e4*4) = make_float4(r[0], r[1], r[2], r[3]);
-        if (a.prep) {
+        if (a.rq) {
+            // the activation ROWS of the int8 tile GEMM that consumes this LayerNorm (qrows.h; k_prep_act modes 3 / 4, statement for
+            // statement): a Q8_0 block (32 elements) is 8 neighbouring lanes of this iteration, a Q8_K block (256) the whole wave
+            uint32_t packed;
+            if (a.prep_mode == MI355X_PREP_Q8_0_ROWS) {
+                float amax = fmaxf(fmaxf(fabsf(r[0]), fabsf(r[1])), fmaxf(fabsf(r[2]), fabsf(r[3])));
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+                const float d  = amax / 127.0f;
+                const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+                const int q0 = (int) rintf(r[0]*id), q1 = (int) rintf(r[1]*id), q2 = (int) rintf(r[2]*id), q3 = (int) rintf(r[3]*id);
+                packed = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+                if (e4 < n4 && (e4 & 7) == 0) a.rd[row * (n >> 5) + (e4 >> 3)] = round_f16(d);
+            } else {
+                float mx = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
+                float mn = fminf(fminf(r[0], r[1]), fminf(r[2], r[3]));
+                #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+                const float amax = fmaxf(mx, -mn);
+                const float maxv = (mx >= -mn) ? mx : mn;
+                int q[4] = { 0, 0, 0, 0 };
+                float d = 0.0f;
+                if (amax != 0.0f) {
+                    const float iscale = -127.0f / maxv;
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) { const int qi = (int) rintf(iscale * r[j]); q[j] = qi < 127 ? qi : 127; }
+                    d = 1.0f / iscale;
+                }
+                int sm = q[0] + q[1] + q[2] + q[3];
+                sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+                packed = (uint32_t) (q[0] & 0xFF) | ((uint32_t) (q[1] & 0xFF) << 8) | ((uint32_t) (q[2] & 0xFF) << 16) | ((uint32_t) (q[3] & 0xFF) << 24);
+                if (e4 < n4 && (e4 & 7) == 0)  a.rs[row * (n >> 5) + (e4 >> 3)] = sm;
+                if (e4 < n4 && (e4 & 63) == 0) a.rd[row * (n >> 8) + (e4 >> 6)] = d;
+            }
+            if (e4 < n4) *(uint32_t *) (a.rq + row * n + (size_t) e4*4) = packed;
+        } else if (a.prep) {
             // the activation preparation of the MFMA GEMM that consumes this LayerNorm (k_prep_act, gemm_mfma.hip), on the values
             // just stored: same operations in the same order, so the f16 matrix is bit-identical to a separate pass over y.
             // A Q8_0 block (32 elements) is 8 neighbouring lanes of this iteration, a Q8_K block (256) the whole wave.
@@ -253,9 +290,11 @@ extern "C" int mi355x_norm_prep(mi355x_ctx * ctx, const mi355x_tensor * x, const
                                 void * prep, int mode) {
     const int64_t K = x->ne[0];
     if (x->type != MI355X_TYPE_F32 || y->type != MI355X_TYPE_F32 || x->nb[0] != 4 || y->nb[0] != 4 || !t_same_shape(x, y)) return MI355X_E_UNSUPPORTED;
-    if (!prep || mode < 0 || mode > 2 || x->ne[2] != 1 || x->ne[3] != 1 || K % 4 || K > 2048 || (mode == 1 && K % 32) || (mode == 2 && K % 256)) return MI355X_E_UNSUPPORTED;
+    if (!prep || mode < 0 || mode > 4 || x->ne[2] != 1 || x->ne[3] != 1 || K % 4 || K > 2048 || (mode == 1 && K % 32) || (mode == 2 && K % 256)) return MI355X_E_UNSUPPORTED;
+    if (mode >= 3 && (K % 128 || (mode == 4 && K % 256))) return MI355X_E_UNSUPPORTED;
     if (((uintptr_t) x->data | (uintptr_t) y->data | (uintptr_t) w | (uintptr_t) b | (uintptr_t) prep) % 16 || (x->nb[1] | y->nb[1]) % 16) return MI355X_E_UNSUPPORTED;
-    NormArgs k = { to_d(x), to_d(y), eps, w, b, t_nrows(x), (uint16_t *) prep, mode };
+    NormArgs k = { to_d(x), to_d(y), eps, w, b, t_nrows(x), (uint16_t *) prep, mode, nullptr, nullptr, nullptr };
+    if (mode >= 3) { const qrows_t R = qrows_of(prep, mode == 4, K, k.nrows); k.rq = R.q; k.rd = R.d; k.rs = R.bsum; k.prep = nullptr; }
     if (k.nrows == 0 || K == 0) return 0;
     return emit(ctx, "norm_prep", k_norm_v4, dim3((uint32_t) ((k.nrows + 3) / 4)), dim3(256), 0, k, (double) t_nelements(x) * 10, 0);
 }

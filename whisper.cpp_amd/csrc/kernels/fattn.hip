@@ -11,6 +11,7 @@
 //                  MFMA is applied identically to V^T), and the O rescale is a per-lane scalar multiply.
 //   T <= 8 (decoder step) goes to k_fattn_dec in decode.hip (128-key partial records, merged by the consumer).
 #include "common.h"
+#include "qrows.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -21,6 +22,7 @@ struct FattnArgs {
     int has_mask; float scale;
     int T, n_kv, H, rk2, rv2;
     uint16_t * prep; int prep_ld;      // also write k_prep_act(mode 1) of the result seen as [T][H*64]: the O-projection's activations
+    int8_t * rq; float * rd;           // ... or its Q8_0 ROWS (k_prep_act mode 3, qrows.h): the int8 tile GEMM's activations
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -272,7 +274,28 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
                 *(float4 *) (dp + d0) = make_float4(o[i][4*g]*inv, o[i][4*g+1]*inv, o[i][4*g+2]*inv, o[i][4*g+3]*inv);
             }
     }
-    if (a.prep) {
+    if (a.rq) {
+        // Q8_0 rows of the result seen as [T][H*64] (quantize_row_q8_0, arch/x86/quants.c:302-398): a block = 32 consecutive dims of one
+        // head = the 16 registers o[i][*] of this lane and of lane^32 (same query)
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            float v[16], amax = 0.0f;
+            #pragma unroll
+            for (int r = 0; r < 16; r++) { v[r] = o[i][r]*inv; amax = fmaxf(amax, fabsf(v[r])); }
+            amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+            const float d  = amax / 127.0f;
+            const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+            if (q_ok) {
+                int8_t * pp = a.rq + (int64_t) qi*a.prep_ld + hq*FA_D;
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int q0 = (int) rintf(v[4*g]*id), q1 = (int) rintf(v[4*g+1]*id), q2 = (int) rintf(v[4*g+2]*id), q3 = (int) rintf(v[4*g+3]*id);
+                    *(uint32_t *) (pp + 32*i + 8*g + 4*hf) = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+                }
+                if (hf == 0) a.rd[(int64_t) qi*(a.prep_ld >> 5) + hq*2 + i] = round_f16(d);
+            }
+        }
+    } else if (a.prep) {
         // The result, seen as [T][H*64], is the activation matrix of the output projection (src/whisper.cpp:2165-2167 -> :2199-2203):
         // leave what k_prep_act (mode 1) would make of it.  A Q8_0 block = 32 consecutive dims of one head = the 16 registers
         // o[i][*] of this lane and of lane^32 (same query).
@@ -315,6 +338,13 @@ extern "C" int mi355x_flash_attn_ext_prep(mi355x_ctx * ctx, const mi355x_tensor 
     return flash_attn_impl(ctx, q, k, v, mask, dst, scale, prep_out);
 }
 
+extern "C" int mi355x_flash_attn_ext_prep_rows(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
+                                               const mi355x_tensor * mask, const mi355x_tensor * dst, float scale, void * rows_out) {
+    if (!rows_out || ((uintptr_t) rows_out % 16) || q->ne[1] <= 8 || k->ne[1] == 0 || (q->ne[2] * FA_D) % 128) return MI355X_E_UNSUPPORTED;
+    if (dst->nb[1] != FA_D*4 || dst->nb[2] != dst->ne[1]*FA_D*4) return MI355X_E_UNSUPPORTED;
+    return flash_attn_impl(ctx, q, k, v, mask, dst, scale, (void *) ((uintptr_t) rows_out | 1));      // bit 0: rows, not f16 (pointers are 16-byte aligned)
+}
+
 static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi355x_tensor * k, const mi355x_tensor * v,
                            const mi355x_tensor * mask, const mi355x_tensor * dst, float scale, void * prep_out) {
     if (q->type != MI355X_TYPE_F32 || k->type != MI355X_TYPE_F16 || v->type != MI355X_TYPE_F16 || dst->type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
@@ -335,7 +365,11 @@ static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi35
     if (mask) a.m = to_d(mask);
     a.has_mask = mask != nullptr; a.scale = scale; a.T = T; a.n_kv = n_kv; a.H = H;
     a.rk2 = (int) (H / k->ne[2]); a.rv2 = (int) (H / v->ne[2]);
-    a.prep = (uint16_t *) prep_out; a.prep_ld = H * FA_D;
+    a.prep_ld = H * FA_D;
+    if ((uintptr_t) prep_out & 1) {
+        const qrows_t R = qrows_of((void *) ((uintptr_t) prep_out & ~(uintptr_t) 1), 0, (int64_t) H * FA_D, T);
+        a.rq = R.q; a.rd = R.d;
+    } else a.prep = (uint16_t *) prep_out;
     const double kv_bytes = 2.0 * n_kv * FA_D * 2 * H;
     const double flops = 4.0 * T * (double) n_kv * FA_D * H;
     if (n_kv == 0) return mi355x_memset(ctx, dst->data, 0, (size_t) dst->nb[3]*dst->ne[3]);

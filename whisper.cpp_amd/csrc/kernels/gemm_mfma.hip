@@ -16,6 +16,7 @@
 //  * Global loads for K-step k+1 are issued before the MFMAs of step k (register-staged prefetch), LDS tiles
 //    are conflict-free for ds_read_b128 via slot ^= (row>>1)&7.
 #include "common.h"
+#include "qrows.h"
 #include <atomic>
 
 // -------------------------------------------------------------------------------------------------
@@ -23,7 +24,8 @@
 //   mode 0: plain f16 rounding (F16/F32 weights: vec_dot_type F16, ggml-cpu/ggml-cpu.c:214-412)
 //   mode 1: Q8_0 round trip     mode 2: Q8_K round trip
 // -------------------------------------------------------------------------------------------------
-struct PrepArgs { const char * x; int64_t x_nb1; uint16_t * y; int K; int64_t T; int mode; int x_f16; };
+//   mode 3 / 4: the Q8_0 / Q8_K blocks themselves (int8 + scales: the activation ROWS of the int8 tile GEMM, qrows.h / mmq.hip)
+struct PrepArgs { const char * x; int64_t x_nb1; uint16_t * y; int K; int64_t T; int mode; int x_f16; int8_t * rq; float * rd; int * rs; };
 
 __global__ void __launch_bounds__(256) k_prep_act(const PrepArgs a) {
     const int64_t t = blockIdx.y;
@@ -38,6 +40,42 @@ __global__ void __launch_bounds__(256) k_prep_act(const PrepArgs a) {
         v[0] = x4.x; v[1] = x4.y; v[2] = x4.z; v[3] = x4.w;
     }
     float r[4];
+    if (a.mode == MI355X_PREP_Q8_0_ROWS) {
+        // quantize_row_q8_0 (arch/x86/quants.c:302-398): the statements of dg_q8_0_store (decode_common.h); 8 lanes = one block
+        float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        const float d  = amax / 127.0f;
+        const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+        const int q0 = (int) rintf(v[0]*id), q1 = (int) rintf(v[1]*id), q2 = (int) rintf(v[2]*id), q3 = (int) rintf(v[3]*id);
+        *(uint32_t *) (a.rq + t*a.K + e) = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+        if ((e & 31) == 0) a.rd[t*(a.K >> 5) + (e >> 5)] = round_f16(d);
+        return;
+    }
+    if (a.mode == MI355X_PREP_Q8_K_ROWS) {
+        // quantize_row_q8_K (ggml-quants.c:2768-2805): the statements of dg_q8_K_store; the wave = one 256-element super-block
+        float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        float mn = fminf(fminf(v[0], v[1]), fminf(v[2], v[3]));
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); mn = fminf(mn, __shfl_xor(mn, o, 64)); }
+        const float amax = fmaxf(mx, -mn);
+        const float maxv = (mx >= -mn) ? mx : mn;
+        int q[4] = { 0, 0, 0, 0 };
+        float d = 0.0f;
+        if (amax != 0.0f) {
+            const float iscale = -127.0f / maxv;
+            #pragma unroll
+            for (int i = 0; i < 4; i++) { const int qi = (int) rintf(iscale * v[i]); q[i] = qi < 127 ? qi : 127; }
+            d = 1.0f / iscale;
+        }
+        int s = q[0] + q[1] + q[2] + q[3];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        *(uint32_t *) (a.rq + t*a.K + e) = (uint32_t) (q[0] & 0xFF) | ((uint32_t) (q[1] & 0xFF) << 8) | ((uint32_t) (q[2] & 0xFF) << 16) | ((uint32_t) (q[3] & 0xFF) << 24);
+        if ((e & 31) == 0)  a.rs[t*(a.K >> 5) + (e >> 5)] = s;
+        if ((e & 255) == 0) a.rd[t*(a.K >> 8) + (e >> 8)] = d;
+        return;
+    }
     if (a.mode == 0) {
         #pragma unroll
         for (int i = 0; i < 4; i++) r[i] = v[i];
@@ -76,8 +114,10 @@ __global__ void __launch_bounds__(256) k_prep_act(const PrepArgs a) {
 
 extern "C" int mi355x_prep_act(mi355x_ctx * ctx, const void * x, int64_t x_nb1, int x_f16, void * yv, int K, int64_t T, int mode) {
     uint16_t * y = (uint16_t *) yv;
-    if (K % 4 || (mode == 1 && K % 32) || (mode == 2 && K % 256) || T > 65535*64LL) return MI355X_E_UNSUPPORTED;
-    PrepArgs k = { (const char *) x, x_nb1, y, K, T, mode, x_f16 };
+    if (mode < 0 || mode > 4 || K % 4 || (mode == 1 && K % 32) || (mode == 2 && K % 256) || T > 65535*64LL) return MI355X_E_UNSUPPORTED;
+    if (mode >= 3 && (K % 128 || (mode == 4 && K % 256) || ((uintptr_t) yv % 16) || T > 65535)) return MI355X_E_UNSUPPORTED;
+    PrepArgs k = { (const char *) x, x_nb1, y, K, T, mode, x_f16, nullptr, nullptr, nullptr };
+    if (mode >= 3) { const qrows_t R = qrows_of(yv, mode == 4, K, T); k.rq = R.q; k.rd = R.d; k.rs = R.bsum; }
     // blockIdx.y limited to 65535: loop in chunks
     int rc = 0;
     for (int64_t t0 = 0; t0 < T && rc == 0; t0 += 65535) {

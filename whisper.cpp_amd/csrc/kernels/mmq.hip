@@ -1,0 +1,526 @@
+// Tile GEMM over the QUANTIZED operands: the reference's integer block dots on the CDNA4 matrix cores.
+//
+//   dst[m, t] = sum over 32-element blocks b of  dw[m,b] * dx[t,b] * ( sum_k qw[m,b,k] * qx[t,b,k] )
+//
+// The CPU path rounds src1 to the weight type's vec_dot_type and accumulates integer block dots with an f32 scale per block for EVERY
+// column count (ggml-cpu/ggml-cpu.c:1322-1357; vec_dot q4_0 / q5_0 / q8_0 x q8_0: ggml-cpu/quants.c:225-259, :365-406, :451-479;
+// q4_K x q8_K: :696-769).  The f16 MFMA path of gemm_mfma.hip approximates that with f16(d*q) products; here the integers themselves
+// go through v_mfma_i32_32x32x32_i8 — K = 32 per instruction is exactly one quantization block — and every block's 32 x 32 tile of
+// integer sums is folded into the f32 accumulators with acc = fma(float(sum), dw*dx, acc), the statement of the decoder mat-vecs
+// (decode.hip).  What reaches dst are the CPU's own integer sums; only the f32 summation order over blocks differs (here: ascending
+// block index; AVX2: eight partial lanes; oracle_mul_mat is matched to <= 1e-10 NMSE, tests/test_gpu_mmq.py).
+//
+//  * A = weights, read from HBM in the block-quantized planar layout (0.56 - 1.06 B/weight, mi355x_kernels.h) and unpacked PER
+//    WORKGROUP to signed int8 on their way into an XOR-swizzled LDS tile — no f16 or int8 copy of any weight exists in HBM.
+//  * B = activations already quantized to Q8_0 / Q8_K rows (qrows.h) by whatever produced them (LayerNorm, attention, the previous
+//    GEMM's epilogue, or mi355x_prep_act); the tile copy is a straight 16-byte move.
+//  * 256 threads = 4 waves in a 2 x 2 arrangement, wave tile (BMT/2) x (BNT/2), K-step = 128 elements (4 blocks), two LDS stages, ONE
+//    barrier per K-step; the global loads of step k+1 are in flight while step k is computed.
+//  * The fix-up is VALU work (16 cvt + 16 fma per 32 x 32 x 32 MFMA).  The 32 x 32 tile of scale products dw[m]*dx[t] — 16 different
+//    weight rows per lane — comes from the matrix cores as well: one v_mfma_f32_32x32x16_f16 whose A operand holds dw (f16, exact) in
+//    K-slot 0 and whose B operand holds dx (an f16 value by construction of Q8_0) in K-slot 0, zeros elsewhere: a rank-1 product,
+//    exact in f32.  Without it every lane would need 16 broadcast LDS reads and 16 multiplies per MFMA (SMF = false: the form Q4_K
+//    uses, whose Q8_K activation scale is not an f16 value).
+//  * Q4_K: unsigned nibbles in the A tile; per 32-element sub-block acc += float(sum) * (d*sc_j)[m] * d8[t] - (dmin*m_j)[m] * (d8*bsum_j)[t]
+//    (the reference sums sc_j*sum_j in integers first; the difference is f32 rounding).
+//  * XCD-aware tile order as in k_gemm_f16_ring (gemm_mfma.hip).
+#include "common.h"
+#include "qrows.h"
+#include <atomic>
+
+typedef int i32x4_t  __attribute__((ext_vector_type(4)));
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+
+struct MmqArgs {
+    const char * A; int64_t nbt;                                // planar quantized weights [K, M]; nbt = total blocks
+    const int8_t * Bq; const float * Bd; const int * Bs;       // activation rows of x [K, T] (qrows.h)
+    int M, K; int64_t T;
+    char * dst; int64_t dst_nb1; int dst_f16;
+    const float * bias; float scale; int has_scale; int gelu; int bias_t;
+    const char * residual; int64_t res_nb1;
+    const uint16_t * gelu_tab;
+    int8_t * pq; float * pd; int prep_only;                    // epilogue also leaves the Q8_0 rows of the result (K' = M): the next GEMM's B
+    int mt, nt, per, m_major;                                  // tile counts and XCD-aware tile order
+};
+
+#define MQ_KS 128                      // K elements per step = bytes per tile row
+__device__ __forceinline__ int mq_off(int row, int slot) { return row*128 + ((slot ^ ((row >> 1) & 7)) << 4); }   // 16-byte slot of a [rows][128 B] tile
+
+// ---- registers of one thread's share of the next A tile: PA (row, block) pairs of one row -------------------------------------------
+template <int WT, int PA> struct mq_aregs;
+template <int PA> struct mq_aregs<MI355X_TYPE_Q4_0, PA> { uint4 q[PA]; uint16_t d[PA]; };
+template <int PA> struct mq_aregs<MI355X_TYPE_Q5_0, PA> { uint4 q[PA]; uint32_t qh[PA]; uint16_t d[PA]; };
+template <int PA> struct mq_aregs<MI355X_TYPE_Q8_0, PA> { uint4 q0[PA], q1[PA]; uint16_t d[PA]; };
+// Q4_K: the thread's PA sub-blocks lie in ONE 64-element chunk (PA = 2: both nibbles of its 32 bytes; PA = 1: one of them)
+template <int PA> struct mq_aregs<MI355X_TYPE_Q4_K, PA> { uint4 q0, q1; uint32_t dm; uint32_t sc[3]; };
+
+// signed bytes from 5-bit values x = nib | bit << 4 (ggml-quants.c:500-524: w = x - 16): spread the four INVERTED high bits to byte
+// masks, then OR 0xF0 into the bytes whose value is negative (x - 16 = 0xF0 | nib there, nib elsewhere)
+__device__ __forceinline__ uint32_t q5_signed(uint32_t nib, uint32_t inv4) {
+    const uint32_t t = ((inv4 & 0xFu) * 0x00204081u) & 0x01010101u;        // bit k -> bit 0 of byte k
+    const uint32_t m = __builtin_amdgcn_perm(0u, 0u, t | 0x0C0C0C0Cu);     // v_perm_b32 selector 0x0C -> 0x00, 0x0D -> 0xFF: a byte mask without a multiply
+    return nib | (m & 0xF0F0F0F0u);
+}
+// signed bytes from nibbles (ggml-quants.c:459-477: w = nib - 8): sign extension of (nib ^ 8) from bit 3, four bytes at once:
+// ((y | 0x80) - 8) ^ 0x80 never borrows across bytes
+__device__ __forceinline__ uint32_t q4_signed(uint32_t nib) { return ((nib ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u; }
+
+template <int WT, int PA>
+__device__ __forceinline__ void mq_a_load(mq_aregs<WT, PA> & r, const MmqArgs & a, int row, int blk /* first 32-block of this thread, global index along K */) {
+    if constexpr (WT == MI355X_TYPE_Q4_K) {
+        const qplanes<MI355X_TYPE_Q4_K> p(a.A, a.nbt);
+        const int64_t sb = (int64_t) row * (a.K >> 8) + (blk >> 3);
+        const uint8_t * qs = p.qs + sb*128 + ((blk & 7) >> 1)*32;
+        r.q0 = *(const uint4 *) qs; r.q1 = *(const uint4 *) (qs + 16);
+        r.dm = p.dm[sb];
+        const uint32_t * sc = (const uint32_t *) (p.sc + sb*12);
+        r.sc[0] = sc[0]; r.sc[1] = sc[1]; r.sc[2] = sc[2];
+    } else {
+        const qplanes<WT> p(a.A, a.nbt);
+        const int64_t ib = (int64_t) row * (a.K >> 5) + blk;
+        #pragma unroll
+        for (int i = 0; i < PA; i++) {
+            if constexpr (WT == MI355X_TYPE_Q8_0) {
+                r.q0[i] = *(const uint4 *) (p.qs + (ib + i)*32);
+                r.q1[i] = *(const uint4 *) (p.qs + (ib + i)*32 + 16);
+            } else {
+                r.q[i] = *(const uint4 *) (p.qs + (ib + i)*16);
+                if constexpr (WT == MI355X_TYPE_Q5_0) r.qh[i] = p.qh[ib + i];
+            }
+            r.d[i] = p.d[ib + i];
+        }
+    }
+}
+
+// unpack to int8 and store: tile rows of 128 bytes, block lb (0..3) of the K-step = slots 2*lb (elements 0..15), 2*lb + 1 (16..31);
+// per-block f32 scales sA[lb][row] (Q4_K: d*sc_j, and mA[lb][row] = -(dmin*m_j))
+template <int WT, int PA, int BMT, bool SMF>
+__device__ __forceinline__ void mq_a_store(const mq_aregs<WT, PA> & r, char * At, float * sA, float * mA, int row, int lb0, int blk) {
+    if constexpr (WT == MI355X_TYPE_Q4_K) {
+        const float d = h2f((uint16_t) (r.dm & 0xFFFF)), dmin = h2f((uint16_t) (r.dm >> 16));
+        const uint32_t w[8] = { r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w };
+        #pragma unroll
+        for (int i = 0; i < PA; i++) {
+            const int j = (blk + i) & 7;                                   // sub-block of the super-block; nibble j & 1 of its chunk
+            const int sh = (j & 1) * 4;
+            uint32_t o[8];
+            #pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (w[e] >> sh) & 0x0F0F0F0Fu;
+            *(uint4 *) (At + mq_off(row, 2*(lb0 + i)))     = make_uint4(o[0], o[1], o[2], o[3]);
+            *(uint4 *) (At + mq_off(row, 2*(lb0 + i) + 1)) = make_uint4(o[4], o[5], o[6], o[7]);
+            int sc, m; q4k_scale_min_w(j, r.sc[0], r.sc[1], r.sc[2], sc, m);
+            sA[(lb0 + i)*BMT + row] = d * (float) sc;                      // exact: 11-bit x 6-bit
+            mA[(lb0 + i)*BMT + row] = -(dmin * (float) m);
+        }
+    } else {
+        #pragma unroll
+        for (int i = 0; i < PA; i++) {
+            uint4 lo, hi;
+            if constexpr (WT == MI355X_TYPE_Q8_0) { lo = r.q0[i]; hi = r.q1[i]; }
+            else {
+                const uint32_t w[4] = { r.q[i].x, r.q[i].y, r.q[i].z, r.q[i].w };
+                uint32_t l[4], h[4];
+                if constexpr (WT == MI355X_TYPE_Q5_0) {
+                    const uint32_t inv = ~r.qh[i];
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        l[e] = q5_signed(w[e] & 0x0F0F0F0Fu,        inv >> (4*e));
+                        h[e] = q5_signed((w[e] >> 4) & 0x0F0F0F0Fu, inv >> (16 + 4*e));
+                    }
+                } else {
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) { l[e] = q4_signed(w[e] & 0x0F0F0F0Fu); h[e] = q4_signed((w[e] >> 4) & 0x0F0F0F0Fu); }
+                }
+                lo = make_uint4(l[0], l[1], l[2], l[3]); hi = make_uint4(h[0], h[1], h[2], h[3]);
+            }
+            *(uint4 *) (At + mq_off(row, 2*(lb0 + i)))     = lo;
+            *(uint4 *) (At + mq_off(row, 2*(lb0 + i) + 1)) = hi;
+            if constexpr (SMF) ((uint32_t *) sA)[(lb0 + i)*BMT + row] = (uint32_t) r.d[i];      // the f16 itself: K-slot 0 of the rank-1 scale MFMA
+            else sA[(lb0 + i)*BMT + row] = h2f(r.d[i]);
+        }
+    }
+}
+
+// ---- epilogue: bias / scale / GELU / residual, F32 or F16 store, optional Q8_0 rows of the result ---------------------------------
+// C layout of the 32 x 32 MFMAs (any dtype): lane holds column t = lane & 31, rows (r & 3) + 8*(r >> 2) + 4*(lane >> 5)
+template <int MT, int NT>
+__device__ __forceinline__ void mq_epilogue(const MmqArgs & a, floatx16 (&acc)[MT][NT], int mw /* first row of the wave */, int64_t nw /* first column */, int lane) {
+    const bool vec_ok = (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) &&
+                        (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || a.bias_t || ((uintptr_t) a.bias % 16 == 0));
+    const int hf = lane >> 5;
+    #pragma unroll
+    for (int i = 0; i < MT; i++) {
+        #pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int64_t t = nw + j*32 + (lane & 31);
+            const int mb = mw + i*32;
+            if (t >= a.T || mb >= a.M) continue;                        // the same for both lanes of a (lane, lane ^ 32) pair
+            float v[16];
+            float amax = 0.0f;
+            #pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int m = mb + 8*g + 4*hf;
+                float x[4] = { acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3] };
+                if (vec_ok && m < a.M) {                                // m % 4 == 0 and M % 4 == 0  =>  m + 3 < M
+                    if (a.bias) {
+                        if (a.bias_t) { const float b = a.bias[t]; x[0] += b; x[1] += b; x[2] += b; x[3] += b; }
+                        else { const float4 b = *(const float4 *) (a.bias + m); x[0] += b.x; x[1] += b.y; x[2] += b.z; x[3] += b.w; }
+                    }
+                    if (a.has_scale) { x[0] *= a.scale; x[1] *= a.scale; x[2] *= a.scale; x[3] *= a.scale; }
+                    if (a.gelu) { x[0] = gelu_lut(x[0], a.gelu_tab); x[1] = gelu_lut(x[1], a.gelu_tab); x[2] = gelu_lut(x[2], a.gelu_tab); x[3] = gelu_lut(x[3], a.gelu_tab); }
+                    if (a.residual) { const float4 r4 = *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4); x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w; }
+                    if (!a.prep_only) {
+                        if (a.dst_f16) *(uint2 *) (a.dst + t*a.dst_nb1 + (int64_t) m*2) = make_uint2((uint32_t) f2h(x[0]) | ((uint32_t) f2h(x[1]) << 16), (uint32_t) f2h(x[2]) | ((uint32_t) f2h(x[3]) << 16));
+                        else           *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(x[0], x[1], x[2], x[3]);
+                    }
+                } else {
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        if (m + e >= a.M) { x[e] = 0.0f; continue; }
+                        if (a.bias) x[e] += a.bias[a.bias_t ? t : (int64_t) (m + e)];
+                        if (a.has_scale) x[e] *= a.scale;
+                        if (a.gelu) x[e] = gelu_lut(x[e], a.gelu_tab);
+                        if (a.residual) x[e] += *(const float *) (a.residual + t*a.res_nb1 + (int64_t) (m + e)*4);
+                        if (!a.prep_only) {
+                            if (a.dst_f16) *(uint16_t *) (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*2) = f2h(x[e]);
+                            else           *(float *)    (a.dst + t*a.dst_nb1 + (int64_t) (m + e)*4) = x[e];
+                        }
+                    }
+                }
+                #pragma unroll
+                for (int e = 0; e < 4; e++) { v[4*g + e] = x[e]; amax = fmaxf(amax, fabsf(x[e])); }
+            }
+            if (a.pq) {
+                // The result is the activation matrix of the NEXT quantized GEMM (fc1 + GELU -> fc2, src/whisper.cpp:2224-2238): leave its
+                // Q8_0 rows (quantize_row_q8_0, arch/x86/quants.c:302-398) straight from the accumulators.  A block = 32 consecutive
+                // features of one token = the 16 registers of this lane and of lane ^ 32.  (host: M % 32 == 0)
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const float d  = amax / 127.0f;
+                const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int m = mb + 8*g + 4*hf;
+                    const int q0 = (int) rintf(v[4*g]*id), q1 = (int) rintf(v[4*g+1]*id), q2 = (int) rintf(v[4*g+2]*id), q3 = (int) rintf(v[4*g+3]*id);
+                    *(uint32_t *) (a.pq + t*a.M + m) = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+                }
+                if (hf == 0) a.pd[t*(a.M >> 5) + (mb >> 5)] = round_f16(d);
+            }
+        }
+    }
+}
+
+// ---- the kernel --------------------------------------------------------------------------------------------------------------------
+// SMF: the tile of scale products dw[m]*dx[t] comes from a rank-1 f16 MFMA (Q4_0 / Q5_0 / Q8_0 only)
+template <int WT, int BMT, int BNT, bool SMF>
+__device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char * lds) {
+    constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
+    static_assert(!(Q4K && SMF), "Q8_K scales are not f16 values");
+    constexpr int MT = BMT / 64, NT = BNT / 64;               // 32 x 32 tiles per wave
+    constexpr int PA = BMT * 4 / 256;                         // (row, block) pairs of A per thread and K-step: 2 or 1
+    constexpr int TPR = 4 / PA;                               // threads per A row
+    constexpr int CB = BNT / 32;                              // 16-byte chunks of B per thread and K-step
+    constexpr int TPB = 8 / CB;                               // threads per B row
+    static_assert(PA == 1 || PA == 2, "BMT is 64 or 128");
+    // one stage: A tile | B tile | sA[4][BMT] | mA[4][BMT] (Q4_K) | sB[4][BNT] | dB[BNT] (Q4_K)
+    constexpr int OFF_B  = BMT * 128;
+    constexpr int OFF_SA = OFF_B + BNT * 128;
+    constexpr int OFF_MA = OFF_SA + 4 * BMT * 4;
+    constexpr int OFF_SB = OFF_MA + (Q4K ? 4 * BMT * 4 : 0);
+    constexpr int OFF_DB = OFF_SB + 4 * BNT * 4;
+    constexpr int OFF_Z  = OFF_DB + (Q4K ? BNT * 4 : 0);     // SMF: one zero word — what lanes 32..63 (K-slots 8..15 of the scale MFMA) read
+    constexpr int STAGE  = OFF_Z + 16;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mi = a.m_major ? tile / a.nt : tile % a.mt;
+    const int ni = a.m_major ? tile % a.nt : tile / a.mt;
+    const int m0 = mi * BMT;
+    const int64_t n0 = (int64_t) ni * BNT;
+    const int nk = a.K / MQ_KS;
+    const int nb = a.K >> 5;
+
+    // staging assignments (rows past the matrix edge are clamped: their results are never stored)
+    const int arow = tid / TPR, alb0 = (tid % TPR) * PA;
+    const int arow_g = m0 + arow < a.M ? m0 + arow : a.M - 1;
+    const int brow = tid / TPB, bslot0 = (tid % TPB) * CB;
+    const int64_t brow_g = n0 + brow < a.T ? n0 + brow : a.T - 1;
+    const int8_t * bq = a.Bq + brow_g * a.K + bslot0 * 16;
+    // scales of B: thread (brow, first block) owns CB/2 blocks' worth of a row's slots
+    constexpr int SBN = CB / 2;                               // blocks per thread
+    const int sblk0 = bslot0 >> 1;
+
+    mq_aregs<WT, PA> ar;
+    uint4 br0, br1, br2 = make_uint4(0, 0, 0, 0), br3 = make_uint4(0, 0, 0, 0);      // (named registers: an array indexed inside the lambdas stays in private memory)
+    float bsc0 = 0.0f, bsc1 = 0.0f; float bd8 = 0.0f; int bsm0 = 0, bsm1 = 0;
+    static_assert(CB == 2 || CB == 4, "B staging is written for 64- and 128-column tiles");
+
+    auto load_tile = [&](int kt) {
+        mq_a_load<WT, PA>(ar, a, arow_g, kt*4 + alb0);
+        const uint4 * bp = (const uint4 *) (bq + (int64_t) kt*MQ_KS);
+        br0 = bp[0]; br1 = bp[1];
+        if constexpr (CB == 4) { br2 = bp[2]; br3 = bp[3]; }
+        if constexpr (Q4K) {
+            bd8 = a.Bd[brow_g * (a.K >> 8) + (kt >> 1)];
+            bsm0 = a.Bs[brow_g * nb + kt*4 + sblk0];
+            if constexpr (SBN == 2) bsm1 = a.Bs[brow_g * nb + kt*4 + sblk0 + 1];
+        } else {
+            bsc0 = a.Bd[brow_g * nb + kt*4 + sblk0];
+            if constexpr (SBN == 2) bsc1 = a.Bd[brow_g * nb + kt*4 + sblk0 + 1];
+        }
+    };
+    auto store_tile = [&](int kt, char * st) {
+        mq_a_store<WT, PA, BMT, SMF>(ar, st, (float *) (st + OFF_SA), (float *) (st + OFF_MA), arow, alb0, kt*4 + alb0);
+        *(uint4 *) (st + OFF_B + mq_off(brow, bslot0))     = br0;
+        *(uint4 *) (st + OFF_B + mq_off(brow, bslot0 + 1)) = br1;
+        if constexpr (CB == 4) {
+            *(uint4 *) (st + OFF_B + mq_off(brow, bslot0 + 2)) = br2;
+            *(uint4 *) (st + OFF_B + mq_off(brow, bslot0 + 3)) = br3;
+        }
+        float * sB = (float *) (st + OFF_SB);
+        if constexpr (Q4K) {
+            sB[sblk0*BNT + brow] = bd8 * (float) bsm0;
+            if constexpr (SBN == 2) sB[(sblk0 + 1)*BNT + brow] = bd8 * (float) bsm1;
+            if (bslot0 == 0) ((float *) (st + OFF_DB))[brow] = bd8;
+        } else if constexpr (SMF) {
+            ((uint32_t *) sB)[sblk0*BNT + brow] = (uint32_t) f2h(bsc0);                        // exact: a Q8_0 scale is an f16 value
+            if constexpr (SBN == 2) ((uint32_t *) sB)[(sblk0 + 1)*BNT + brow] = (uint32_t) f2h(bsc1);
+        } else {
+            sB[sblk0*BNT + brow] = bsc0;
+            if constexpr (SBN == 2) sB[(sblk0 + 1)*BNT + brow] = bsc1;
+        }
+    };
+
+    floatx16 acc[MT][NT];
+    #pragma unroll
+    for (int i = 0; i < MT; i++)
+        #pragma unroll
+        for (int j = 0; j < NT; j++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    if (tid < 8) ((uint32_t *) (lds + (tid >> 2) * STAGE + OFF_Z))[tid & 3] = 0u;
+    load_tile(0);
+    store_tile(0, lds);
+    __syncthreads();
+
+    const int l31 = lane & 31, hf = lane >> 5;
+    const i32x16_t zi = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    const floatx16 zf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+
+    // Compute schedule of one K-step.  Left alone, hipcc issues all 32 MFMAs of a step first, sinks the (memory-free) cvt / fma chains of
+    // ALL tile-blocks below the last of them and keeps 16 result sets (512 registers) alive; sched_barrier alone only pins what the IR
+    // passes left.  So the order is carried as DATA dependencies by empty asm statements ("+v" operands) and then pinned:
+    //   issue(n + 1)  — the MFMA pair of the next tile-block; its asm also names tile-block n's results, whose fold can therefore not
+    //                   start before these MFMAs are in the pipe
+    //   fold(n)       — 16 cvt + 16 fma in their shadow; ends with the accumulator tile named, so it cannot sink below the next issue
+    // Two result sets in flight (64 registers).  A block's fragments and scale operands are requested from LDS right after the LAST
+    // issue of the previous block (its two remaining folds cover the latency) into the SAME registers: nothing is double-buffered.
+    // The scale operands are 4-register tuples of which only dword 0 is ever written; their zeros come from an asm (opaque to constant
+    // propagation) so that the tuples stay loop-carried registers instead of being re-assembled with three v_mov per use.
+    struct frags { i32x4_t af[MT], bf[NT]; i32x4_t as[SMF ? MT : 1], bs[SMF ? NT : 1]; float sa[SMF ? 1 : MT][SMF ? 1 : 16], ma[Q4K ? MT : 1][Q4K ? 16 : 1], dxn[SMF ? 1 : NT], vbn[Q4K ? NT : 1]; };
+    frags f;
+    if constexpr (SMF) {
+        int z0; asm volatile("v_mov_b32 %0, 0" : "=v"(z0));
+        #pragma unroll
+        for (int i = 0; i < MT; i++) f.as[i] = i32x4_t{ z0, z0, z0, z0 };
+        #pragma unroll
+        for (int j = 0; j < NT; j++) f.bs[j] = i32x4_t{ z0, z0, z0, z0 };
+    }
+    auto read_frags = [&](const char * st, int b) {
+        const char * At = st, * Bt = st + OFF_B;
+        const float * sA = (const float *) (st + OFF_SA), * mA = (const float *) (st + OFF_MA), * sB = (const float *) (st + OFF_SB);
+        #pragma unroll
+        for (int i = 0; i < MT; i++) f.af[i] = *(const i32x4_t *) (At + mq_off(wm*(MT*32) + i*32 + l31, 2*b + hf));
+        #pragma unroll
+        for (int j = 0; j < NT; j++) f.bf[j] = *(const i32x4_t *) (Bt + mq_off(wn*(NT*32) + j*32 + l31, 2*b + hf));
+        if constexpr (SMF) {
+            // rank-1 scale tiles: K-slot 0 of the A / B operand = element 0 of lanes 0..31; lanes 32..63 read the stage's zero word
+            #pragma unroll
+            for (int i = 0; i < MT; i++) f.as[i][0] = *(const int *) (st + (hf == 0 ? OFF_SA + (b*BMT + wm*(MT*32) + i*32 + l31)*4 : OFF_Z));
+            #pragma unroll
+            for (int j = 0; j < NT; j++) f.bs[j][0] = *(const int *) (st + (hf == 0 ? OFF_SB + (b*BNT + wn*(NT*32) + j*32 + l31)*4 : OFF_Z));
+        } else {
+            // scales of this lane's 16 rows per tile: four float4 broadcast reads (rows 8g + 4*hf .. + 3); its column's scale is a scalar
+            #pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int c = wn*(NT*32) + j*32 + l31;
+                if constexpr (Q4K) { f.dxn[j] = ((const float *) (st + OFF_DB))[c]; f.vbn[j] = sB[b*BNT + c]; }
+                else f.dxn[j] = sB[b*BNT + c];
+            }
+            #pragma unroll
+            for (int i = 0; i < MT; i++)
+                #pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int row = wm*(MT*32) + i*32 + 8*g + 4*hf;
+                    const float4 s4 = *(const float4 *) (sA + b*BMT + row);
+                    f.sa[i][4*g] = s4.x; f.sa[i][4*g+1] = s4.y; f.sa[i][4*g+2] = s4.z; f.sa[i][4*g+3] = s4.w;
+                    if constexpr (Q4K) { const float4 m4 = *(const float4 *) (mA + b*BMT + row); f.ma[i][4*g] = m4.x; f.ma[i][4*g+1] = m4.y; f.ma[i][4*g+2] = m4.z; f.ma[i][4*g+3] = m4.w; }
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // tile-block n of a block = (i, j) = (n % MT, n / MT)
+    constexpr int NTB = MT * NT;
+    static_assert(NTB == 2 || NTB == 4, "2 or 4 tile-blocks per wave and block");
+    auto issue = [&](int n, i32x16_t & S, floatx16 & SC, i32x16_t & Sp, floatx16 & SCp, bool tie) {
+        const int i = n % MT, j = n / MT;
+        S = __builtin_amdgcn_mfma_i32_32x32x32_i8(f.af[i], f.bf[j], zi, 0, 0, 0);
+        if constexpr (SMF) {
+            SC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, f.as[i]), __builtin_bit_cast(half8_t, f.bs[j]), zf, 0, 0, 0);
+            if (tie) asm volatile("" : "+v"(S), "+v"(SC), "+v"(Sp), "+v"(SCp));
+            else     asm volatile("" : "+v"(S), "+v"(SC));
+        } else {
+            if (tie) asm volatile("" : "+v"(S), "+v"(Sp));
+            else     asm volatile("" : "+v"(S));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // scale operands of the VALU form are copied out before the next block's reads overwrite them
+    auto fold = [&](int n, const i32x16_t & S, const floatx16 & SC) {
+        const int i = n % MT, j = n / MT;
+        #pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if constexpr (SMF) acc[i][j][r] = fmaf((float) S[r], SC[r], acc[i][j][r]);
+            else {
+                acc[i][j][r] = fmaf((float) S[r], f.sa[i][r] * f.dxn[j], acc[i][j][r]);
+                if constexpr (Q4K) acc[i][j][r] = fmaf(f.ma[i][r], f.vbn[j], acc[i][j][r]);
+            }
+        }
+        asm volatile("" : "+v"(acc[i][j]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one block; nb_ >= 0: the next block's fragments are requested as soon as this block's last MFMAs are issued (SMF), or — the VALU
+    // form still needs this block's scale registers in its folds — after its last fold
+    auto block = [&](const char * st, int nb_) {
+        i32x16_t S0, S1; floatx16 SC0 = zf, SC1 = zf;
+        issue(0, S0, SC0, S1, SC1, false);
+        issue(1, S1, SC1, S0, SC0, true);
+        if constexpr (NTB == 4) {
+            fold(0, S0, SC0);
+            issue(2, S0, SC0, S1, SC1, true);
+            fold(1, S1, SC1);
+            issue(3, S1, SC1, S0, SC0, true);
+            if constexpr (SMF) { if (nb_ >= 0) read_frags(st, nb_); }
+            fold(2, S0, SC0);
+            fold(3, S1, SC1);
+        } else {
+            if constexpr (SMF) { if (nb_ >= 0) read_frags(st, nb_); }
+            fold(0, S0, SC0);
+            fold(1, S1, SC1);
+        }
+        if constexpr (!SMF) { if (nb_ >= 0) read_frags(st, nb_); }
+    };
+
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char * st = lds + (kt & 1) * STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(st, 0);
+        block(st, 1);
+        block(st, 2);
+        block(st, 3);
+        block(st, -1);
+        if (kt + 1 < nk) store_tile(kt + 1, lds + ((kt + 1) & 1) * STAGE);
+        __syncthreads();
+    }
+    mq_epilogue<MT, NT>(a, acc, m0 + wm*(MT*32), n0 + wn*(NT*32), lane);
+}
+
+template <int WT, int BMT, int BNT, bool SMF>
+__global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char mq_lds[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = xcd * a.per + idx;
+    if (tile >= a.mt * a.nt) return;                  // padding blocks of the last XCD range (uniform exit, before any barrier)
+    mmq_tile<WT, BMT, BNT, SMF>(a, tile, mq_lds);
+}
+
+template <int WT, int BMT, int BNT>
+static constexpr uint32_t mmq_lds_bytes() {
+    constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
+    return 2u * (uint32_t) ((BMT + BNT) * 128 + 4 * BMT * 4 * (Q4K ? 2 : 1) + 4 * BNT * 4 + (Q4K ? BNT * 4 : 0) + 16);
+}
+
+template <int WT, int BMT, int BNT, bool SMF>
+static int launch_mmq(mi355x_ctx * ctx, const MmqArgs & k0, double bytes, double flops) {
+    constexpr uint32_t lds = mmq_lds_bytes<WT, BMT, BNT>();
+    MmqArgs k = k0;
+    k.mt = (k.M + BMT - 1) / BMT; k.nt = (int) ((k.T + BNT - 1) / BNT);
+    const int64_t ntiles = (int64_t) k.mt * k.nt;
+    k.per = (int) ((ntiles + 7) / 8);
+    // bytes each XCD pulls through its L2 for its `per` consecutive tiles, column-major vs row-major tile order (gemm_mfma.hip: ring_tiling)
+    const double a_tile = (double) BMT * k.K * 0.7, b_tile = (double) BNT * k.K * 1.125;
+    const double col_major = a_tile * (k.per < k.mt ? k.per : k.mt) + b_tile * ((k.per + k.mt - 1) / k.mt + (k.per % k.mt ? 1 : 0));
+    const double row_major = b_tile * (k.per < k.nt ? k.per : k.nt) + a_tile * ((k.per + k.nt - 1) / k.nt + (k.per % k.nt ? 1 : 0));
+    k.m_major = row_major < col_major ? 1 : 0;
+    static std::atomic<bool> attr_set[64];
+    const int dev = ctx->device & 63;
+    if (lds > 64 * 1024 && !attr_set[dev].load()) {
+        if (hipFuncSetAttribute((const void *) k_mmq<WT, BMT, BNT, SMF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
+        attr_set[dev].store(true);
+    }
+    return emit(ctx, "mmq", k_mmq<WT, BMT, BNT, SMF>, dim3((uint32_t) (8 * k.per)), dim3(256), lds, k, bytes, flops);
+}
+
+// tile shape: 128 x 128 when that still gives every CU a workgroup, else 64 x 128 (the A unpack is amortised over the tile's columns,
+// so narrow-M / wide-N is the cheaper way to more tiles); GGML_MI355X_MMQ_TILE=128128 | 64128 | 12864 forces one
+template <int WT, bool SMF>
+static int launch_mmq_shape(mi355x_ctx * ctx, const MmqArgs & k, double bytes, double flops) {
+    if constexpr (!SMF) return launch_mmq<WT, 64, 128, false>(ctx, k, bytes, flops);       // (16 + 16 scale registers per tile: only the small tile fits 256 registers)
+    else {
+        const int force = getenv("GGML_MI355X_MMQ_TILE") ? atoi(getenv("GGML_MI355X_MMQ_TILE")) : 0;
+        const int64_t t128 = (int64_t) ((k.M + 127) / 128) * ((k.T + 127) / 128);
+        if (force == 12864) return launch_mmq<WT, 128, 64, true>(ctx, k, bytes, flops);
+        // (Q8_0: its A tile is a plain copy — nothing to amortise over a wider tile — and its 18 prefetch registers do not fit beside 128 x 128)
+        if (force == 64128 || (force == 0 && t128 < ctx->n_cu) || WT == MI355X_TYPE_Q8_0) return launch_mmq<WT, 64, 128, true>(ctx, k, bytes, flops);
+        if constexpr (WT != MI355X_TYPE_Q8_0) return launch_mmq<WT, 128, 128, true>(ctx, k, bytes, flops);
+        return MI355X_E_UNSUPPORTED;
+    }
+}
+
+// mi355x_gemm_q8act (mi355x_kernels.h): w planar quantized [K, M]; act = activation rows of x [K, T]
+static int gemm_q8act_impl(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act, int64_t T, void * dst, int64_t dst_nb1, int dst_type,
+                           const mi355x_epilogue * ep, void * prep_out, int prep_only) {
+    if (dst_type != MI355X_TYPE_F32 && dst_type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
+    const int K = (int) A->ne[0], M = (int) A->ne[1];
+    const int wt = A->type;
+    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;
+    if (!t_is_contiguous(A) || A->ne[2] != 1 || A->ne[3] != 1 || M <= 0 || T <= 0 || K <= 0 || K % MQ_KS || (wt == MI355X_TYPE_Q4_K && K % 256)) return MI355X_E_UNSUPPORTED;
+    if (((uintptr_t) A->data % 16) || ((uintptr_t) act % 16) || !dst) return MI355X_E_UNSUPPORTED;
+    const bool q8k = wt == MI355X_TYPE_Q4_K;
+    const qrows_t B = qrows_of((void *) act, q8k, K, T);
+    MmqArgs k; memset(&k, 0, sizeof(k));
+    k.A = (const char *) A->data; k.nbt = (int64_t) M * (K / type_block(wt));
+    k.Bq = B.q; k.Bd = B.d; k.Bs = B.bsum; k.M = M; k.K = K; k.T = T;
+    k.dst = (char *) dst; k.dst_nb1 = dst_nb1; k.dst_f16 = dst_type == MI355X_TYPE_F16; k.gelu_tab = ctx->gelu_tab;
+    if (ep) { k.bias_t = ep->bias && ep->bias_per_col; k.bias = ep->bias; k.scale = ep->scale; k.has_scale = ep->has_scale; k.gelu = ep->gelu; k.residual = (const char *) ep->residual; k.res_nb1 = ep->residual_nb1; }
+    if (prep_out) {
+        if (M % MQ_KS || ((uintptr_t) prep_out % 16)) return MI355X_E_UNSUPPORTED;
+        const qrows_t P = qrows_of(prep_out, 0, M, T);
+        k.pq = P.q; k.pd = P.d; k.prep_only = prep_only;
+    }
+    const double flops = 2.0 * M * (double) K * (double) T;
+    const double bytes = (double) mi355x_type_row_bytes(wt, K) * M + (double) qrows_bytes(q8k, K, T) + (prep_only ? 0.0 : (double) T*M*(k.dst_f16 ? 2 : 4)) + (prep_out ? (double) qrows_bytes(0, M, T) : 0.0);
+    // GGML_MI355X_MMQ_SCALE_MFMA=0: scale products on the VALU from broadcast LDS reads (the Q4_K form) instead of the rank-1 MFMA
+    const bool smf = !(getenv("GGML_MI355X_MMQ_SCALE_MFMA") && !atoi(getenv("GGML_MI355X_MMQ_SCALE_MFMA")));
+    switch (wt) {
+        case MI355X_TYPE_Q4_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q4_0, true>(ctx, k, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q4_0, false>(ctx, k, bytes, flops);
+        case MI355X_TYPE_Q5_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q5_0, true>(ctx, k, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q5_0, false>(ctx, k, bytes, flops);
+        case MI355X_TYPE_Q8_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q8_0, true>(ctx, k, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q8_0, false>(ctx, k, bytes, flops);
+        default:               return launch_mmq_shape<MI355X_TYPE_Q4_K, false>(ctx, k, bytes, flops);
+    }
+}
+
+extern "C" size_t mi355x_act_rows_bytes(int wtype, int64_t K, int64_t T) { return (qrows_bytes(wtype == MI355X_TYPE_Q4_K, K, T) + 15) & ~(size_t) 15; }
+
+extern "C" int mi355x_gemm_q8act(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act_rows, int64_t T, void * dst, int64_t dst_nb1, int dst_type,
+                                 const mi355x_epilogue * ep) {
+    return gemm_q8act_impl(ctx, A, act_rows, T, dst, dst_nb1, dst_type, ep, nullptr, 0);
+}
+
+extern "C" int mi355x_gemm_q8act_prep(mi355x_ctx * ctx, const mi355x_tensor * A, const void * act_rows, int64_t T, void * dst, int64_t dst_nb1,
+                                      const mi355x_epilogue * ep, void * prep_rows_out) {
+    if (!prep_rows_out) return MI355X_E_UNSUPPORTED;
+    if (dst && (((uintptr_t) dst % 16) || (dst_nb1 % 16))) return MI355X_E_UNSUPPORTED;
+    return gemm_q8act_impl(ctx, A, act_rows, T, dst ? dst : prep_rows_out, dst ? dst_nb1 : A->ne[1]*4, MI355X_TYPE_F32, ep, prep_rows_out, dst ? 0 : 1);
+}

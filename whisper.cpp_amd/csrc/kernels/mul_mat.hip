@@ -1,6 +1,7 @@
 // ggml_mul_mat dispatch (ggml/src/ggml.c:3278; CPU ggml-cpu/ggml-cpu.c:1254-1452):
 //   T <= 8 columns            -> k_gemv   (gemv.hip, int8 dot, HBM-bound)
-//   2-D, T > 8                -> k_prep_act + k_gemm_mfma (gemm_mfma.hip, MFMA-bound)
+//   2-D, T > 8, quantized     -> k_prep_act (rows) + k_mmq (mmq.hip: int8 MFMA over the quantized operands)
+//   2-D, T > 8, F16 / F32     -> k_prep_act + k_gemm_mfma / k_gemm_f16_ring (gemm_mfma.hip, f16 MFMA)
 //   batched / strided / F32 A -> k_mul_mat_generic below (one wave per output element; only reached by the
 //                                -nfa attention path and by f32 models, never by the default whisper graphs)
 #include "common.h"
@@ -98,6 +99,16 @@ extern "C" int mi355x_mul_mat(mi355x_ctx * ctx, const mi355x_tensor * w, const m
         ((x->type == MI355X_TYPE_F32 && x->nb[0] == 4 && x->nb[1] % 16 == 0) || (x->type == MI355X_TYPE_F16 && x->nb[0] == 2 && x->nb[1] % 16 == 0)) &&
         ((uintptr_t) x->data % 16 == 0)) {
         const int mode = w->type == MI355X_TYPE_Q4_K ? 2 : (wq ? 1 : 0);
+        // quantized weight, K in whole 128-element steps: the int8 tile GEMM on the reference's own Q8_0 / Q8_K integers (mmq.hip)
+        static const bool mmq_on = !(getenv("GGML_MI355X_MMQ") && !atoi(getenv("GGML_MI355X_MMQ")));
+        if (mmq_on && wq && t_is_contiguous(w) && K % 128 == 0 && (mode != 2 || K % 256 == 0) && T <= 65535) {
+            mi355x_scratch_reset(ctx);
+            void * rows = mi355x_scratch_alloc(ctx, mi355x_act_rows_bytes(w->type, K, T));
+            if (!rows) return (int) hipErrorOutOfMemory;
+            int rc = mi355x_prep_act(ctx, x->data, x->nb[1], x->type == MI355X_TYPE_F16, rows, (int) K, T, mode == 2 ? 4 : 3);
+            if (rc == 0) rc = mi355x_gemm_q8act(ctx, w, rows, T, dst->data, dst->nb[1], dst->type, ep);
+            if (rc != MI355X_E_UNSUPPORTED) return rc;
+        }
         if (!(mode == 1 && K % 32) && !(mode == 2 && K % 256)) {
             const uint16_t * B; int64_t ldb;
             if (x->type == MI355X_TYPE_F16 && mode == 0) { B = (const uint16_t *) x->data; ldb = x->nb[1] / 2; }
