@@ -75,12 +75,15 @@ GGML_MI355X_API int  ggml_backend_mi355x_trace(uint64_t * out16);
 /* Cross-state batching: whisper_states of one device whose next graph is a single-token decoder step are
  * executed as the COLUMNS of one launch chain — every weight byte is read once for all of them instead of once per state — by whichever
  * of their host threads completes the set (up to 8 columns; a state alone runs the ordinary path; a state whose next graph is anything
- * else leaves the group at once).  Per state the results are bit-identical to running alone.  Off by default: GGML_MI355X_BATCH=1 or
- * ggml_backend_mi355x_set_batching(1) at any time.  With fewer than 5 decoding states (GGML_MI355X_BATCH_MIN_STREAMS) every state still
- * runs its own chain — measured faster on one MI355X up to 4 states; an argument n >= 2 (or GGML_MI355X_BATCH=n) merges from n states on.
+ * else leaves the group at once).  Per state the results are bit-identical to running alone.  ON by default since round 4 (a
+ * whisper_full_parallel user with 8 states otherwise gets the own-chain collapse): GGML_MI355X_BATCH=0 or
+ * ggml_backend_mi355x_set_batching(0) switch it off at any time; ggml_backend_mi355x_get_batching returns the current setting.  With
+ * fewer than 5 decoding states (GGML_MI355X_BATCH_MIN_STREAMS) every state still runs its own chain — measured faster on one MI355X up
+ * to 4 states; an argument n >= 2 (or GGML_MI355X_BATCH=n) merges from n states on.
  * ggml_backend_mi355x_batch_stats: out[0..4] = merged chains, columns carried, steps
  * run alone, groups that fell back to one chain per state, windows that closed on an absent state. */
 GGML_MI355X_API void ggml_backend_mi355x_set_batching(int on);
+GGML_MI355X_API int  ggml_backend_mi355x_get_batching(void);
 /* Device-side greedy sampling: most probable token of logits row `row` (-1: last) of the decoder step the CALLING
  * THREAD issued last, reduced in HBM (16 bytes come back); *top1 = its logit, *margin = distance to the runner-up.  -1: no such step.
  * For hosts with their own decoding loop above whisper_decode (include/mi355x_host.h greedy mode); whisper_full's sampler is untouched. */

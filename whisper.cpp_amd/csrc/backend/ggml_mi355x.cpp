@@ -491,6 +491,7 @@ struct mi_backend_ctx {
     hipEvent_t  own_ev = nullptr;
     hipEvent_t  batch_wait_sync = nullptr, batch_wait_stream = nullptr;   // completion of the last batch this state was a column of: synchronize() / the own stream still have to wait for it
     int         no_batch_nodes = 0;                             // graph size (n_nodes) that was found not to fit the batch walker
+    uint64_t    sig_nodes = 0; const void * sig_w = nullptr;    // graph shape of THIS state that was last checked congruent with its group's (mi_compute_batch)
     // host-visible mirror of the logits: the vocabulary projection stores its result a second time into pinned, device-mapped host memory,
     // so whisper's read-back of the row(s) (ggml_backend_tensor_get, src/whisper.cpp:2957-2963) is a memcpy instead of a device-to-host copy
     char *      mirror_host = nullptr; char * mirror_dev = nullptr;
@@ -1690,7 +1691,7 @@ static ggml_status mi_compute_own(mi_backend_ctx * b, ggml_cgraph * cgraph) {
 
 // ---------------------------------------------------------------------------------------------------
 // cross-state batches: the rendezvous.  Every whisper_state has its own ggml_backend_t (own host thread, own HIP stream: src/
-// whisper.cpp:7848-7869).  When batching is on (GGML_MI355X_BATCH=1 / ggml_backend_mi355x_set_batching), a backend whose graph is a
+// whisper.cpp:7848-7869).  When batching is on (the default; GGML_MI355X_BATCH=0 / ggml_backend_mi355x_set_batching(0) switch it off), a backend whose graph is a
 // single-token decoder step does not launch it: it joins its device's group, and once every backend that is currently decoding has
 // arrived (or the window closes) ONE of the waiting threads launches the merged chain on the group's stream (mi_walk_batch) — up to
 // MI355X_MAX_COLS states as the columns of one pass over the weights.  A state that stops decoding (its next graph is an encoder,
@@ -1711,13 +1712,16 @@ struct mi_batch_group {
     int         lane_cols[MI_BATCH_LANES] = {};      // columns of the chain each busy lane is launching
     std::mutex  sig_m;
     uint64_t    sig_nodes = 0; const void * sig_w = nullptr;   // graph shape the dry walk + congruence check last accepted (sig_m)
-    uint64_t    n_batches = 0, n_columns = 0, n_solo = 0, n_fallback = 0, n_timeouts = 0;
+    uint64_t    n_batches = 0, n_columns = 0, n_solo = 0, n_timeouts = 0;
+    std::atomic<uint64_t> n_fallback{0};                 // (updated outside the group lock)
 };
 static mi_batch_group     g_batch[MI_MAX_DEVICES];
 static std::atomic<int>   g_batching{-1};            // -1: not decided yet (environment), 0 off, 1 on (from mi_batch_min_states() states), n >= 2: on from n states
 static bool mi_batching_on() {
     int v = g_batching.load();
-    if (v < 0) { const char * e = getenv("GGML_MI355X_BATCH"); v = e ? std::max(0, atoi(e)) : 0; g_batching.store(v); }
+    // on by default (r04): fewer than mi_batch_min_states() decoding states keep their own chains anyway, and beyond four states own
+    // chains collapse (8 states: 1.8 chunks/s against 9.4 merged) — a whisper_full_parallel user must not have to know a switch
+    if (v < 0) { const char * e = getenv("GGML_MI355X_BATCH"); v = e ? std::max(0, atoi(e)) : 1; g_batching.store(v); }
     return v != 0;
 }
 // Fewer decoding states than this run their own chains side by side (states-on-streams) although batching is on: a merged chain costs
@@ -1775,10 +1779,17 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
         for (int c = 1; c < n; c++) same = same && cs.g[c]->n_nodes == g0->n_nodes && cs.g[c]->nodes[g0->n_nodes - 1]->src[0]->data == sw;
         std::lock_guard<std::mutex> sl(grp.sig_m);
         if (!same) ok = false;
-        else if (grp.sig_nodes != sn || grp.sig_w != sw) {
-            for (int c = 1; c < n && ok; c++) ok = mi_graphs_congruent(g0, cs.g[c]);
-            if (ok) ok = mi_walk_batch(nullptr, cs) == 0;
-            if (ok) { grp.sig_nodes = sn; grp.sig_w = sw; }
+        else {
+            // every state is checked ONCE per graph shape — node for node against the chain's first graph — before it may be a column,
+            // not only the states that happened to be in the first batch of that shape
+            bool fresh = grp.sig_nodes != sn || grp.sig_w != sw;
+            for (int c = 0; c < n && ok; c++) {
+                mi_backend_ctx * bc = mem[c]->b;
+                if (bc->sig_nodes == sn && bc->sig_w == sw && !fresh) continue;
+                if (c > 0 || !fresh) ok = mi_graphs_congruent(g0, cs.g[c]);
+            }
+            if (ok && fresh) ok = mi_walk_batch(nullptr, cs) == 0;
+            if (ok) { grp.sig_nodes = sn; grp.sig_w = sw; for (int c = 0; c < n; c++) { mem[c]->b->sig_nodes = sn; mem[c]->b->sig_w = sw; } }
             else for (int c = 0; c < n; c++) mem[c]->b->no_batch_nodes = g0->n_nodes;       // this graph shape never batches: stop joining with it
         }
     }
@@ -1797,14 +1808,32 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
             (void) hipStreamWaitEvent(bs, b->own_ev, 0);
             b->own_dirty = false;
         }
+        // the previous chain this state was a column of may have run on ANOTHER lane: its KV-cache and activation writes must be
+        // ordered in front of this chain by the streams themselves, not by the host synchronize whisper happens to call between steps
+        // (graph_compute is an asynchronous entry point)
+        if (b->batch_wait_stream) (void) hipStreamWaitEvent(bs, b->batch_wait_stream, 0);
     }
     mi_io_order_stream(b0->device, ln.io, bs);                // every member's graph inputs leave with one scatter launch at the head of the chain
     const int rc = mi_walk_batch(ln.k, cs);
+    if (rc != 0) {
+        // a kernel rejected the chain half-way (a shape or alignment only its launch code knows): what was launched has written nothing a
+        // repeat would not write again (activations, this position's KV rows), so every member runs its step again on its own chain
+        // once the partial chain has drained, and this graph shape stops batching
+        GGML_LOG_WARN("ggml-mi355x: cross-state batch rejected mid-chain (rc=%d %s): %d states repeat the step on their own chains\n", rc, mi355x_last_error(), n);
+        (void) mi355x_ctx_synchronize(ln.k);
+        grp.n_fallback++;
+        { std::lock_guard<std::mutex> sl(grp.sig_m); grp.sig_nodes = 0; grp.sig_w = nullptr; }
+        for (int c = 0; c < n; c++) {
+            mem[c]->b->no_batch_nodes = mem[c]->g->n_nodes; mem[c]->b->sig_nodes = 0;
+            mem[c]->status = mi_compute_own(mem[c]->b, mem[c]->g);
+        }
+        return false;
+    }
     hipEvent_t ev = ln.ev_ring[ln.ev_next]; ln.ev_next = (ln.ev_next + 1) % 16;
     (void) hipEventRecord(ev, bs);
     for (int c = 0; c < n; c++) {
         mem[c]->b->batch_wait_sync = ev; mem[c]->b->batch_wait_stream = ev;
-        mem[c]->status = rc == 0 ? GGML_STATUS_SUCCESS : GGML_STATUS_FAILED;
+        mem[c]->status = GGML_STATUS_SUCCESS;
     }
     return true;
 }
@@ -2112,6 +2141,7 @@ int ggml_backend_mi355x_argmax_last(int row, float * top1, float * margin) {
 
 // cross-state batching (mi_batch_group): on = 1 / 0 at run time (the environment's GGML_MI355X_BATCH is only the initial value)
 void ggml_backend_mi355x_set_batching(int on) { g_batching.store(on > 0 ? on : 0); }
+int  ggml_backend_mi355x_get_batching(void) { (void) mi_batching_on(); return g_batching.load(); }
 // out[0..4] of `device`: merged launch chains, columns they carried, steps a state ran alone, groups that fell back to one launch chain
 // per state (graphs did not fit), windows that closed on an absent state
 void ggml_backend_mi355x_batch_stats(int device, uint64_t * out5) {
@@ -2119,7 +2149,7 @@ void ggml_backend_mi355x_batch_stats(int device, uint64_t * out5) {
     if (device < 0 || device >= MI_MAX_DEVICES) return;
     mi_batch_group & grp = g_batch[device];
     std::lock_guard<std::mutex> lk(grp.m);
-    out5[0] = grp.n_batches; out5[1] = grp.n_columns; out5[2] = grp.n_solo; out5[3] = grp.n_fallback; out5[4] = grp.n_timeouts;
+    out5[0] = grp.n_batches; out5[1] = grp.n_columns; out5[2] = grp.n_solo; out5[3] = grp.n_fallback.load(); out5[4] = grp.n_timeouts;
 }
 
 // TEST hook (no device needed: nothing is launched).  S >= 2: would S copies of `cgraph` run as the columns of one launch chain?
@@ -2424,6 +2454,7 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_host_times"))      return (void *) ggml_backend_mi355x_host_times;
     if (!strcmp(name, "ggml_backend_mi355x_trace"))           return (void *) ggml_backend_mi355x_trace;
     if (!strcmp(name, "ggml_backend_mi355x_set_batching"))    return (void *) ggml_backend_mi355x_set_batching;
+    if (!strcmp(name, "ggml_backend_mi355x_get_batching"))    return (void *) ggml_backend_mi355x_get_batching;
     if (!strcmp(name, "ggml_backend_mi355x_argmax_last"))     return (void *) ggml_backend_mi355x_argmax_last;
     if (!strcmp(name, "ggml_backend_mi355x_debug_walk"))      return (void *) ggml_backend_mi355x_debug_walk;
     if (!strcmp(name, "ggml_backend_mi355x_batch_stats"))     return (void *) ggml_backend_mi355x_batch_stats;

@@ -180,8 +180,13 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
     }
     set_batching_fn set_batching = reg ? (set_batching_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_set_batching") : nullptr;
     batch_stats_fn  batch_stats  = reg ? (batch_stats_fn)  ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_batch_stats")  : nullptr;
+    // the switch is process-wide in the plugin: whatever this run sets is put back when it ends (-1: left as it is)
+    typedef int (*get_batching_fn)(void);
+    get_batching_fn get_batching = reg ? (get_batching_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_get_batching") : nullptr;
+    struct batching_restore { set_batching_fn set = nullptr; int old = 0; bool armed = false; ~batching_restore() { if (armed && set) set(old); } } restore;
     if (cfg->batching >= 0 && cfg->use_gpu) {
         if (!set_batching) return fail(2, "plugin has no ggml_backend_mi355x_set_batching");
+        if (get_batching) { restore.set = set_batching; restore.old = get_batching(); restore.armed = true; }
         set_batching(cfg->batching);
     }
     argmax_last_fn argmax_last = reg ? (argmax_last_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_argmax_last") : nullptr;
