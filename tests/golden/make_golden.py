@@ -119,7 +119,27 @@ def mel_npz():
     print("mel.npz:", n_mel, n_len, n_org, "tail", mel[0, -1])
 
 
+def vad_npz():
+    """the reference's only real-weight known-answer test on this path (tests/test-vad.cpp:31,39): the silero VAD graph (src/whisper.cpp:
+    4545-4680) with its TRAINED weights (models/for-tests-silero-v6.2.0-ggml.bin, 885 KB — a data fixture, stored byte for byte because
+    the GPU box has no /root/reference) on samples/jfk.wav: the 344 probabilities and 4 speech segments of the reference CPU path, produced
+    by tests/native/bin/vad_parity (which includes the reference's src/whisper.cpp in place) in its CPU-only mode."""
+    import json
+    ref = Path(os.environ.get("WHISPER_REF", "/root/reference"))
+    model = ref / "models" / "for-tests-silero-v6.2.0-ggml.bin"
+    pcm16 = np.load(HERE / "mel.npz")["pcm16"]
+    with tempfile.TemporaryDirectory() as d:
+        (pcm16.astype(np.float32) / 32768.0).tofile(Path(d) / "pcm.f32")
+        r = subprocess.run([str(HERE.parent / "native" / "bin" / "vad_parity"), str(model), str(Path(d) / "pcm.f32"), "cpu"], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    j = json.loads(r.stdout)["cpu"]
+    assert j["n_probs"] == 344 and len(j["segments"]) == 4, (j["n_probs"], j["segments"])          # the reference test's own assertions
+    np.savez_compressed(HERE / "vad.npz", model=np.frombuffer(model.read_bytes(), dtype=np.uint8), probs=np.array(j["probs"], dtype=np.float32),
+                        segments=np.array(j["segments"], dtype=np.float32))
+    print("vad.npz:", j["n_probs"], "probabilities,", j["segments"])
+
+
 if __name__ == "__main__":
     ops_npz()
     blocks_npz()
     mel_npz()
+    vad_npz()

@@ -1068,7 +1068,8 @@ static bool mi_supports_op_impl(const ggml_tensor * op) {
             const ggml_type wt = s0->type;
             if (!(wt == GGML_TYPE_F32 || wt == GGML_TYPE_F16 || wt == GGML_TYPE_Q4_0 || wt == GGML_TYPE_Q5_0 || wt == GGML_TYPE_Q8_0 || wt == GGML_TYPE_Q4_K)) return false;
             if (s1->type != GGML_TYPE_F32 && s1->type != GGML_TYPE_F16) return false;
-            if (s1->nb[0] != ggml_type_size(s1->type)) return false;
+            // src1 strided along k (a transposed view: the voice-activity LSTM, src/whisper.cpp:4598-4602): the generic kernel only
+            if (s1->nb[0] != ggml_type_size(s1->type)) return !is_quant_type(wt) && s0->nb[0] == ggml_type_size(wt) && s1->nb[0] % ggml_type_size(s1->type) == 0;
             if (is_quant_type(wt)) return whole_quant_ok(s0) && s0->ne[0] % 32 == 0;
             return s0->nb[0] == ggml_type_size(wt);
         }

@@ -24,7 +24,8 @@ __global__ void __launch_bounds__(256) k_mul_mat_generic(const MMGenArgs a) {
     if constexpr (AT == MI355X_TYPE_F32 || AT == MI355X_TYPE_F16) {
         const char * ap = a.a.data + n*a.a.nb[1] + (i2 / a.r2)*a.a.nb[2] + (i3 / a.r3)*a.a.nb[3];
         for (int64_t k = lane; k < K; k += 64) {
-            float x = a.bt == MI355X_TYPE_F32 ? ((const float *) bp)[k] : h2f(((const uint16_t *) bp)[k]);
+            // (x may be strided along k: the voice-activity LSTM feeds a transposed view, src/whisper.cpp:4598-4602)
+            float x = a.bt == MI355X_TYPE_F32 ? *(const float *) (bp + k*a.b.nb[0]) : h2f(*(const uint16_t *) (bp + k*a.b.nb[0]));
             float w;
             if (AT == MI355X_TYPE_F16) { w = h2f(((const uint16_t *) ap)[k]); x = round_f16(x); }
             else w = ((const float *) ap)[k];
@@ -39,7 +40,7 @@ __global__ void __launch_bounds__(256) k_mul_mat_generic(const MMGenArgs a) {
             dequant_block32<AT>(p, rowidx*nb32 + g, w);
             #pragma unroll
             for (int j = 0; j < 32; j++) {
-                const float x = a.bt == MI355X_TYPE_F32 ? ((const float *) bp)[g*32 + j] : h2f(((const uint16_t *) bp)[g*32 + j]);
+                const float x = a.bt == MI355X_TYPE_F32 ? *(const float *) (bp + (g*32 + j)*a.b.nb[0]) : h2f(*(const uint16_t *) (bp + (g*32 + j)*a.b.nb[0]));
                 acc = fmaf(w[j], x, acc);
             }
         }
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256) k_mul_mat_generic(const MMGenArgs a) {
 static int mul_mat_generic(mi355x_ctx * ctx, const mi355x_tensor * w, const mi355x_tensor * x, const mi355x_tensor * dst) {
     if (dst->type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
     if (x->type != MI355X_TYPE_F32 && x->type != MI355X_TYPE_F16) return MI355X_E_UNSUPPORTED;
-    if (x->nb[0] != (x->type == MI355X_TYPE_F32 ? 4 : 2)) return MI355X_E_UNSUPPORTED;
+    if (x->nb[0] <= 0 || x->nb[0] % (x->type == MI355X_TYPE_F32 ? 4 : 2)) return MI355X_E_UNSUPPORTED;
     MMGenArgs k; k.a = to_d(w); k.b = to_d(x); k.d = to_d(dst); k.at = w->type; k.bt = x->type; k.nbt = 0;
     k.nout = t_nelements(dst);
     k.r2 = (int) (x->ne[2] / w->ne[2]); k.r3 = (int) (x->ne[3] / w->ne[3]);
