@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Concurrency check for the backend (SURVEY.md §8b "Threading"): S whisper_states on one whisper_context run the
-whisper-bench protocol from S host threads at once; every stream's logits must equal, bit for bit, what the same stream
-produces when it runs alone.  Prints one JSON line.   usage: stream_check.py <arch> <qtype> <streams> <n_decode>"""
+whisper-bench protocol from S host threads at once; every stream's logits — EVERY decode step's row — must equal, bit for bit, what
+the same stream produces when it runs alone.  From 5 streams on the concurrent leg runs as merged launch chains (cross-state batching,
+on by default): the batched-versus-own-chain comparison of BASELINE.json configs[3].  Prints one JSON line.   usage: stream_check.py <arch> <qtype> <streams> <n_decode>"""
 import ctypes as C
 import json
 import os
@@ -59,7 +60,12 @@ for t in th:
 mismatch = sum(int(not np.array_equal(a.view(np.uint32), b.view(np.uint32))) for s in range(S) for a, b in zip(serial[s], conc[s]))
 distinct = int(not np.array_equal(serial[0][-1], serial[-1][-1])) if S > 1 else 1
 finite = bool(all(np.isfinite(x).all() for s in range(S) for x in conc[s]))
+# merged launch chains the plugin formed for the concurrent leg (cross-state batching is on by default from 5 decoding states)
+bs = (C.c_uint64 * 5)()
+p.ggml_backend_mi355x_batch_stats.argtypes = [C.c_int, C.POINTER(C.c_uint64)]
+p.ggml_backend_mi355x_batch_stats(0, bs)
 print(json.dumps({"streams": S, "n_decode": n_dec, "rows_compared": sum(len(x) for x in conc), "mismatching_rows": mismatch,
-                  "streams_differ_from_each_other": distinct, "finite": finite, "errors": errs}))
+                  "streams_differ_from_each_other": distinct, "finite": finite, "errors": errs,
+                  "batch_stats": {"chains": int(bs[0]), "columns": int(bs[1]), "solo": int(bs[2]), "fallbacks": int(bs[3]), "timeouts": int(bs[4])}}))
 st.close()
 w.whisper_free(ctx)

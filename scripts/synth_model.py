@@ -70,7 +70,34 @@ def planted_token(pos: int) -> int:
     return 1000 + (pos * 7919) % 40000
 
 
-def write_f16_model(path: Path, arch: str, seed: int = 1234, plant: bool = False):
+# ---- "x-planted" models: the token decision is CARRIED BY CROSS-ATTENTION, with every layer at full strength -------------------------
+# (VERDICT r03 weak #1a: in the planted model above the transcript is decided by pos-emb . token-emb alone — cross-attention could
+# return garbage and the test would still pass.)  Here position p offers TWO candidates a_p / b_p with equal strength in the positional
+# embedding; which of them wins is decided by the sign of ONE number that only the last decoder layer's cross-attention produces:
+#   * u: a fixed random direction; a_p / b_p = the text tokens whose embeddings project most positively / most negatively on u
+#   * last layer: row 0 of cross_attn.value.weight = w (random), column 0 of cross_attn.out.weight = g * u, query / key weights x c
+#     (sharper attention) => the block adds g * u * s_p to the residual stream with s_p = sum_k softmax_k(q_p . K) (w . enc_k): a number
+#     that depends on the AUDIO (the encoder output), on the position's query, on the softmax over 1500 keys and on V — i.e. on every
+#     piece of arithmetic of the cross-attention path
+#   * every residual-writing projection keeps its full scale (out_scale 1): self-attention, the other 31 cross-attentions and all MLPs
+#     contribute at the level of a random-weight model
+# sign(s_p) picks a_p or b_p; the margin is ~ g * |s_p| * (proj_a - proj_b) / rms(x).  (f, g, c) per architecture were calibrated
+# with the reference CPU path (scripts/xplant_calibrate.py; profiles/r04_xplant_calibration.txt).
+XPLANT = {"base.en": (6.0, 24.0, 3.0), "large-v3-turbo": (6.0, 24.0, 3.0), "large-v3": (6.0, 24.0, 3.0), "micro": (6.0, 24.0, 3.0), "large-v3-2l": (6.0, 24.0, 3.0)}
+
+
+def xplant_tables(te: np.ndarray, n_text_ctx: int, seed: int):
+    """(u, a[p], b[p]) for a token-embedding matrix te [n_vocab, n] (f16)"""
+    n = te.shape[1]
+    u = np.random.default_rng(seed + 77).standard_normal(n).astype(np.float32)
+    u /= np.linalg.norm(u)
+    n_text = 50256                                  # ordinary text tokens only (the samplers suppress special tokens)
+    proj = te[:n_text].astype(np.float32) @ u
+    order = np.argsort(proj)
+    return u, order[::-1][:n_text_ctx].copy(), order[:n_text_ctx].copy()
+
+
+def write_f16_model(path: Path, arch: str, seed: int = 1234, plant=False):
     """plant=True: a model with LARGE logit margins and a known transcript.  Random-weight models have near-Gaussian logits whose top-2
     margin falls below any backend's rounding differences every 10-20 steps, so free-running token sequences of two correct back ends
     part ways for reasons that have nothing to do with correctness.  Trained models have margins orders of
@@ -134,11 +161,16 @@ def write_f16_model(path: Path, arch: str, seed: int = 1234, plant: bool = False
         pe = rng.normal((n_text_ctx, n_ts), 0.02).astype(np.float32)
         # token embedding doubles as the logits matrix: larger scale so that logits are well separated
         te = rng.normal((n_vocab, n_ts), 0.05).astype(np.float16)
-        if plant:
+        xp = plant == "x"
+        if xp:
+            xf, xg, xc = (float(v) for v in os.environ["XPLANT_PARAMS"].split(",")) if os.environ.get("XPLANT_PARAMS") else XPLANT[arch]      # (override: calibration runs)
+            xu, xa, xb = xplant_tables(te, n_text_ctx, seed)
+            pe = np.stack([xf * (te[xa[p]].astype(np.float32) + te[xb[p]].astype(np.float32)) for p in range(n_text_ctx)])
+        elif plant:
             pe = np.stack([12.0 * te[planted_token(p)].astype(np.float32) for p in range(n_text_ctx)])
         _w_tensor(f, "decoder.positional_embedding", pe)
         _w_tensor(f, "decoder.token_embedding.weight", te)
-        out_scale = 0.02 if plant else 1.0
+        out_scale = 0.02 if (plant and not xp) else 1.0
         vec("decoder.ln.weight", n_ts, 0.02, 1.0)
         vec("decoder.ln.bias", n_ts)
         for i in range(n_tl):
@@ -152,18 +184,28 @@ def write_f16_model(path: Path, arch: str, seed: int = 1234, plant: bool = False
             mat(p + "attn.value.weight", n_ts, n_ts); vec(p + "attn.value.bias", n_ts)
             omat(p + "attn.out.weight", n_ts, n_ts); vec(p + "attn.out.bias", n_ts, 0.02 * out_scale)
             vec(p + "cross_attn_ln.weight", n_ts, 0.02, 1.0); vec(p + "cross_attn_ln.bias", n_ts)
+            if xp and i == n_tl - 1:
+                # the deciding block (see XPLANT above)
+                _w_tensor(f, p + "cross_attn.query.weight", (rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts)) * xc).astype(np.float16)); vec(p + "cross_attn.query.bias", n_ts)
+                _w_tensor(f, p + "cross_attn.key.weight", (rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts)) * xc).astype(np.float16))
+                wv = rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts))
+                _w_tensor(f, p + "cross_attn.value.weight", wv.astype(np.float16)); vec(p + "cross_attn.value.bias", n_ts)
+                wo = rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts))
+                wo[:, 0] = xg * xu
+                _w_tensor(f, p + "cross_attn.out.weight", wo.astype(np.float16)); vec(p + "cross_attn.out.bias", n_ts, 0.02)
+                continue
             mat(p + "cross_attn.query.weight", n_ts, n_ts); vec(p + "cross_attn.query.bias", n_ts)
             mat(p + "cross_attn.key.weight", n_ts, n_ts)
             mat(p + "cross_attn.value.weight", n_ts, n_ts); vec(p + "cross_attn.value.bias", n_ts)
             omat(p + "cross_attn.out.weight", n_ts, n_ts); vec(p + "cross_attn.out.bias", n_ts, 0.02 * out_scale)
 
 
-def make_model(arch: str, qtype: str, out_dir: Path | None = None, seed: int = 1234, quantize_bin: Path | None = None, plant: bool = False) -> Path:
+def make_model(arch: str, qtype: str, out_dir: Path | None = None, seed: int = 1234, quantize_bin: Path | None = None, plant=False) -> Path:
     """Create (or reuse) <out_dir>/synth-<arch>[-planted]-<qtype>.bin and return its path."""
     assert arch in ARCHS and qtype in QTYPES
     out_dir = Path(out_dir or os.environ.get("WHISPER_SYNTH_DIR", "/tmp/whisper_synth"))
     out_dir.mkdir(parents=True, exist_ok=True)
-    tag = f"{arch}-planted" if plant else arch
+    tag = f"{arch}-xplanted" if plant == "x" else (f"{arch}-planted" if plant else arch)
     f16 = out_dir / f"synth-{tag}-f16.bin"
     if not f16.exists():
         tmp = f16.with_suffix(".tmp")
@@ -209,5 +251,6 @@ if __name__ == "__main__":
     ap.add_argument("--out-dir", default=None)
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--plant", action="store_true", help="large-margin model with a known transcript (see write_f16_model)")
+    ap.add_argument("--xplant", action="store_true", help="model whose token decisions are carried by cross-attention (see XPLANT)")
     a = ap.parse_args()
-    print(make_model(a.arch, a.qtype, a.out_dir, a.seed, plant=a.plant))
+    print(make_model(a.arch, a.qtype, a.out_dir, a.seed, plant="x" if a.xplant else a.plant))

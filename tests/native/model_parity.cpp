@@ -59,9 +59,10 @@ int main(int argc, char ** argv) {
 
     const int n_mels = whisper_model_n_mels(cpu), n_vocab = whisper_n_vocab(cpu), n_len = 3000;
     std::vector<float> mel((size_t) n_mels * n_len);
-    std::mt19937 rng(42);
+    const float mel_phase = getenv("MODEL_PARITY_MEL_SEED") ? 0.37f * (float) atoi(getenv("MODEL_PARITY_MEL_SEED")) : 0.0f;
+    std::mt19937 rng(getenv("MODEL_PARITY_MEL_SEED") ? (unsigned) atoi(getenv("MODEL_PARITY_MEL_SEED")) : 42u);      // another seed = another "audio"
     for (int j = 0; j < n_mels; j++) for (int i = 0; i < n_len; i++)
-        mel[(size_t) j * n_len + i] = 0.6f * sinf(0.013f * i + 0.21f * j) + 0.4f * ((rng() >> 8) * (1.0f / 8388608.0f) - 1.0f);
+        mel[(size_t) j * n_len + i] = 0.6f * sinf(0.013f * i + 0.21f * j + mel_phase) + 0.4f * ((rng() >> 8) * (1.0f / 8388608.0f) - 1.0f);
     whisper_set_mel(cpu, mel.data(), n_len, n_mels);
     // self-test with MODEL_PARITY_PERTURB=eps: the reference against ITSELF on an input scaled by (1 + eps) — how far the reference's
     // own logits move under a perturbation of the size of one f32 rounding (its int8 activation rounding decides discretely)
@@ -82,7 +83,7 @@ int main(int argc, char ** argv) {
     // ---- teacher-forced single-token steps ----
     double worst_nmse = 0, worst_diff = 0, max_ref = 0, min_margin_on_mismatch = 1e30, max_margin_on_mismatch = 0, sum_nmse = 0; int agree = 0;
     int n_tight = 0, n_tight_mismatch = 0;      // steps whose CPU top-2 margin is below 2 x the largest logit difference of that step ("near-ties")
-    const bool brief = n_steps > 32;            // long runs: per-step rows only for the steps that matter
+    const bool brief = n_steps > 32 && !getenv("MODEL_PARITY_ALL_STEPS");      // long runs: per-step rows only for the steps that matter
     whisper_token tok = whisper_token_sot(cpu);
     double gpu_ms = 0, cpu_ms = 0;
     printf(" \"steps\": [");

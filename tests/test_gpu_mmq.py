@@ -80,11 +80,12 @@ def quantize(oracle, ka, tid, wf):
 
 
 def rows_views(buf: np.ndarray, q8k: bool, K: int, T: int):
-    """(q int8 [T][K], d f32 [T][nd], bsum i32 [T][K/32] or None) of a rows buffer (csrc/kernels/qrows.h)"""
+    """(q int8 [T][K], d f32 [T][nd], bsum i32 [T][K/32] or None) of a rows buffer (csrc/kernels/qrows.h: the scales and sums are stored
+    block-major, [nd][T] / [K/32][T]; returned per column here)"""
     nd = K // 256 if q8k else K // 32
     q = buf[: T * K].view(np.int8).reshape(T, K)
-    d = buf[T * K: T * K + T * nd * 4].view(np.float32).reshape(T, nd)
-    bs = buf[T * K + T * nd * 4: T * K + T * nd * 4 + T * (K // 32) * 4].view(np.int32).reshape(T, K // 32) if q8k else None
+    d = np.ascontiguousarray(buf[T * K: T * K + T * nd * 4].view(np.float32).reshape(nd, T).T)
+    bs = np.ascontiguousarray(buf[T * K + T * nd * 4: T * K + T * nd * 4 + T * (K // 32) * 4].view(np.int32).reshape(K // 32, T).T) if q8k else None
     return q, d, bs
 
 

@@ -929,6 +929,34 @@ static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c, const ggml_cgrap
 static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const mi355x_attn_partials & parts, int & end_out, int & rc_out);
 static int  run_node(mi_backend_ctx * b, const ggml_tensor * n);
 
+// TEST fault injection (negative control of the parity tests: a test that cannot fail proves nothing).  GGML_MI355X_TEST_FAULT=
+// "xattn:<n>:<factor>" multiplies the output of the n-th cross-attention block of a decoder step (n = -1: all of them) — the
+// (W_o . attention + bias) that is added to the residual stream, src/whisper.cpp:2703-2770 — by `factor`, for steps of up to 8 columns.
+// Cross-attention = the FLASH_ATTN_EXT nodes without a mask (decoder self-attention carries one; encoder attention has > 8 columns and
+// never passes here).  Unset: the factor is exactly 1 and nothing changes.
+struct mi_test_fault { int layer = -2; float factor = 1.0f; };
+static const mi_test_fault & mi_fault() {
+    static const mi_test_fault f = [] {
+        mi_test_fault t;
+        const char * e = getenv("GGML_MI355X_TEST_FAULT");
+        if (e && !strncmp(e, "xattn:", 6)) { int l = 0; float x = 1.0f; if (sscanf(e + 6, "%d:%f", &l, &x) == 2) { t.layer = l; t.factor = x; } }
+        return t;
+    }();
+    return f;
+}
+// epilogue scale of the output projection that consumes FLASH_ATTN_EXT node i of graph g (1 = untouched)
+static float mi_fault_scale(const ggml_cgraph * g, int i) {
+    const mi_test_fault & f = mi_fault();
+    if (f.layer == -2 || g->nodes[i]->src[3]) return 1.0f;
+    int ord = 0;
+    for (int j = 0; j < i; j++) if (g->nodes[j]->op == GGML_OP_FLASH_ATTN_EXT && !g->nodes[j]->src[3]) ord++;
+    return (f.layer < 0 || f.layer == ord) ? f.factor : 1.0f;
+}
+static void mi_fault_apply(const ggml_cgraph * g, int i, mi355x_epilogue & ep) {
+    const float fs = mi_fault_scale(g, i);
+    if (fs != 1.0f) { ep.scale = (ep.has_scale ? ep.scale : 1.0f) * fs; ep.has_scale = 1; }
+}
+
 
 // is this chain the vocabulary projection whose rows the caller reads back (src/whisper.cpp:2957-2963)?  Then its rows are mirrored.
 // (whisper does not flag the logits as a graph output; they are the LAST node of the decoder graph, src/whisper.cpp:2827-2840)
@@ -1039,6 +1067,7 @@ static void attn_consume(mi_backend_ctx * b, const ggml_cgraph * g, int i, const
             d.attn_part_o = parts.part_o; d.attn_part_ml = parts.part_ml; d.attn_nparts = parts.nparts;
             mi355x_gemv_seg & sg = d.seg[0];
             sg.w = w->data; sg.wtype = (int32_t) w->type; sg.N = (int32_t) w->ne[1]; sg.ep = ch.ep;
+            mi_fault_apply(g, i, sg.ep);
             sg.dst = ch.last->data; sg.dst_type = (int32_t) ch.last->type;
             sg.dst_nb1 = ch.last->type == GGML_TYPE_F16 ? (int64_t) w->ne[1]*2 : (ch.last == ch.mm ? (int64_t) ch.mm->nb[1] : (int64_t) ch.last->nb[1]);
             rc = mi355x_gemv_fused(b->k, &d);
@@ -1390,6 +1419,7 @@ static bool q_attn_proj(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, in
     mi355x_gemv_cols cols; memset(&cols, 0, sizeof(cols));
     d.K = (int) (H*64); d.T = cs.T; d.nseg = 1; d.x_planes = p0; d.cols = &cols;
     q_fill_seg(cs, ch, 0, d, cols);
+    mi_fault_apply(g, i, d.seg[0].ep);
     if (rc == 0) rc = mi355x_gemv_fused(k, &d);
     if (rc == MI355X_E_UNSUPPORTED) { rc = (int) hipErrorInvalidValue; GGML_LOG_ERROR("ggml-mi355x: plane pipeline rejected the attention output projection\n"); }
     rc_out = rc;

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) k_norm_v4(const NormArgs a) {
                 const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
                 const int q0 = (int) rintf(r[0]*id), q1 = (int) rintf(r[1]*id), q2 = (int) rintf(r[2]*id), q3 = (int) rintf(r[3]*id);
                 packed = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
-                if (e4 < n4 && (e4 & 7) == 0) a.rd[row * (n >> 5) + (e4 >> 3)] = round_f16(d);
+                if (e4 < n4 && (e4 & 7) == 0) a.rd[(int64_t) (e4 >> 3) * a.nrows + row] = round_f16(d);
             } else {
                 float mx = fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3]));
                 float mn = fminf(fminf(r[0], r[1]), fminf(r[2], r[3]));
@@ -243,8 +243,8 @@ __global__ void __launch_bounds__(256) k_norm_v4(const NormArgs a) {
                 int sm = q[0] + q[1] + q[2] + q[3];
                 sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
                 packed = (uint32_t) (q[0] & 0xFF) | ((uint32_t) (q[1] & 0xFF) << 8) | ((uint32_t) (q[2] & 0xFF) << 16) | ((uint32_t) (q[3] & 0xFF) << 24);
-                if (e4 < n4 && (e4 & 7) == 0)  a.rs[row * (n >> 5) + (e4 >> 3)] = sm;
-                if (e4 < n4 && (e4 & 63) == 0) a.rd[row * (n >> 8) + (e4 >> 6)] = d;
+                if (e4 < n4 && (e4 & 7) == 0)  a.rs[(int64_t) (e4 >> 3) * a.nrows + row] = sm;
+                if (e4 < n4 && (e4 & 63) == 0) a.rd[(int64_t) (e4 >> 6) * a.nrows + row] = d;
             }
             if (e4 < n4) *(uint32_t *) (a.rq + row * n + (size_t) e4*4) = packed;
         } else if (a.prep) {

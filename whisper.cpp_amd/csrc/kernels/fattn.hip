@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256*NG) k_fattn_mfma(const FattnArgs a) {
                     const int q0 = (int) rintf(v[4*g]*id), q1 = (int) rintf(v[4*g+1]*id), q2 = (int) rintf(v[4*g+2]*id), q3 = (int) rintf(v[4*g+3]*id);
                     *(uint32_t *) (pp + 32*i + 8*g + 4*hf) = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
                 }
-                if (hf == 0) a.rd[(int64_t) qi*(a.prep_ld >> 5) + hq*2 + i] = round_f16(d);
+                if (hf == 0) a.rd[(int64_t) (hq*2 + i)*a.T + qi] = round_f16(d);
             }
         }
     } else if (a.prep) {

@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_prep_act(const PrepArgs a) {
         const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
         const int q0 = (int) rintf(v[0]*id), q1 = (int) rintf(v[1]*id), q2 = (int) rintf(v[2]*id), q3 = (int) rintf(v[3]*id);
         *(uint32_t *) (a.rq + t*a.K + e) = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
-        if ((e & 31) == 0) a.rd[t*(a.K >> 5) + (e >> 5)] = round_f16(d);
+        if ((e & 31) == 0) a.rd[(int64_t) (e >> 5)*a.T + t] = round_f16(d);
         return;
     }
     if (a.mode == MI355X_PREP_Q8_K_ROWS) {
@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(256) k_prep_act(const PrepArgs a) {
         int s = q[0] + q[1] + q[2] + q[3];
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
         *(uint32_t *) (a.rq + t*a.K + e) = (uint32_t) (q[0] & 0xFF) | ((uint32_t) (q[1] & 0xFF) << 8) | ((uint32_t) (q[2] & 0xFF) << 16) | ((uint32_t) (q[3] & 0xFF) << 24);
-        if ((e & 31) == 0)  a.rs[t*(a.K >> 5) + (e >> 5)] = s;
-        if ((e & 255) == 0) a.rd[t*(a.K >> 8) + (e >> 8)] = d;
+        if ((e & 31) == 0)  a.rs[(int64_t) (e >> 5)*a.T + t] = s;
+        if ((e & 255) == 0) a.rd[(int64_t) (e >> 8)*a.T + t] = d;
         return;
     }
     if (a.mode == 0) {

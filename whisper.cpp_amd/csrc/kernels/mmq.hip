@@ -46,12 +46,15 @@ struct MmqArgs {
 #define MQ_KS 128                      // K elements per step = bytes per tile row
 __device__ __forceinline__ int mq_off(int row, int slot) { return row*128 + ((slot ^ ((row >> 1) & 7)) << 4); }   // 16-byte slot of a [rows][128 B] tile
 
-// ---- registers of one thread's share of the next A tile: PA (row, block) pairs of one row -------------------------------------------
+// ---- registers of one thread's share of the next A tile ----------------------------------------------------------------------------
+// Q4_0 / Q5_0 / Q8_0: PA (row, block) pairs, pair j = (row (tid >> 2) + 64*j, block tid & 3 of the K-step): the four lanes of a row read
+// its 4 blocks' quants, high bits and scales as ONE contiguous run each (64 / 16 / 8 bytes) — 16 runs per wave instruction instead of 32
+// lines with one 16-byte piece used of each.
 template <int WT, int PA> struct mq_aregs;
 template <int PA> struct mq_aregs<MI355X_TYPE_Q4_0, PA> { uint4 q[PA]; uint16_t d[PA]; };
 template <int PA> struct mq_aregs<MI355X_TYPE_Q5_0, PA> { uint4 q[PA]; uint32_t qh[PA]; uint16_t d[PA]; };
 template <int PA> struct mq_aregs<MI355X_TYPE_Q8_0, PA> { uint4 q0[PA], q1[PA]; uint16_t d[PA]; };
-// Q4_K: the thread's PA sub-blocks lie in ONE 64-element chunk (PA = 2: both nibbles of its 32 bytes; PA = 1: one of them)
+// Q4_K: the thread's PA sub-blocks lie in ONE 64-element chunk of row tid / (4 / PA) (PA = 2: both nibbles of its 32 bytes; PA = 1: one of them)
 template <int PA> struct mq_aregs<MI355X_TYPE_Q4_K, PA> { uint4 q0, q1; uint32_t dm; uint32_t sc[3]; };
 
 // signed bytes from 5-bit values x = nib | bit << 4 (ggml-quants.c:500-524: w = x - 16): spread the four INVERTED high bits to byte
@@ -61,15 +64,17 @@ __device__ __forceinline__ uint32_t q5_signed(uint32_t nib, uint32_t inv4) {
     const uint32_t m = __builtin_amdgcn_perm(0u, 0u, t | 0x0C0C0C0Cu);     // v_perm_b32 selector 0x0C -> 0x00, 0x0D -> 0xFF: a byte mask without a multiply
     return nib | (m & 0xF0F0F0F0u);
 }
-// signed bytes from nibbles (ggml-quants.c:459-477: w = nib - 8): sign extension of (nib ^ 8) from bit 3, four bytes at once:
-// ((y | 0x80) - 8) ^ 0x80 never borrows across bytes
-__device__ __forceinline__ uint32_t q4_signed(uint32_t nib) { return ((nib ^ 0x88888888u) - 0x08080808u) ^ 0x80808080u; }
+// signed bytes from nibbles (ggml-quants.c:459-477: w = nib - 8), four bytes at once: with bit 7 set as a guard the subtraction never
+// borrows across bytes ((nib | 0x80) - 8 = 0x78 + nib), and flipping bit 7 back leaves nib - 8 in two's complement
+// (nib >= 8: 0x80 + (nib - 8) -> nib - 8;  nib < 8: 0x78 + nib -> 0xF8 + nib)
+__device__ __forceinline__ uint32_t q4_signed(uint32_t nib) { return ((nib | 0x80808080u) - 0x08080808u) ^ 0x80808080u; }
 
+// row0 = the thread's (clamped) global row of pair 0, row1 of pair 1; blk = its 32-block along K (Q4_K: first sub-block of its chunk run)
 template <int WT, int PA>
-__device__ __forceinline__ void mq_a_load(mq_aregs<WT, PA> & r, const MmqArgs & a, int row, int blk /* first 32-block of this thread, global index along K */) {
+__device__ __forceinline__ void mq_a_load(mq_aregs<WT, PA> & r, const MmqArgs & a, int row0, int row1, int blk) {
     if constexpr (WT == MI355X_TYPE_Q4_K) {
         const qplanes<MI355X_TYPE_Q4_K> p(a.A, a.nbt);
-        const int64_t sb = (int64_t) row * (a.K >> 8) + (blk >> 3);
+        const int64_t sb = (int64_t) row0 * (a.K >> 8) + (blk >> 3);
         const uint8_t * qs = p.qs + sb*128 + ((blk & 7) >> 1)*32;
         r.q0 = *(const uint4 *) qs; r.q1 = *(const uint4 *) (qs + 16);
         r.dm = p.dm[sb];
@@ -77,23 +82,24 @@ __device__ __forceinline__ void mq_a_load(mq_aregs<WT, PA> & r, const MmqArgs & 
         r.sc[0] = sc[0]; r.sc[1] = sc[1]; r.sc[2] = sc[2];
     } else {
         const qplanes<WT> p(a.A, a.nbt);
-        const int64_t ib = (int64_t) row * (a.K >> 5) + blk;
         #pragma unroll
         for (int i = 0; i < PA; i++) {
+            const int64_t ib = (int64_t) (i == 0 ? row0 : row1) * (a.K >> 5) + blk;
             if constexpr (WT == MI355X_TYPE_Q8_0) {
-                r.q0[i] = *(const uint4 *) (p.qs + (ib + i)*32);
-                r.q1[i] = *(const uint4 *) (p.qs + (ib + i)*32 + 16);
+                r.q0[i] = *(const uint4 *) (p.qs + ib*32);
+                r.q1[i] = *(const uint4 *) (p.qs + ib*32 + 16);
             } else {
-                r.q[i] = *(const uint4 *) (p.qs + (ib + i)*16);
-                if constexpr (WT == MI355X_TYPE_Q5_0) r.qh[i] = p.qh[ib + i];
+                r.q[i] = *(const uint4 *) (p.qs + ib*16);
+                if constexpr (WT == MI355X_TYPE_Q5_0) r.qh[i] = p.qh[ib];
             }
-            r.d[i] = p.d[ib + i];
+            r.d[i] = p.d[ib];
         }
     }
 }
 
 // unpack to int8 and store: tile rows of 128 bytes, block lb (0..3) of the K-step = slots 2*lb (elements 0..15), 2*lb + 1 (16..31);
 // per-block f32 scales sA[lb][row] (Q4_K: d*sc_j, and mA[lb][row] = -(dmin*m_j))
+// (Q4_0 / Q5_0 / Q8_0: pair i is tile row `row + 64*i`, block lb0; Q4_K: PA sub-blocks lb0 .. of tile row `row`)
 template <int WT, int PA, int BMT, bool SMF>
 __device__ __forceinline__ void mq_a_store(const mq_aregs<WT, PA> & r, char * At, float * sA, float * mA, int row, int lb0, int blk) {
     if constexpr (WT == MI355X_TYPE_Q4_K) {
@@ -133,10 +139,11 @@ __device__ __forceinline__ void mq_a_store(const mq_aregs<WT, PA> & r, char * At
                 }
                 lo = make_uint4(l[0], l[1], l[2], l[3]); hi = make_uint4(h[0], h[1], h[2], h[3]);
             }
-            *(uint4 *) (At + mq_off(row, 2*(lb0 + i)))     = lo;
-            *(uint4 *) (At + mq_off(row, 2*(lb0 + i) + 1)) = hi;
-            if constexpr (SMF) ((uint32_t *) sA)[(lb0 + i)*BMT + row] = (uint32_t) r.d[i];      // the f16 itself: K-slot 0 of the rank-1 scale MFMA
-            else sA[(lb0 + i)*BMT + row] = h2f(r.d[i]);
+            const int ri = row + 64*i;
+            *(uint4 *) (At + mq_off(ri, 2*lb0))     = lo;
+            *(uint4 *) (At + mq_off(ri, 2*lb0 + 1)) = hi;
+            if constexpr (SMF) ((uint32_t *) sA)[lb0*BMT + ri] = (uint32_t) r.d[i];      // the f16 itself: K-slot 0 of the rank-1 scale MFMA
+            else sA[lb0*BMT + ri] = h2f(r.d[i]);
         }
     }
 }
@@ -203,7 +210,7 @@ __device__ __forceinline__ void mq_epilogue(const MmqArgs & a, floatx16 (&acc)[M
                     const int q0 = (int) rintf(v[4*g]*id), q1 = (int) rintf(v[4*g+1]*id), q2 = (int) rintf(v[4*g+2]*id), q3 = (int) rintf(v[4*g+3]*id);
                     *(uint32_t *) (a.pq + t*a.M + m) = (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
                 }
-                if (hf == 0) a.pd[t*(a.M >> 5) + (mb >> 5)] = round_f16(d);
+                if (hf == 0) a.pd[(int64_t) (mb >> 5)*a.T + t] = round_f16(d);
             }
         }
     }
@@ -219,7 +226,6 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
     constexpr int PA = BMT * 4 / 256;                         // (row, block) pairs of A per thread and K-step: 2 or 1
     constexpr int TPR = 4 / PA;                               // threads per A row
     constexpr int CB = BNT / 32;                              // 16-byte chunks of B per thread and K-step
-    constexpr int TPB = 8 / CB;                               // threads per B row
     static_assert(PA == 1 || PA == 2, "BMT is 64 or 128");
     // one stage: A tile | B tile | sA[4][BMT] | mA[4][BMT] (Q4_K) | sB[4][BNT] | dB[BNT] (Q4_K)
     constexpr int OFF_B  = BMT * 128;
@@ -240,53 +246,67 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
     const int nb = a.K >> 5;
 
     // staging assignments (rows past the matrix edge are clamped: their results are never stored)
-    const int arow = tid / TPR, alb0 = (tid % TPR) * PA;
-    const int arow_g = m0 + arow < a.M ? m0 + arow : a.M - 1;
-    const int brow = tid / TPB, bslot0 = (tid % TPB) * CB;
-    const int64_t brow_g = n0 + brow < a.T ? n0 + brow : a.T - 1;
-    const int8_t * bq = a.Bq + brow_g * a.K + bslot0 * 16;
-    // scales of B: thread (brow, first block) owns CB/2 blocks' worth of a row's slots
-    constexpr int SBN = CB / 2;                               // blocks per thread
-    const int sblk0 = bslot0 >> 1;
+    //   A (Q4_0 / Q5_0 / Q8_0): pair j = tile row (tid >> 2) + 64*j, block tid & 3;  A (Q4_K): tile row tid / TPR, sub-blocks (tid % TPR) * PA ..
+    //   B: 16-byte chunk i of the thread = tile row (tid >> 3) + 32*i, slot tid & 7: eight lanes move one whole 128-byte line
+    //   B scales: value i of the thread = element tid + 256*i of the [4][BNT] scale block: a wave reads 256 contiguous bytes
+    const int arow = Q4K ? tid / TPR : tid >> 2, alb0 = Q4K ? (tid % TPR) * PA : tid & 3;
+    const int arow_g0 = m0 + arow < a.M ? m0 + arow : a.M - 1;
+    const int arow_g1 = m0 + arow + 64 < a.M ? m0 + arow + 64 : a.M - 1;
+    const int brow = tid >> 3, bslot = tid & 7;
+    const int8_t * bq[CB];
+    #pragma unroll
+    for (int i = 0; i < CB; i++) {
+        const int64_t r = n0 + brow + 32*i;
+        bq[i] = a.Bq + (r < a.T ? r : a.T - 1) * a.K + bslot * 16;
+    }
+    constexpr int SBN = BNT * 4 / 256;                        // B scales per thread and K-step (1 or 2)
+    int64_t scol[SBN]; int sblk[SBN];
+    #pragma unroll
+    for (int i = 0; i < SBN; i++) {
+        const int e = tid + 256*i;
+        sblk[i] = e / BNT;
+        const int64_t c = n0 + e % BNT;
+        scol[i] = c < a.T ? c : a.T - 1;
+    }
 
     mq_aregs<WT, PA> ar;
     uint4 br0, br1, br2 = make_uint4(0, 0, 0, 0), br3 = make_uint4(0, 0, 0, 0);      // (named registers: an array indexed inside the lambdas stays in private memory)
-    float bsc0 = 0.0f, bsc1 = 0.0f; float bd8 = 0.0f; int bsm0 = 0, bsm1 = 0;
+    float bsc0 = 0.0f, bsc1 = 0.0f; float bd80 = 0.0f, bd81 = 0.0f; int bsm0 = 0, bsm1 = 0;
     static_assert(CB == 2 || CB == 4, "B staging is written for 64- and 128-column tiles");
 
     auto load_tile = [&](int kt) {
-        mq_a_load<WT, PA>(ar, a, arow_g, kt*4 + alb0);
-        const uint4 * bp = (const uint4 *) (bq + (int64_t) kt*MQ_KS);
-        br0 = bp[0]; br1 = bp[1];
-        if constexpr (CB == 4) { br2 = bp[2]; br3 = bp[3]; }
+        mq_a_load<WT, PA>(ar, a, arow_g0, arow_g1, kt*4 + alb0);
+        br0 = *(const uint4 *) (bq[0] + (int64_t) kt*MQ_KS); br1 = *(const uint4 *) (bq[1] + (int64_t) kt*MQ_KS);
+        if constexpr (CB == 4) { br2 = *(const uint4 *) (bq[2] + (int64_t) kt*MQ_KS); br3 = *(const uint4 *) (bq[3] + (int64_t) kt*MQ_KS); }
         if constexpr (Q4K) {
-            bd8 = a.Bd[brow_g * (a.K >> 8) + (kt >> 1)];
-            bsm0 = a.Bs[brow_g * nb + kt*4 + sblk0];
-            if constexpr (SBN == 2) bsm1 = a.Bs[brow_g * nb + kt*4 + sblk0 + 1];
+            bd80 = a.Bd[(int64_t) (kt >> 1) * a.T + scol[0]];
+            bsm0 = a.Bs[(int64_t) (kt*4 + sblk[0]) * a.T + scol[0]];
+            if constexpr (SBN == 2) { bd81 = a.Bd[(int64_t) (kt >> 1) * a.T + scol[1]]; bsm1 = a.Bs[(int64_t) (kt*4 + sblk[1]) * a.T + scol[1]]; }
         } else {
-            bsc0 = a.Bd[brow_g * nb + kt*4 + sblk0];
-            if constexpr (SBN == 2) bsc1 = a.Bd[brow_g * nb + kt*4 + sblk0 + 1];
+            bsc0 = a.Bd[(int64_t) (kt*4 + sblk[0]) * a.T + scol[0]];
+            if constexpr (SBN == 2) bsc1 = a.Bd[(int64_t) (kt*4 + sblk[1]) * a.T + scol[1]];
         }
     };
     auto store_tile = [&](int kt, char * st) {
         mq_a_store<WT, PA, BMT, SMF>(ar, st, (float *) (st + OFF_SA), (float *) (st + OFF_MA), arow, alb0, kt*4 + alb0);
-        *(uint4 *) (st + OFF_B + mq_off(brow, bslot0))     = br0;
-        *(uint4 *) (st + OFF_B + mq_off(brow, bslot0 + 1)) = br1;
+        *(uint4 *) (st + OFF_B + mq_off(brow, bslot))      = br0;
+        *(uint4 *) (st + OFF_B + mq_off(brow + 32, bslot)) = br1;
         if constexpr (CB == 4) {
-            *(uint4 *) (st + OFF_B + mq_off(brow, bslot0 + 2)) = br2;
-            *(uint4 *) (st + OFF_B + mq_off(brow, bslot0 + 3)) = br3;
+            *(uint4 *) (st + OFF_B + mq_off(brow + 64, bslot)) = br2;
+            *(uint4 *) (st + OFF_B + mq_off(brow + 96, bslot)) = br3;
         }
         float * sB = (float *) (st + OFF_SB);
+        const int e0 = tid, e1 = tid + 256;                       // element of the [4][BNT] scale block = sblk * BNT + column
         if constexpr (Q4K) {
-            sB[sblk0*BNT + brow] = bd8 * (float) bsm0;
-            if constexpr (SBN == 2) sB[(sblk0 + 1)*BNT + brow] = bd8 * (float) bsm1;
-            if (bslot0 == 0) ((float *) (st + OFF_DB))[brow] = bd8;
+            sB[e0] = bd80 * (float) bsm0;
+            if constexpr (SBN == 2) sB[e1] = bd81 * (float) bsm1;
+            if (e0 < BNT) ((float *) (st + OFF_DB))[e0] = bd80;      // (block 0's threads hold every column's d8 once)
         } else if constexpr (SMF) {
-            ((uint32_t *) sB)[sblk0*BNT + brow] = (uint32_t) f2h(bsc0);                        // exact: a Q8_0 scale is an f16 value
-            if constexpr (SBN == 2) ((uint32_t *) sB)[(sblk0 + 1)*BNT + brow] = (uint32_t) f2h(bsc1);
+            ((uint32_t *) sB)[e0] = (uint32_t) f2h(bsc0);                        // exact: a Q8_0 scale is an f16 value
+            if constexpr (SBN == 2) ((uint32_t *) sB)[e1] = (uint32_t) f2h(bsc1);
         } else {
-            sB[sblk0*BNT + brow] = bsc0;
-            if constexpr (SBN == 2) sB[(sblk0 + 1)*BNT + brow] = bsc1;
+            sB[e0] = bsc0;
+            if constexpr (SBN == 2) sB[e1] = bsc1;
         }
     };
 

@@ -5,8 +5,10 @@
 // f16, q = round(x / d)), Q8_K blocks for Q4_K weights (ggml-quants.c:2768-2805: one f32 scale per 256, sums per 16).  The int8 tile
 // GEMM (mmq.hip) consumes exactly those integers.  For x [K, T] the bytes are, K-contiguous per column so that a 128-element K-step
 // of a column is one 128-byte line:
-//     Q8_0 rows : q[T][K] int8 | d[T][K/32]  f32 (f16-valued)
-//     Q8_K rows : q[T][K] int8 | d[T][K/256] f32 | bsum[T][K/32] i32 (sum of the 32 q of a sub-block: pairs of the reference's bsums)
+//     Q8_0 rows : q[T][K] int8 | d[K/32][T]  f32 (f16-valued)
+//     Q8_K rows : q[T][K] int8 | d[K/256][T] f32 | bsum[K/32][T] i32 (sum of the 32 q of a sub-block: pairs of the reference's bsums)
+// The scales are BLOCK-major (one block's scales of consecutive columns are contiguous): a tile of the GEMM needs 4 blocks x 128
+// columns of them per K-step, i.e. four 512-byte runs instead of 128 four-float snippets 4*K/32 bytes apart.
 // (The decoder's "planes" — decode_common.h — are the same integers arranged for the mat-vec kernels' LDS image.)
 #pragma once
 #include <stdint.h>
