@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call around the int8 tile GEMM (csrc/kernels/mmq.hip): hardware probe, kernel tests, micro benchmark, encoder A-B, full suite.
-# usage: scripts/gpu_mmq.sh [stage ...]   stages: probe mmqtest kbench encab pytest   (default: all; later stages are skipped when mmqtest fails)
+# usage: scripts/gpu_mmq.sh [stage ...]   stages: probe mmqtest kbench encab sel pytest   (default: all; later stages are skipped when mmqtest fails)
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD
@@ -42,6 +42,11 @@ try:
 except Exception as e: print("parse failed", e)
 PY
     done
+    ;;
+sel)
+    stage "pytest selection: ${PYTEST_SEL:-}"
+    timeout 1500 python3 -m pytest ${PYTEST_FILES:-tests} -m gpu -q -p no:cacheprovider -k "${PYTEST_SEL:-vad}" > "$OUT/pytest_sel.txt" 2>&1
+    echo "exit=$?"; tail -25 "$OUT/pytest_sel.txt"
     ;;
 pytest)
     stage "pytest -m gpu (everything)"

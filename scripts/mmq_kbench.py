@@ -94,8 +94,7 @@ def main():
     pf16 = torch.zeros((T, 4 * n), dtype=torch.float16, device="cuda:0")
     torch.cuda.synchronize()
 
-    MMQ = [("mmq default", {}), ("mmq 128x128", {"GGML_MI355X_MMQ_TILE": 128128}), ("mmq 64x128", {"GGML_MI355X_MMQ_TILE": 64128}),
-           ("mmq 128x64", {"GGML_MI355X_MMQ_TILE": 12864}), ("mmq 64x128, VALU scales", {"GGML_MI355X_MMQ_SCALE_MFMA": 0})]
+    MMQ = [("mmq 64x128 (default)", {}), ("mmq 128x64", {"GGML_MI355X_MMQ_TILE": 12864}), ("mmq 64x128, VALU scales", {"GGML_MI355X_MMQ_SCALE_MFMA": 0})]
 
     def cases(label, M, K, rows, act16, ep, prep):
         count = max(4, int(400e6 // (M * K * 2)))
@@ -105,8 +104,8 @@ def main():
         def mmq(i):
             tw = ka.tensor(wq[i % count].data_ptr(), tid, [K, M])
             if prep:
-                return L.mi355x_gemm_q8act_prep(ctx.h, C.byref(tw), rows.data_ptr(), T, None, 0, C.byref(ep), prow.data_ptr())
-            return L.mi355x_gemm_q8act(ctx.h, C.byref(tw), rows.data_ptr(), T, dst.data_ptr(), M * 4, ka.F32, C.byref(ep))
+                return L.mi355x_gemm_q8act_prep(ctx.h, C.byref(tw), rows.data_ptr(), T, None, 0, C.byref(ep), prow.data_ptr()) or L.mi355x_flush(ctx.h)
+            return L.mi355x_gemm_q8act(ctx.h, C.byref(tw), rows.data_ptr(), T, dst.data_ptr(), M * 4, ka.F32, C.byref(ep)) or L.mi355x_flush(ctx.h)
         for name, e in MMQ:
             timed(label, name, e, mmq, 2.0 * T * M * K, a.iters)
         del wq
@@ -146,8 +145,10 @@ def main():
                 if rc:
                     return rc
             return 0
-        for name, e in MMQ[:3]:
-            timed("qkv", name + " (3 launches)", e, qkv, 3 * 2.0 * T * n * n, a.iters)
+        def qkv_flush(i):
+            return qkv(i) or L.mi355x_flush(ctx.h)
+        timed("qkv", "mmq, grouped launch", {}, qkv_flush, 3 * 2.0 * T * n * n, a.iters)
+        timed("qkv", "mmq, 3 launches", {"GGML_MI355X_MMQ_GROUP": 0}, qkv_flush, 3 * 2.0 * T * n * n, a.iters)
         del wq
         wf = [(torch.randn((n, n), device="cuda:0", generator=g) * n ** -0.5).to(torch.float16) for _ in range(count)]
 

@@ -76,9 +76,11 @@ def planted_token(pos: int) -> int:
 # embedding; which of them wins is decided by the sign of ONE number that only the last decoder layer's cross-attention produces:
 #   * u: a fixed random direction; a_p / b_p = the text tokens whose embeddings project most positively / most negatively on u
 #   * last layer: row 0 of cross_attn.value.weight = w (random), column 0 of cross_attn.out.weight = g * u, query / key weights x c
-#     (sharper attention) => the block adds g * u * s_p to the residual stream with s_p = sum_k softmax_k(q_p . K) (w . enc_k): a number
-#     that depends on the AUDIO (the encoder output), on the position's query, on the softmax over 1500 keys and on V — i.e. on every
-#     piece of arithmetic of the cross-attention path
+#     (c > 1: sharper attention), element 0 of cross_attn.value.bias = 1 => the block adds g * u * s_p to the residual stream with
+#     s_p = sum_k softmax_k(q_p . K) (w . enc_k + 1): a number produced by the softmax over the 1500 encoder keys (it must sum to one),
+#     by V and by W_o — i.e. by every piece of arithmetic of the cross-attention path.  (Random-weight encoders barely react to their
+#     input — two different "audios" change 0 of 96 decisions even with g = 0 — so the transcript is NOT audio-dependent; what the model
+#     guarantees is that a wrong cross-attention changes it.)
 #   * every residual-writing projection keeps its full scale (out_scale 1): self-attention, the other 31 cross-attentions and all MLPs
 #     contribute at the level of a random-weight model
 # sign(s_p) picks a_p or b_p; the margin is ~ g * |s_p| * (proj_a - proj_b) / rms(x).  (f, g, c) per architecture were calibrated
@@ -95,6 +97,36 @@ def xplant_tables(te: np.ndarray, n_text_ctx: int, seed: int):
     proj = te[:n_text].astype(np.float32) @ u
     order = np.argsort(proj)
     return u, order[::-1][:n_text_ctx].copy(), order[:n_text_ctx].copy()
+
+
+def read_token_embedding(f16_model: Path) -> np.ndarray:
+    """decoder.token_embedding.weight [n_vocab, n] (f16) of an F16 model file written by write_f16_model"""
+    with open(f16_model, "rb") as f:
+        f.read(4 + 44)
+        nm, nf = struct.unpack("ii", f.read(8))
+        f.seek(nm * nf * 4, 1)
+        (nv,) = struct.unpack("i", f.read(4))
+        for _ in range(nv):
+            (ln,) = struct.unpack("I", f.read(4))
+            f.seek(ln, 1)
+        while True:
+            h = f.read(12)
+            if len(h) < 12:
+                raise RuntimeError("no token embedding in " + str(f16_model))
+            nd, nl, ft = struct.unpack("iii", h)
+            ne = struct.unpack("i" * nd, f.read(4 * nd))
+            name = f.read(nl).decode()
+            n = int(np.prod(ne)) * (2 if ft == 1 else 4)
+            if name == "decoder.token_embedding.weight":
+                return np.frombuffer(f.read(n), dtype=np.float16).reshape(ne[1], ne[0]).copy()
+            f.seek(n, 1)
+
+
+def xplant_candidates(arch: str, out_dir: Path | None = None, seed: int = 1234):
+    """(a[p], b[p]): the two candidate tokens of every decoder position of the x-planted model of `arch` (made if necessary)"""
+    f16 = make_model(arch, "f16", out_dir, seed, plant="x")
+    _, a, b = xplant_tables(read_token_embedding(f16), ARCHS[arch][5], seed)
+    return [int(t) for t in a], [int(t) for t in b]
 
 
 def write_f16_model(path: Path, arch: str, seed: int = 1234, plant=False):
@@ -189,7 +221,10 @@ def write_f16_model(path: Path, arch: str, seed: int = 1234, plant=False):
                 _w_tensor(f, p + "cross_attn.query.weight", (rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts)) * xc).astype(np.float16)); vec(p + "cross_attn.query.bias", n_ts)
                 _w_tensor(f, p + "cross_attn.key.weight", (rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts)) * xc).astype(np.float16))
                 wv = rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts))
-                _w_tensor(f, p + "cross_attn.value.weight", wv.astype(np.float16)); vec(p + "cross_attn.value.bias", n_ts)
+                _w_tensor(f, p + "cross_attn.value.weight", wv.astype(np.float16))
+                bv = rng.normal((n_ts,), 0.02).astype(np.float32)
+                bv[0] = 1.0                                  # s_p = sum_k softmax_k (w . enc_k) + 1: a stable sign, still every step of the attention arithmetic
+                _w_tensor(f, p + "cross_attn.value.bias", bv)
                 wo = rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts))
                 wo[:, 0] = xg * xu
                 _w_tensor(f, p + "cross_attn.out.weight", wo.astype(np.float16)); vec(p + "cross_attn.out.bias", n_ts, 0.02)

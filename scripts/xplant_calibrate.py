@@ -21,30 +21,7 @@ os.environ["XPLANT_PARAMS"] = params
 out = Path(f"/tmp/xplant_cal/{params.replace(',', '_')}")
 m = sm.make_model(arch, qtype, out_dir=out, plant="x")
 (n_vocab, _, _, _, _, n_text_ctx, n_ts, _, n_tl, _) = sm.ARCHS[arch]
-# the candidate tables, from the f16 file's token embedding
-rng = sm._Rng(1234)
-# (re-derive te exactly as write_f16_model does is fragile: read it back from the f16 file instead)
-import struct
-f16 = out / f"synth-{arch}-xplanted-f16.bin"
-te = None
-with open(f16, "rb") as f:
-    f.read(4 + 44)
-    nm, nf = struct.unpack("ii", f.read(8)); f.read(nm * nf * 4)
-    (nv,) = struct.unpack("i", f.read(4))
-    for _ in range(nv):
-        (ln,) = struct.unpack("I", f.read(4)); f.read(ln)
-    while True:
-        h = f.read(12)
-        if len(h) < 12:
-            break
-        nd, nl, ft = struct.unpack("iii", h)
-        ne = struct.unpack("i" * nd, f.read(4 * nd))
-        name = f.read(nl).decode()
-        n = int(np.prod(ne)) * (2 if ft == 1 else 4)
-        if name == "decoder.token_embedding.weight":
-            te = np.frombuffer(f.read(n), dtype=np.float16).reshape(ne[1], ne[0]).copy()
-            break
-        f.seek(n, 1)
+te = sm.read_token_embedding(out / f"synth-{arch}-xplanted-f16.bin")
 u, xa, xb = sm.xplant_tables(te, n_text_ctx, 1234)
 env = dict(os.environ, GGML_MI355X_PLUGIN="cpu", MODEL_PARITY_ALL_STEPS="1", LD_LIBRARY_PATH=str(ROOT / "oracle" / "_ref"))
 runs = []

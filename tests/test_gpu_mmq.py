@@ -181,12 +181,47 @@ def test_mmq_tile_shapes_and_scale_forms_are_bit_identical(gpu, oracle, t, K, N,
     x = rng.standard_normal((T, K)).astype(np.float32)
     _, planar = quantize(oracle, ka, tid, wf)
     got = {}
-    for name, kv in {"default": {}, "64x128": dict(GGML_MI355X_MMQ_TILE=64128), "128x64": dict(GGML_MI355X_MMQ_TILE=12864),
-                     "128x128": dict(GGML_MI355X_MMQ_TILE=128128), "valu-scales": dict(GGML_MI355X_MMQ_SCALE_MFMA=0)}.items():
+    for name, kv in {"default": {}, "128x64": dict(GGML_MI355X_MMQ_TILE=12864), "valu-scales": dict(GGML_MI355X_MMQ_SCALE_MFMA=0),
+                     "single launches": dict(GGML_MI355X_MMQ_GROUP=0)}.items():
         with env(**kv):
             got[name], _ = run_mmq(gpu, tid, planar, x, K, N, T)
     for name in got:
         assert np.array_equal(got["default"].view(np.uint32), got[name].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("t", ["q5_0", "q8_0", "q4_K"])
+def test_grouped_mmq_launch_is_bit_identical_to_single_launches(gpu, oracle, t):
+    """three products on the same activation rows (an encoder layer's Q / K / V) leave as ONE grouped launch; every tile runs the single
+    form's code: the results are word for word those of three launches"""
+    ctx, ka, torch = gpu
+    tid = QT[t]
+    K, N, T = 512, 384, 333
+    rng = np.random.default_rng(11 + tid)
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    x_d = dev(torch, x)
+    r_d = make_rows(gpu, tid, x_d, K, T)
+    ws, biases = [], []
+    for i in range(3):
+        wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+        ws.append(dev(torch, quantize(oracle, ka, tid, wf)[1]))
+        biases.append(dev(torch, rng.standard_normal(N).astype(np.float32)))
+    out = {}
+    for grouped in (1, 0):
+        ys = [torch.full((T, N), 5.0, dtype=torch.float16 if i == 1 else torch.float32, device="cuda:0") for i in range(3)]
+        torch.cuda.synchronize()
+        with env(GGML_MI355X_MMQ_GROUP=grouped):
+            ctx.prof(True); ctx.prof_reset()
+            for i in range(3):
+                ep = ka.Epilogue(bias=biases[i].data_ptr())
+                tw = ka.tensor(ws[i].data_ptr(), tid, [K, N])
+                ctx.check(ka.lib().mi355x_gemm_q8act(ctx.h, C.byref(tw), r_d.data_ptr(), T, ys[i].data_ptr(), N * (2 if i == 1 else 4), ka.F16 if i == 1 else ka.F32, C.byref(ep)), "gemm_q8act")
+            ctx.sync()
+            rows = ctx.prof_report(); ctx.prof(False)
+        launches = sum(r["calls"] for r in rows if "mmq" in r["name"])
+        assert launches == (1 if grouped else 3), rows
+        out[grouped] = [y.cpu().numpy() for y in ys]
+    for i in range(3):
+        assert np.array_equal(out[1][i].view(np.uint16 if i == 1 else np.uint32), out[0][i].view(np.uint16 if i == 1 else np.uint32)), i
 
 
 def gelu_table_lookup(ka, x: np.ndarray) -> np.ndarray:

@@ -785,8 +785,9 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
 static int hold_ring_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, double flops) {
     static const bool group_on = !(getenv("GGML_MI355X_GEMM_GROUP") && !atoi(getenv("GGML_MI355X_GEMM_GROUP")));
     PendingGemms * P = (PendingGemms *) ctx->pending_store;
-    if (ctx->pending_n > 0 && !(group_on && gemm_mergeable(*P, ctx->pending_n, k))) {
-        const int rc = flush_pending_gemms(ctx);
+    // (the pending store may hold another kernel family's launches — mmq.hip groups its products the same way: those leave first)
+    if (ctx->pending_n > 0 && (ctx->pending_flush != flush_pending_gemms || !(group_on && gemm_mergeable(*P, ctx->pending_n, k)))) {
+        const int rc = mi355x_flush_pending(ctx);
         if (rc) return rc;
     }
     if (ctx->pending_n == 0) { P->bytes = 0; P->flops = 0; }

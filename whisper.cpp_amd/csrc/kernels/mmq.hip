@@ -16,7 +16,12 @@
 //    GEMM's epilogue, or mi355x_prep_act); the tile copy is a straight 16-byte move.
 //  * 256 threads = 4 waves in a 2 x 2 arrangement, wave tile (BMT/2) x (BNT/2), K-step = 128 elements (4 blocks), two LDS stages, ONE
 //    barrier per K-step; the global loads of step k+1 are in flight while step k is computed.
-//  * The fix-up is VALU work (16 cvt + 16 fma per 32 x 32 x 32 MFMA).  The 32 x 32 tile of scale products dw[m]*dx[t] — 16 different
+//  * The fix-up is VALU work, and the VALU — 4 cycles per wave instruction, 128 for the naive 16 cvt + 16 fma against the 64 of the MFMA
+//    pair (first GPU run: 57 us for fc1, the f16 path 46) — is what bounds the kernel.  So (i) the integer sums arrive AS FLOATS: the
+//    MFMA's C operand is the constant 0x4B400000 in every element, i.e. D = bits(1.5 * 2^23) + sum, whose float value is 12582912 + sum
+//    exactly for |sum| < 2^22 (Q8_0 x Q8_0: 32 * 127 * 127 < 2^19), and 12582912 is subtracted again — exactly, float(sum) bit for bit —
+//    by a PACKED add; (ii) the fma is packed as well: 8 v_pk_add_f32 + 8 v_pk_fma_f32 = 64 cycles per MFMA pair.
+//    The 32 x 32 tile of scale products dw[m]*dx[t] — 16 different
 //    weight rows per lane — comes from the matrix cores as well: one v_mfma_f32_32x32x16_f16 whose A operand holds dw (f16, exact) in
 //    K-slot 0 and whose B operand holds dx (an f16 value by construction of Q8_0) in K-slot 0, zeros elsewhere: a rank-1 product,
 //    exact in f32.  Without it every lane would need 16 broadcast LDS reads and 16 multiplies per MFMA (SMF = false: the form Q4_K
@@ -64,44 +69,19 @@ __device__ __forceinline__ uint32_t q5_signed(uint32_t nib, uint32_t inv4) {
     const uint32_t m = __builtin_amdgcn_perm(0u, 0u, t | 0x0C0C0C0Cu);     // v_perm_b32 selector 0x0C -> 0x00, 0x0D -> 0xFF: a byte mask without a multiply
     return nib | (m & 0xF0F0F0F0u);
 }
+// the same with the 4-bit -> byte-mask step read from a 16-entry table in LDS (lut[x] = 0xF0 in byte k where bit k of x is set): two
+// VALU operations (extract, scale the index) and one ds_read_b32 instead of five — the unpack is VALU time the fix-up needs
+__device__ __forceinline__ uint32_t q5_signed_lut(uint32_t nib, uint32_t inv, int shift, const uint32_t * lut) { return nib | lut[(inv >> shift) & 0xFu]; }
 // signed bytes from nibbles (ggml-quants.c:459-477: w = nib - 8), four bytes at once: with bit 7 set as a guard the subtraction never
 // borrows across bytes ((nib | 0x80) - 8 = 0x78 + nib), and flipping bit 7 back leaves nib - 8 in two's complement
 // (nib >= 8: 0x80 + (nib - 8) -> nib - 8;  nib < 8: 0x78 + nib -> 0xF8 + nib)
 __device__ __forceinline__ uint32_t q4_signed(uint32_t nib) { return ((nib | 0x80808080u) - 0x08080808u) ^ 0x80808080u; }
 
-// row0 = the thread's (clamped) global row of pair 0, row1 of pair 1; blk = its 32-block along K (Q4_K: first sub-block of its chunk run)
-template <int WT, int PA>
-__device__ __forceinline__ void mq_a_load(mq_aregs<WT, PA> & r, const MmqArgs & a, int row0, int row1, int blk) {
-    if constexpr (WT == MI355X_TYPE_Q4_K) {
-        const qplanes<MI355X_TYPE_Q4_K> p(a.A, a.nbt);
-        const int64_t sb = (int64_t) row0 * (a.K >> 8) + (blk >> 3);
-        const uint8_t * qs = p.qs + sb*128 + ((blk & 7) >> 1)*32;
-        r.q0 = *(const uint4 *) qs; r.q1 = *(const uint4 *) (qs + 16);
-        r.dm = p.dm[sb];
-        const uint32_t * sc = (const uint32_t *) (p.sc + sb*12);
-        r.sc[0] = sc[0]; r.sc[1] = sc[1]; r.sc[2] = sc[2];
-    } else {
-        const qplanes<WT> p(a.A, a.nbt);
-        #pragma unroll
-        for (int i = 0; i < PA; i++) {
-            const int64_t ib = (int64_t) (i == 0 ? row0 : row1) * (a.K >> 5) + blk;
-            if constexpr (WT == MI355X_TYPE_Q8_0) {
-                r.q0[i] = *(const uint4 *) (p.qs + ib*32);
-                r.q1[i] = *(const uint4 *) (p.qs + ib*32 + 16);
-            } else {
-                r.q[i] = *(const uint4 *) (p.qs + ib*16);
-                if constexpr (WT == MI355X_TYPE_Q5_0) r.qh[i] = p.qh[ib];
-            }
-            r.d[i] = p.d[ib];
-        }
-    }
-}
-
 // unpack to int8 and store: tile rows of 128 bytes, block lb (0..3) of the K-step = slots 2*lb (elements 0..15), 2*lb + 1 (16..31);
 // per-block f32 scales sA[lb][row] (Q4_K: d*sc_j, and mA[lb][row] = -(dmin*m_j))
 // (Q4_0 / Q5_0 / Q8_0: pair i is tile row `row + 64*i`, block lb0; Q4_K: PA sub-blocks lb0 .. of tile row `row`)
 template <int WT, int PA, int BMT, bool SMF>
-__device__ __forceinline__ void mq_a_store(const mq_aregs<WT, PA> & r, char * At, float * sA, float * mA, int row, int lb0, int blk) {
+__device__ __forceinline__ void mq_a_store(const mq_aregs<WT, PA> & r, char * At, float * sA, float * mA, int row, int lb0, int blk, const uint32_t * lut) {
     if constexpr (WT == MI355X_TYPE_Q4_K) {
         const float d = h2f((uint16_t) (r.dm & 0xFFFF)), dmin = h2f((uint16_t) (r.dm >> 16));
         const uint32_t w[8] = { r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w };
@@ -130,8 +110,8 @@ __device__ __forceinline__ void mq_a_store(const mq_aregs<WT, PA> & r, char * At
                     const uint32_t inv = ~r.qh[i];
                     #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        l[e] = q5_signed(w[e] & 0x0F0F0F0Fu,        inv >> (4*e));
-                        h[e] = q5_signed((w[e] >> 4) & 0x0F0F0F0Fu, inv >> (16 + 4*e));
+                        l[e] = q5_signed_lut(w[e] & 0x0F0F0F0Fu,        inv, 4*e,      lut);
+                        h[e] = q5_signed_lut((w[e] >> 4) & 0x0F0F0F0Fu, inv, 16 + 4*e, lut);
                     }
                 } else {
                     #pragma unroll
@@ -233,8 +213,11 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
     constexpr int OFF_MA = OFF_SA + 4 * BMT * 4;
     constexpr int OFF_SB = OFF_MA + (Q4K ? 4 * BMT * 4 : 0);
     constexpr int OFF_DB = OFF_SB + 4 * BNT * 4;
-    constexpr int OFF_Z  = OFF_DB + (Q4K ? BNT * 4 : 0);     // SMF: one zero word — what lanes 32..63 (K-slots 8..15 of the scale MFMA) read
-    constexpr int STAGE  = OFF_Z + 16;
+    // SMF: a block of zeros the size of the larger scale array — what lanes 32..63 (K-slots 8..15 of the rank-1 scale MFMA) read, at
+    // the same constant offsets lanes 0..31 use into sA / sB (so that the per-block offset can be an instruction immediate for every lane)
+    constexpr int ZB     = SMF ? 4 * (BMT > BNT ? BMT : BNT) * 4 : 16;
+    constexpr int OFF_Z  = OFF_DB + (Q4K ? BNT * 4 : 0);
+    constexpr int STAGE  = OFF_Z + ZB;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -253,6 +236,7 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
     const int arow_g0 = m0 + arow < a.M ? m0 + arow : a.M - 1;
     const int arow_g1 = m0 + arow + 64 < a.M ? m0 + arow + 64 : a.M - 1;
     const int brow = tid >> 3, bslot = tid & 7;
+    // running pointers: every operand advances by a constant number of bytes per K-step (no 64-bit multiplies inside the loop)
     const int8_t * bq[CB];
     #pragma unroll
     for (int i = 0; i < CB; i++) {
@@ -260,13 +244,34 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
         bq[i] = a.Bq + (r < a.T ? r : a.T - 1) * a.K + bslot * 16;
     }
     constexpr int SBN = BNT * 4 / 256;                        // B scales per thread and K-step (1 or 2)
-    int64_t scol[SBN]; int sblk[SBN];
+    const float * bdp[SBN]; const int * bsp[SBN]; const float * bd8p[SBN];
     #pragma unroll
     for (int i = 0; i < SBN; i++) {
         const int e = tid + 256*i;
-        sblk[i] = e / BNT;
         const int64_t c = n0 + e % BNT;
-        scol[i] = c < a.T ? c : a.T - 1;
+        const int64_t cc = c < a.T ? c : a.T - 1;
+        bdp[i]  = a.Bd + (int64_t) (e / BNT) * a.T + cc;       // Q8_0 rows: scale of block e / BNT of the K-step
+        bsp[i]  = Q4K ? a.Bs + (int64_t) (e / BNT) * a.T + cc : nullptr;
+        bd8p[i] = a.Bd + cc;                                    // Q8_K rows: the super-block's scale
+    }
+    const int64_t step_scales = 4 * a.T;                      // elements per K-step in a block-major scale array
+    // A: byte addresses of this thread's first block in each plane
+    const char * aq0, * aq1 = nullptr; const char * ah0 = nullptr, * ah1 = nullptr; const char * ad0 = nullptr, * ad1 = nullptr;
+    int a_sb0 = 0;
+    {
+        const int nbk = a.K >> 5;
+        if constexpr (Q4K) {
+            const qplanes<MI355X_TYPE_Q4_K> p(a.A, a.nbt);
+            a_sb0 = arow_g0 * (a.K >> 8);
+            aq0 = (const char *) p.qs + (int64_t) a_sb0 * 128 + (alb0 >> 1) * 32;
+        } else {
+            const qplanes<WT> p(a.A, a.nbt);
+            constexpr int QB = WT == MI355X_TYPE_Q8_0 ? 32 : 16;
+            const int64_t ib0 = (int64_t) arow_g0 * nbk + alb0, ib1 = (int64_t) arow_g1 * nbk + alb0;
+            aq0 = (const char *) p.qs + ib0 * QB; aq1 = (const char *) p.qs + ib1 * QB;
+            ad0 = (const char *) (p.d + ib0);     ad1 = (const char *) (p.d + ib1);
+            if constexpr (WT == MI355X_TYPE_Q5_0) { ah0 = (const char *) (p.qh + ib0); ah1 = (const char *) (p.qh + ib1); }
+        }
     }
 
     mq_aregs<WT, PA> ar;
@@ -274,21 +279,49 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
     float bsc0 = 0.0f, bsc1 = 0.0f; float bd80 = 0.0f, bd81 = 0.0f; int bsm0 = 0, bsm1 = 0;
     static_assert(CB == 2 || CB == 4, "B staging is written for 64- and 128-column tiles");
 
+    // loads of K-step kt; called with kt = 0, 1, 2, ... in order (the pointers run along)
     auto load_tile = [&](int kt) {
-        mq_a_load<WT, PA>(ar, a, arow_g0, arow_g1, kt*4 + alb0);
-        br0 = *(const uint4 *) (bq[0] + (int64_t) kt*MQ_KS); br1 = *(const uint4 *) (bq[1] + (int64_t) kt*MQ_KS);
-        if constexpr (CB == 4) { br2 = *(const uint4 *) (bq[2] + (int64_t) kt*MQ_KS); br3 = *(const uint4 *) (bq[3] + (int64_t) kt*MQ_KS); }
         if constexpr (Q4K) {
-            bd80 = a.Bd[(int64_t) (kt >> 1) * a.T + scol[0]];
-            bsm0 = a.Bs[(int64_t) (kt*4 + sblk[0]) * a.T + scol[0]];
-            if constexpr (SBN == 2) { bd81 = a.Bd[(int64_t) (kt >> 1) * a.T + scol[1]]; bsm1 = a.Bs[(int64_t) (kt*4 + sblk[1]) * a.T + scol[1]]; }
+            const qplanes<MI355X_TYPE_Q4_K> p(a.A, a.nbt);
+            ar.q0 = *(const uint4 *) aq0; ar.q1 = *(const uint4 *) (aq0 + 16);
+            aq0 += 64;                                           // 4 sub-blocks = 2 chunks of 32 bytes
+            const int sb = a_sb0 + ((kt*4 + alb0) >> 3);
+            ar.dm = p.dm[sb];
+            const uint32_t * sc = (const uint32_t *) (p.sc + (int64_t) sb*12);
+            ar.sc[0] = sc[0]; ar.sc[1] = sc[1]; ar.sc[2] = sc[2];
         } else {
-            bsc0 = a.Bd[(int64_t) (kt*4 + sblk[0]) * a.T + scol[0]];
-            if constexpr (SBN == 2) bsc1 = a.Bd[(int64_t) (kt*4 + sblk[1]) * a.T + scol[1]];
+            constexpr int QB = WT == MI355X_TYPE_Q8_0 ? 32 : 16;
+            if constexpr (WT == MI355X_TYPE_Q8_0) { ar.q0[0] = *(const uint4 *) aq0; ar.q1[0] = *(const uint4 *) (aq0 + 16); }
+            else ar.q[0] = *(const uint4 *) aq0;
+            if constexpr (WT == MI355X_TYPE_Q5_0) ar.qh[0] = *(const uint32_t *) ah0;
+            ar.d[0] = *(const uint16_t *) ad0;
+            if constexpr (PA == 2) {
+                if constexpr (WT == MI355X_TYPE_Q8_0) { ar.q0[1] = *(const uint4 *) aq1; ar.q1[1] = *(const uint4 *) (aq1 + 16); }
+                else ar.q[1] = *(const uint4 *) aq1;
+                if constexpr (WT == MI355X_TYPE_Q5_0) ar.qh[1] = *(const uint32_t *) ah1;
+                ar.d[1] = *(const uint16_t *) ad1;
+            }
+            aq0 += 4*QB; aq1 += 4*QB; ad0 += 8; ad1 += 8;
+            if constexpr (WT == MI355X_TYPE_Q5_0) { ah0 += 16; ah1 += 16; }
+        }
+        br0 = *(const uint4 *) bq[0]; br1 = *(const uint4 *) bq[1];
+        if constexpr (CB == 4) { br2 = *(const uint4 *) bq[2]; br3 = *(const uint4 *) bq[3]; }
+        #pragma unroll
+        for (int i = 0; i < CB; i++) bq[i] += MQ_KS;
+        if constexpr (Q4K) {
+            bd80 = *bd8p[0]; bsm0 = *bsp[0];
+            if constexpr (SBN == 2) { bd81 = *bd8p[1]; bsm1 = *bsp[1]; }
+            #pragma unroll
+            for (int i = 0; i < SBN; i++) { bsp[i] += step_scales; if (kt & 1) bd8p[i] += a.T; }
+        } else {
+            bsc0 = *bdp[0];
+            if constexpr (SBN == 2) bsc1 = *bdp[1];
+            #pragma unroll
+            for (int i = 0; i < SBN; i++) bdp[i] += step_scales;
         }
     };
     auto store_tile = [&](int kt, char * st) {
-        mq_a_store<WT, PA, BMT, SMF>(ar, st, (float *) (st + OFF_SA), (float *) (st + OFF_MA), arow, alb0, kt*4 + alb0);
+        mq_a_store<WT, PA, BMT, SMF>(ar, st, (float *) (st + OFF_SA), (float *) (st + OFF_MA), arow, alb0, kt*4 + alb0, (const uint32_t *) (lds + 2*STAGE));
         *(uint4 *) (st + OFF_B + mq_off(brow, bslot))      = br0;
         *(uint4 *) (st + OFF_B + mq_off(brow + 32, bslot)) = br1;
         if constexpr (CB == 4) {
@@ -318,14 +351,20 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
             #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    if (tid < 8) ((uint32_t *) (lds + (tid >> 2) * STAGE + OFF_Z))[tid & 3] = 0u;
+    for (int e = tid; e < 2 * (ZB / 4); e += 256) ((uint32_t *) (lds + (e / (ZB / 4)) * STAGE + OFF_Z))[e % (ZB / 4)] = 0u;
+    if (tid < 16) ((uint32_t *) (lds + 2*STAGE))[tid] = ((tid & 1) ? 0xF0u : 0u) | ((tid & 2) ? 0xF000u : 0u) | ((tid & 4) ? 0xF00000u : 0u) | ((tid & 8) ? 0xF0000000u : 0u);
     load_tile(0);
     store_tile(0, lds);
     __syncthreads();
 
     const int l31 = lane & 31, hf = lane >> 5;
-    const i32x16_t zi = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    // C operand of every integer MFMA: 0x4B400000 = bits(12582912.0f) in all 16 elements, so that D read as a float is 12582912 + sum
+    // (from an asm: left to itself the compiler re-materialises the 16 registers in front of every MFMA)
+    int mg; asm volatile("v_mov_b32 %0, 0x4b400000" : "=v"(mg));
+    const i32x16_t zi = { mg, mg, mg, mg, mg, mg, mg, mg, mg, mg, mg, mg, mg, mg, mg, mg };
     const floatx16 zf = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    typedef float float2_t __attribute__((ext_vector_type(2)));
+    const float2_t cmg = { 12582912.0f, 12582912.0f };
 
     // Compute schedule of one K-step.  Left alone, hipcc issues all 32 MFMAs of a step first, sinks the (memory-free) cvt / fma chains of
     // ALL tile-blocks below the last of them and keeps 16 result sets (512 registers) alive; sched_barrier alone only pins what the IR
@@ -346,19 +385,28 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
         #pragma unroll
         for (int j = 0; j < NT; j++) f.bs[j] = i32x4_t{ z0, z0, z0, z0 };
     }
+    // LDS addresses of this lane's fragment reads: the XOR swizzle of a row depends on (row >> 1) & 7 only, i.e. on the lane (tile rows
+    // start at multiples of 32), so the four blocks' slot offsets are four per-lane constants and everything else — tile index, array
+    // base, block of the scale arrays — is an instruction immediate: two address adds per block instead of eleven
+    int xo[4];
+    #pragma unroll
+    for (int b = 0; b < 4; b++) xo[b] = ((2*b + hf) ^ ((l31 >> 1) & 7)) << 4;
+    const int a_lane = (wm*(MT*32) + l31) * 128, b_lane = OFF_B + (wn*(NT*32) + l31) * 128;
+    const int sa_lane = hf == 0 ? OFF_SA + (wm*(MT*32) + l31) * 4 : OFF_Z + l31 * 4;
+    const int sb_lane = hf == 0 ? OFF_SB + (wn*(NT*32) + l31) * 4 : OFF_Z + l31 * 4;
     auto read_frags = [&](const char * st, int b) {
-        const char * At = st, * Bt = st + OFF_B;
         const float * sA = (const float *) (st + OFF_SA), * mA = (const float *) (st + OFF_MA), * sB = (const float *) (st + OFF_SB);
+        const char * pa = st + a_lane + xo[b], * pb = st + b_lane + xo[b];
         #pragma unroll
-        for (int i = 0; i < MT; i++) f.af[i] = *(const i32x4_t *) (At + mq_off(wm*(MT*32) + i*32 + l31, 2*b + hf));
+        for (int i = 0; i < MT; i++) f.af[i] = *(const i32x4_t *) (pa + i*4096);
         #pragma unroll
-        for (int j = 0; j < NT; j++) f.bf[j] = *(const i32x4_t *) (Bt + mq_off(wn*(NT*32) + j*32 + l31, 2*b + hf));
+        for (int j = 0; j < NT; j++) f.bf[j] = *(const i32x4_t *) (pb + j*4096);
         if constexpr (SMF) {
-            // rank-1 scale tiles: K-slot 0 of the A / B operand = element 0 of lanes 0..31; lanes 32..63 read the stage's zero word
+            // rank-1 scale tiles: K-slot 0 of the A / B operand = element 0 of lanes 0..31; lanes 32..63 read the stage's zero block
             #pragma unroll
-            for (int i = 0; i < MT; i++) f.as[i][0] = *(const int *) (st + (hf == 0 ? OFF_SA + (b*BMT + wm*(MT*32) + i*32 + l31)*4 : OFF_Z));
+            for (int i = 0; i < MT; i++) f.as[i][0] = *(const int *) (st + sa_lane + (b*BMT + i*32) * 4);
             #pragma unroll
-            for (int j = 0; j < NT; j++) f.bs[j][0] = *(const int *) (st + (hf == 0 ? OFF_SB + (b*BNT + wn*(NT*32) + j*32 + l31)*4 : OFF_Z));
+            for (int j = 0; j < NT; j++) f.bs[j][0] = *(const int *) (st + sb_lane + (b*BNT + j*32) * 4);
         } else {
             // scales of this lane's 16 rows per tile: four float4 broadcast reads (rows 8g + 4*hf .. + 3); its column's scale is a scalar
             #pragma unroll
@@ -398,13 +446,18 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
     // scale operands of the VALU form are copied out before the next block's reads overwrite them
     auto fold = [&](int n, const i32x16_t & S, const floatx16 & SC) {
         const int i = n % MT, j = n / MT;
+        // float(sum) = (12582912 + sum) - 12582912, exact; two accumulator elements per VALU instruction
+        const floatx16 Sf = __builtin_bit_cast(floatx16, S);
         #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            if constexpr (SMF) acc[i][j][r] = fmaf((float) S[r], SC[r], acc[i][j][r]);
+        for (int r = 0; r < 16; r += 2) {
+            const float2_t t = float2_t{ Sf[r], Sf[r + 1] } - cmg;
+            float2_t av = { acc[i][j][r], acc[i][j][r + 1] };
+            if constexpr (SMF) av = __builtin_elementwise_fma(t, float2_t{ SC[r], SC[r + 1] }, av);
             else {
-                acc[i][j][r] = fmaf((float) S[r], f.sa[i][r] * f.dxn[j], acc[i][j][r]);
-                if constexpr (Q4K) acc[i][j][r] = fmaf(f.ma[i][r], f.vbn[j], acc[i][j][r]);
+                av = __builtin_elementwise_fma(t, float2_t{ f.sa[i][r], f.sa[i][r + 1] } * float2_t{ f.dxn[j], f.dxn[j] }, av);
+                if constexpr (Q4K) av = __builtin_elementwise_fma(float2_t{ f.ma[i][r], f.ma[i][r + 1] }, float2_t{ f.vbn[j], f.vbn[j] }, av);
             }
+            acc[i][j][r] = av[0]; acc[i][j][r + 1] = av[1];
         }
         asm volatile("" : "+v"(acc[i][j]));
         __builtin_amdgcn_sched_barrier(0);
@@ -455,47 +508,145 @@ __global__ void __launch_bounds__(256, 2) k_mmq(const MmqArgs a) {
     mmq_tile<WT, BMT, BNT, SMF>(a, tile, mq_lds);
 }
 
+// Grouped form: up to MMQ_GROUP_MAX independent products on the SAME activation rows and of the same shape (the Q / K / V projections
+// of an encoder layer; the cross-attention K / V projections of consecutive decoder layers), one launch over the concatenated tile
+// space, dealt to the XCDs in contiguous ranges like the single form (gemm_mfma.hip: k_gemm_f16_ring_group).  Every tile runs exactly the
+// code of the single form: bit-identical.
+#define MMQ_GROUP_MAX 8
+struct MmqGroupArgs { MmqArgs g[MMQ_GROUP_MAX]; int n, tiles_per_member, per; };
+template <int WT, int BMT, int BNT, bool SMF>
+__global__ void __launch_bounds__(256, 2) k_mmq_group(const MmqGroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char mq_lds_g[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t = xcd * ga.per + idx;
+    if (t >= ga.n * ga.tiles_per_member) return;
+    const int gi = t / ga.tiles_per_member;
+    mmq_tile<WT, BMT, BNT, SMF>(ga.g[gi], t - gi * ga.tiles_per_member, mq_lds_g);
+}
+
 template <int WT, int BMT, int BNT>
 static constexpr uint32_t mmq_lds_bytes() {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
-    return 2u * (uint32_t) ((BMT + BNT) * 128 + 4 * BMT * 4 * (Q4K ? 2 : 1) + 4 * BNT * 4 + (Q4K ? BNT * 4 : 0) + 16);
+    // two stages (tiles | scales | zero block, SMF or not: the larger) + the Q5_0 unpack table
+    return 2u * (uint32_t) ((BMT + BNT) * 128 + 4 * BMT * 4 * (Q4K ? 2 : 1) + 4 * BNT * 4 + (Q4K ? BNT * 4 : 0) + 4 * (BMT > BNT ? BMT : BNT) * 4) + 64u;
 }
 
-template <int WT, int BMT, int BNT, bool SMF>
-static int launch_mmq(mi355x_ctx * ctx, const MmqArgs & k0, double bytes, double flops) {
-    constexpr uint32_t lds = mmq_lds_bytes<WT, BMT, BNT>();
-    MmqArgs k = k0;
+// tile counts of one member + the XCD-aware tile order for ranges of `per` consecutive tiles (gemm_mfma.hip: ring_tiling)
+template <int BMT, int BNT>
+static void mmq_tiling(MmqArgs & k, int64_t per) {
     k.mt = (k.M + BMT - 1) / BMT; k.nt = (int) ((k.T + BNT - 1) / BNT);
     const int64_t ntiles = (int64_t) k.mt * k.nt;
-    k.per = (int) ((ntiles + 7) / 8);
-    // bytes each XCD pulls through its L2 for its `per` consecutive tiles, column-major vs row-major tile order (gemm_mfma.hip: ring_tiling)
+    k.per = (int) (per < ntiles ? per : ntiles);
     const double a_tile = (double) BMT * k.K * 0.7, b_tile = (double) BNT * k.K * 1.125;
     const double col_major = a_tile * (k.per < k.mt ? k.per : k.mt) + b_tile * ((k.per + k.mt - 1) / k.mt + (k.per % k.mt ? 1 : 0));
     const double row_major = b_tile * (k.per < k.nt ? k.per : k.nt) + a_tile * ((k.per + k.nt - 1) / k.nt + (k.per % k.nt ? 1 : 0));
     k.m_major = row_major < col_major ? 1 : 0;
-    static std::atomic<bool> attr_set[64];
-    const int dev = ctx->device & 63;
-    if (lds > 64 * 1024 && !attr_set[dev].load()) {
-        if (hipFuncSetAttribute((const void *) k_mmq<WT, BMT, BNT, SMF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
-        attr_set[dev].store(true);
-    }
-    return emit(ctx, "mmq", k_mmq<WT, BMT, BNT, SMF>, dim3((uint32_t) (8 * k.per)), dim3(256), lds, k, bytes, flops);
 }
 
-// tile shape: 128 x 128 when that still gives every CU a workgroup, else 64 x 128 (the A unpack is amortised over the tile's columns,
-// so narrow-M / wide-N is the cheaper way to more tiles); GGML_MI355X_MMQ_TILE=128128 | 64128 | 12864 forces one
-template <int WT, bool SMF>
-static int launch_mmq_shape(mi355x_ctx * ctx, const MmqArgs & k, double bytes, double flops) {
-    if constexpr (!SMF) return launch_mmq<WT, 64, 128, false>(ctx, k, bytes, flops);       // (16 + 16 scale registers per tile: only the small tile fits 256 registers)
-    else {
-        const int force = getenv("GGML_MI355X_MMQ_TILE") ? atoi(getenv("GGML_MI355X_MMQ_TILE")) : 0;
-        const int64_t t128 = (int64_t) ((k.M + 127) / 128) * ((k.T + 127) / 128);
-        if (force == 12864) return launch_mmq<WT, 128, 64, true>(ctx, k, bytes, flops);
-        // (Q8_0: its A tile is a plain copy — nothing to amortise over a wider tile — and its 18 prefetch registers do not fit beside 128 x 128)
-        if (force == 64128 || (force == 0 && t128 < ctx->n_cu) || WT == MI355X_TYPE_Q8_0) return launch_mmq<WT, 64, 128, true>(ctx, k, bytes, flops);
-        if constexpr (WT != MI355X_TYPE_Q8_0) return launch_mmq<WT, 128, 128, true>(ctx, k, bytes, flops);
-        return MI355X_E_UNSUPPORTED;
+template <typename F>
+static int mmq_lds_attr(mi355x_ctx * ctx, F func, uint32_t lds, std::atomic<bool> * attr_set) {
+    const int dev = ctx->device & 63;
+    if (lds > 64 * 1024 && !attr_set[dev].load()) {
+        if (hipFuncSetAttribute((const void *) func, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
+        attr_set[dev].store(true);
     }
+    return 0;
+}
+
+template <int WT, int BMT, int BNT, bool SMF>
+static int launch_mmq(mi355x_ctx * ctx, const MmqArgs * members, int n, double bytes, double flops) {
+    constexpr uint32_t lds = mmq_lds_bytes<WT, BMT, BNT>();
+    const int64_t tiles = (int64_t) ((members[0].M + BMT - 1) / BMT) * ((members[0].T + BNT - 1) / BNT);
+    const int64_t per = (n * tiles + 7) / 8;
+    if (n == 1) {
+        MmqArgs k = members[0];
+        mmq_tiling<BMT, BNT>(k, per);
+        k.per = (int) per;
+        static std::atomic<bool> attr_set[64];
+        if (mmq_lds_attr(ctx, k_mmq<WT, BMT, BNT, SMF>, lds, attr_set) != 0) return MI355X_E_UNSUPPORTED;
+        return emit(ctx, "mmq", k_mmq<WT, BMT, BNT, SMF>, dim3((uint32_t) (8 * per)), dim3(256), lds, k, bytes, flops);
+    }
+    MmqGroupArgs ga; memset(&ga, 0, sizeof(ga));
+    for (int i = 0; i < n; i++) { ga.g[i] = members[i]; mmq_tiling<BMT, BNT>(ga.g[i], per); }
+    ga.n = n; ga.tiles_per_member = (int) tiles; ga.per = (int) per;
+    static std::atomic<bool> attr_set_g[64];
+    if (mmq_lds_attr(ctx, k_mmq_group<WT, BMT, BNT, SMF>, lds, attr_set_g) != 0) return MI355X_E_UNSUPPORTED;
+    return emit(ctx, "mmq_group", k_mmq_group<WT, BMT, BNT, SMF>, dim3((uint32_t) (8 * per)), dim3(256), lds, ga, bytes, flops);
+}
+
+// tile shape: 64 x 128 — the A unpack is amortised over the tile's 128 columns, the B tile is a plain copy, and two result sets, the
+// constant C operand and the prefetch registers fit 256 VGPRs beside 2 accumulator tiles per wave (with 4 — a 128 x 128 tile — they
+// spill); GGML_MI355X_MMQ_TILE=12864 selects 128 x 64 for A-B measurements
+template <int WT, bool SMF>
+static int launch_mmq_shape(mi355x_ctx * ctx, const MmqArgs * members, int n, double bytes, double flops) {
+    if constexpr (SMF) {
+        const int force = getenv("GGML_MI355X_MMQ_TILE") ? atoi(getenv("GGML_MI355X_MMQ_TILE")) : 0;
+        if (force == 12864) return launch_mmq<WT, 128, 64, true>(ctx, members, n, bytes, flops);
+    }
+    return launch_mmq<WT, 64, 128, SMF>(ctx, members, n, bytes, flops);
+}
+
+static int launch_mmq_any(mi355x_ctx * ctx, int wt, const MmqArgs * members, int n, double bytes, double flops) {
+    // GGML_MI355X_MMQ_SCALE_MFMA=0: scale products on the VALU from broadcast LDS reads (the Q4_K form) instead of the rank-1 MFMA
+    const bool smf = !(getenv("GGML_MI355X_MMQ_SCALE_MFMA") && !atoi(getenv("GGML_MI355X_MMQ_SCALE_MFMA")));
+    switch (wt) {
+        case MI355X_TYPE_Q4_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q4_0, true>(ctx, members, n, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q4_0, false>(ctx, members, n, bytes, flops);
+        case MI355X_TYPE_Q5_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q5_0, true>(ctx, members, n, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q5_0, false>(ctx, members, n, bytes, flops);
+        case MI355X_TYPE_Q8_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q8_0, true>(ctx, members, n, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q8_0, false>(ctx, members, n, bytes, flops);
+        default:               return launch_mmq_shape<MI355X_TYPE_Q4_K, false>(ctx, members, n, bytes, flops);
+    }
+}
+
+// ---- held-back products (mi355x_ctx::pending_*): independent neighbours on the same activation rows leave as ONE grouped launch ----
+struct PendingMmq { MmqArgs k[MMQ_GROUP_MAX]; int wt; double bytes, flops; };
+static_assert(sizeof(PendingMmq) <= sizeof(((mi355x_ctx *) nullptr)->pending_store), "pending_store too small");
+
+static bool mq_overlap(const void * a, int64_t na, const void * b, int64_t nb) {
+    return a && b && na > 0 && nb > 0 && (const char *) a < (const char *) b + nb && (const char *) b < (const char *) a + na;
+}
+static int64_t mq_dst_bytes(const MmqArgs & k) { return (k.T - 1) * k.dst_nb1 + (int64_t) k.M * (k.dst_f16 ? 2 : 4); }
+static int64_t mq_res_bytes(const MmqArgs & k) { return k.residual ? (k.T - 1) * k.res_nb1 + (int64_t) k.M * 4 : 0; }
+
+// may `k` join the held-back members?  Same rows and shape, and no member reads or writes what another member writes.
+static bool mmq_mergeable(const PendingMmq & P, int n, int wt, const MmqArgs & k) {
+    const MmqArgs & f = P.k[0];
+    if (k.pq || f.pq || wt != P.wt) return false;                          // a product that also writes activation rows goes alone
+    if (n >= MMQ_GROUP_MAX || k.Bq != f.Bq || k.K != f.K || k.T != f.T || k.M != f.M) return false;
+    const int64_t kd = mq_dst_bytes(k);
+    if (mq_overlap(k.dst, kd, k.Bq, k.T * (int64_t) k.K * 2)) return false;
+    for (int i = 0; i < n; i++) {
+        const MmqArgs & e = P.k[i];
+        const int64_t ed = mq_dst_bytes(e);
+        if (mq_overlap(k.dst, kd, e.dst, ed)) return false;
+        if (mq_overlap(k.residual, mq_res_bytes(k), e.dst, ed) || mq_overlap(e.residual, mq_res_bytes(e), k.dst, kd)) return false;
+        if (mq_overlap(k.bias, (k.bias_t ? k.T : (int64_t) k.M) * 4, e.dst, ed) || mq_overlap(e.bias, (e.bias_t ? e.T : (int64_t) e.M) * 4, k.dst, kd)) return false;
+    }
+    return true;
+}
+
+static int flush_pending_mmq(mi355x_ctx * ctx) {
+    PendingMmq P; memcpy(&P, ctx->pending_store, sizeof(P));
+    const int n = ctx->pending_n;
+    ctx->pending_n = 0;
+    ctx->in_flush = true;
+    const int rc = launch_mmq_any(ctx, P.wt, P.k, n, P.bytes, P.flops);
+    ctx->in_flush = false;
+    return rc;
+}
+
+static int hold_mmq(mi355x_ctx * ctx, int wt, const MmqArgs & k, double bytes, double flops) {
+    const bool group_on = !(getenv("GGML_MI355X_MMQ_GROUP") && !atoi(getenv("GGML_MI355X_MMQ_GROUP")));      // (read per call: a test compares both forms in one process)
+    if (!group_on) return launch_mmq_any(ctx, wt, &k, 1, bytes, flops);
+    PendingMmq * P = (PendingMmq *) ctx->pending_store;
+    if (ctx->pending_n > 0 && (ctx->pending_flush != flush_pending_mmq || !mmq_mergeable(*P, ctx->pending_n, wt, k))) {
+        const int rc = mi355x_flush_pending(ctx);
+        if (rc) return rc;
+    }
+    if (ctx->pending_n == 0) { P->bytes = 0; P->flops = 0; P->wt = wt; }
+    P->k[ctx->pending_n++] = k;
+    P->bytes += bytes; P->flops += flops;
+    ctx->pending_flush = flush_pending_mmq;
+    return 0;
 }
 
 // mi355x_gemm_q8act (mi355x_kernels.h): w planar quantized [K, M]; act = activation rows of x [K, T]
@@ -521,14 +672,7 @@ static int gemm_q8act_impl(mi355x_ctx * ctx, const mi355x_tensor * A, const void
     }
     const double flops = 2.0 * M * (double) K * (double) T;
     const double bytes = (double) mi355x_type_row_bytes(wt, K) * M + (double) qrows_bytes(q8k, K, T) + (prep_only ? 0.0 : (double) T*M*(k.dst_f16 ? 2 : 4)) + (prep_out ? (double) qrows_bytes(0, M, T) : 0.0);
-    // GGML_MI355X_MMQ_SCALE_MFMA=0: scale products on the VALU from broadcast LDS reads (the Q4_K form) instead of the rank-1 MFMA
-    const bool smf = !(getenv("GGML_MI355X_MMQ_SCALE_MFMA") && !atoi(getenv("GGML_MI355X_MMQ_SCALE_MFMA")));
-    switch (wt) {
-        case MI355X_TYPE_Q4_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q4_0, true>(ctx, k, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q4_0, false>(ctx, k, bytes, flops);
-        case MI355X_TYPE_Q5_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q5_0, true>(ctx, k, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q5_0, false>(ctx, k, bytes, flops);
-        case MI355X_TYPE_Q8_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q8_0, true>(ctx, k, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q8_0, false>(ctx, k, bytes, flops);
-        default:               return launch_mmq_shape<MI355X_TYPE_Q4_K, false>(ctx, k, bytes, flops);
-    }
+    return hold_mmq(ctx, wt, k, bytes, flops);       // leaves with the next flush (any other launch, synchronize, end of the graph range)
 }
 
 extern "C" size_t mi355x_act_rows_bytes(int wtype, int64_t K, int64_t T) { return (qrows_bytes(wtype == MI355X_TYPE_Q4_K, K, T) + 15) & ~(size_t) 15; }
