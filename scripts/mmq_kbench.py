@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--qtype", default="q5_0")
     ap.add_argument("--what", default="fc1,fc2,oproj,qkv")
     ap.add_argument("--T", type=int, default=1500)
+    ap.add_argument("--anatomy", action="store_true", help="time the kernel with parts of its K-step switched off (GGML_MI355X_MMQ_DBG)")
     a = ap.parse_args()
     what = set(a.what.split(","))
     tid = ka.TYPE_NAMES[a.qtype]
@@ -95,6 +96,11 @@ def main():
     torch.cuda.synchronize()
 
     MMQ = [("mmq 64x128 (default)", {}), ("mmq 128x64", {"GGML_MI355X_MMQ_TILE": 12864}), ("mmq 64x128, VALU scales", {"GGML_MI355X_MMQ_SCALE_MFMA": 0})]
+    if a.anatomy:
+        # what a K-step is made of: the kernel with parts of it switched off (results are garbage, only the time counts)
+        MMQ = [("mmq 64x128 (default)", {}), ("  no MFMA / fold", {"GGML_MI355X_MMQ_DBG": 1}), ("  no global loads", {"GGML_MI355X_MMQ_DBG": 2}),
+               ("  no LDS stores (no unpack)", {"GGML_MI355X_MMQ_DBG": 4}), ("  loads + stores only", {"GGML_MI355X_MMQ_DBG": 1}),
+               ("  compute only", {"GGML_MI355X_MMQ_DBG": 6}), ("  barriers only", {"GGML_MI355X_MMQ_DBG": 7})]
 
     def cases(label, M, K, rows, act16, ep, prep):
         count = max(4, int(400e6 // (M * K * 2)))

@@ -46,6 +46,7 @@ struct MmqArgs {
     const uint16_t * gelu_tab;
     int8_t * pq; float * pd; int prep_only;                    // epilogue also leaves the Q8_0 rows of the result (K' = M): the next GEMM's B
     int mt, nt, per, m_major;                                  // tile counts and XCD-aware tile order
+    int dbg;                                                   // GGML_MI355X_MMQ_DBG (anatomy of a K-step, scripts/mmq_kbench.py): 1 no MFMA / fold, 2 no global loads after the first step, 4 no LDS stores after the first step
 };
 
 #define MQ_KS 128                      // K elements per step = bytes per tile row
@@ -484,16 +485,19 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
         if constexpr (!SMF) { if (nb_ >= 0) read_frags(st, nb_); }
     };
 
+    const bool dbg_nocomp = a.dbg & 1, dbg_noload = a.dbg & 2, dbg_nostore = a.dbg & 4;
     for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk && !dbg_noload) load_tile(kt + 1);
         const char * st = lds + (kt & 1) * STAGE;
         __builtin_amdgcn_sched_barrier(0);
-        read_frags(st, 0);
-        block(st, 1);
-        block(st, 2);
-        block(st, 3);
-        block(st, -1);
-        if (kt + 1 < nk) store_tile(kt + 1, lds + ((kt + 1) & 1) * STAGE);
+        if (!dbg_nocomp) {
+            read_frags(st, 0);
+            block(st, 1);
+            block(st, 2);
+            block(st, 3);
+            block(st, -1);
+        }
+        if (kt + 1 < nk && !dbg_nostore) store_tile(kt + 1, lds + ((kt + 1) & 1) * STAGE);
         __syncthreads();
     }
     mq_epilogue<MT, NT>(a, acc, m0 + wm*(MT*32), n0 + wn*(NT*32), lane);
@@ -670,6 +674,7 @@ static int gemm_q8act_impl(mi355x_ctx * ctx, const mi355x_tensor * A, const void
         const qrows_t P = qrows_of(prep_out, 0, M, T);
         k.pq = P.q; k.pd = P.d; k.prep_only = prep_only;
     }
+    k.dbg = getenv("GGML_MI355X_MMQ_DBG") ? atoi(getenv("GGML_MI355X_MMQ_DBG")) : 0;
     const double flops = 2.0 * M * (double) K * (double) T;
     const double bytes = (double) mi355x_type_row_bytes(wt, K) * M + (double) qrows_bytes(q8k, K, T) + (prep_only ? 0.0 : (double) T*M*(k.dst_f16 ? 2 : 4)) + (prep_out ? (double) qrows_bytes(0, M, T) : 0.0);
     return hold_mmq(ctx, wt, k, bytes, flops);       // leaves with the next flush (any other launch, synchronize, end of the graph range)
