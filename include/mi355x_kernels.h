@@ -223,8 +223,13 @@ MI355X_API int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
  * ggml-quants.c:2768-2805 Q8_K) into "planes" in HBM — byte for byte the image of the LDS planes the fused T <= 2 kernels build
  * in every workgroup — and every mat-vec workgroup only copies that image (Q8_0 family: lo[T][K/32] uint4 | hi[T][K/32] uint4 |
  * d[T][K/32] f32 | sum[T][K/32] i32; Q8_K: q[4][T][K/64] uint4 | d[T][K/256] f32 | sums[T][K/32] i32).  Same arithmetic, same
- * summation order per column as the fused kernels: a column's result does not depend on T or on which path computed it. */
-#define MI355X_MAX_COLS 8
+ * summation order per column as the fused kernels: a column's result does not depend on T or on which path computed it.
+ * More than 8 columns (cross-state batches of up to 32 states) are carried as GROUPS of 8: the planes of T columns are ceil(T/8)
+ * such images back to back, image g (columns 8g .. min(8g+8, T)-1) at byte offset g * mi355x_act_planes_bytes(wtype, K, 8); the
+ * mat-vec kernels keep their weight rows in registers and pass over the images one after the other — the weights are still read
+ * from HBM once per step, and a column's arithmetic is the one of the 8-column kernels (bit-identical for every T). */
+#define MI355X_MAX_COLS 32
+#define MI355X_IMG_COLS 8
 typedef struct mi355x_gemv_cols {
     void *        dst[3][MI355X_MAX_COLS];     /* [segment][column] */
     const float * res[3][MI355X_MAX_COLS];     /* NULL entries where the segment has no residual */
@@ -258,7 +263,7 @@ typedef struct mi355x_act_desc {
 } mi355x_act_desc;
 MI355X_API size_t mi355x_act_planes_bytes(int wtype, int K, int T);
 MI355X_API int    mi355x_act_prepare(mi355x_ctx * ctx, const mi355x_act_desc * d, void * planes);
-/* two plane buffers owned by the context (each holds any K <= 8192, T <= 8): a stage reads one while its epilogue fills the other */
+/* two plane buffers owned by the context (each holds any K <= 8192, T <= MI355X_MAX_COLS): a stage reads one while its epilogue fills the other */
 MI355X_API void * mi355x_act_scratch(mi355x_ctx * ctx, int which);
 
 

@@ -1,0 +1,49 @@
+#!/bin/bash
+# One gpurun call around the > 8-column merged chains (images of 8 columns, decode_q.hip) and the x-planted token parity test.
+# usage: scripts/gpu_cols.sh [stage ...]   stages: batchtest scaling xplant streams
+set -u
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+STAGES=${*:-batchtest scaling xplant streams}
+stage() { echo; echo "=== $1 === $(date +%T)"; }
+for s in $STAGES; do case $s in
+batchtest)
+    stage "pytest tests/test_gpu_batch.py"
+    timeout 1500 python3 -m pytest tests/test_gpu_batch.py -m gpu -q -p no:cacheprovider -x > "$OUT/pytest_batch.txt" 2>&1
+    echo "exit=$?"; tail -30 "$OUT/pytest_batch.txt"
+    ;;
+scaling)
+    stage "stream scaling, batched, large-v3 Q5_0"
+    { echo "# GGML_MI355X_BATCH_COLS=16"; GGML_MI355X_BATCH_COLS=16 timeout 600 python3 scripts/stream_scaling.py --streams 8,12,16 --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
+      echo "# GGML_MI355X_BATCH_COLS=32"; GGML_MI355X_BATCH_COLS=32 timeout 600 python3 scripts/stream_scaling.py --streams 16,24,32 --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
+    } > "$OUT/stream_scaling_cols.txt" 2>&1
+    cut -c1-260 "$OUT/stream_scaling_cols.txt"
+    ;;
+xplant)
+    stage "x-planted token parity + fault controls"
+    timeout 2400 python3 -m pytest tests/test_gpu.py -m gpu -q -p no:cacheprovider -k "cross_attention_carried" > "$OUT/pytest_xplant.txt" 2>&1
+    echo "exit=$?"; tail -30 "$OUT/pytest_xplant.txt"
+    ;;
+streams)
+    stage "concurrent streams == serial (incl. 12 and 16 streams)"
+    timeout 1800 python3 -m pytest tests/test_gpu.py -m gpu -q -p no:cacheprovider -k "concurrent_streams" > "$OUT/pytest_streams.txt" 2>&1
+    echo "exit=$?"; tail -30 "$OUT/pytest_streams.txt"
+    ;;
+trace)
+    stage "rocprofv3 kernel trace of 16 batched streams (large-v3 Q5_0, 64 steps per chunk)"
+    rm -rf "$OUT/trace16"; mkdir -p "$OUT/trace16"
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace16" -o t16 --output-format csv -- python3 "$ROOT/scripts/stream_scaling.py" --streams ${TRACE_STREAMS:-16} --batching 1 --steps 1 --n-decode 64 > "$OUT/trace16/run.log" 2>&1 )
+    echo "exit=$?"; tail -3 "$OUT/trace16/run.log" | cut -c1-300
+    f=$(find "$OUT/trace16" -name '*kernel_stats.csv' | head -1)
+    [ -n "$f" ] && { cp "$f" "$OUT/trace16_kernel_stats.csv"; head -25 "$f" | cut -c1-220; }
+    find "$OUT/trace16" -name '*kernel_trace.csv' -size +60M -delete
+    ;;
+xcd)
+    stage "XCD-local teams probe"
+    timeout 120 scripts/_bin/xcd_team_probe 32 2>&1 | tee "$OUT/xcd_team_probe.txt"
+    ;;
+esac; done
+echo; echo "=== done === $(date +%T)"

@@ -85,7 +85,7 @@ def planted_token(pos: int) -> int:
 #     contribute at the level of a random-weight model
 # sign(s_p) picks a_p or b_p; the margin is ~ g * |s_p| * (proj_a - proj_b) / rms(x).  (f, g, c) per architecture were calibrated
 # with the reference CPU path (scripts/xplant_calibrate.py; profiles/r04_xplant_calibration.txt).
-XPLANT = {"base.en": (6.0, 24.0, 3.0), "large-v3-turbo": (6.0, 24.0, 3.0), "large-v3": (6.0, 24.0, 3.0), "micro": (6.0, 24.0, 3.0), "large-v3-2l": (6.0, 24.0, 3.0)}
+XPLANT = {"base.en": (20.0, 80.0, 1.0, 0.1), "large-v3-turbo": (16.0, 120.0, 1.0, 0.1), "large-v3": (40.0, 300.0, 1.0, 0.1)}      # (f, g, c, w); calibrated architectures only
 
 
 def xplant_tables(te: np.ndarray, n_text_ctx: int, seed: int):
@@ -195,7 +195,7 @@ def write_f16_model(path: Path, arch: str, seed: int = 1234, plant=False):
         te = rng.normal((n_vocab, n_ts), 0.05).astype(np.float16)
         xp = plant == "x"
         if xp:
-            xf, xg, xc = (float(v) for v in os.environ["XPLANT_PARAMS"].split(",")) if os.environ.get("XPLANT_PARAMS") else XPLANT[arch]      # (override: calibration runs)
+            xf, xg, xc, xw = (float(v) for v in os.environ["XPLANT_PARAMS"].split(",")) if os.environ.get("XPLANT_PARAMS") else XPLANT[arch]      # (override: calibration runs)
             xu, xa, xb = xplant_tables(te, n_text_ctx, seed)
             pe = np.stack([xf * (te[xa[p]].astype(np.float32) + te[xb[p]].astype(np.float32)) for p in range(n_text_ctx)])
         elif plant:
@@ -221,6 +221,7 @@ def write_f16_model(path: Path, arch: str, seed: int = 1234, plant=False):
                 _w_tensor(f, p + "cross_attn.query.weight", (rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts)) * xc).astype(np.float16)); vec(p + "cross_attn.query.bias", n_ts)
                 _w_tensor(f, p + "cross_attn.key.weight", (rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts)) * xc).astype(np.float16))
                 wv = rng.normal((n_ts, n_ts), 1.0 / np.sqrt(n_ts))
+                wv[0, :] *= xw                               # row 0 = w of the comment above, small against the bias: s_p = 1 + O(w)
                 _w_tensor(f, p + "cross_attn.value.weight", wv.astype(np.float16))
                 bv = rng.normal((n_ts,), 0.02).astype(np.float32)
                 bv[0] = 1.0                                  # s_p = sum_k softmax_k (w . enc_k) + 1: a stable sign, still every step of the attention arithmetic

@@ -33,7 +33,7 @@ def _seg(ka, d, s, w_d, tid, N, y_d, dst_type=None, ep=None, nb1=None):
 
 
 @pytest.mark.parametrize("t", list(QT))
-@pytest.mark.parametrize("K,T", [(1280, 1), (1280, 3), (1280, 5), (1280, 8), (512, 4), (512, 7)])
+@pytest.mark.parametrize("K,T", [(1280, 1), (1280, 3), (1280, 5), (1280, 8), (512, 4), (512, 7), (1280, 9), (1280, 16), (512, 21), (1280, 32)])      # T > 8: images of 8 columns
 def test_layernorm_qkv_through_planes_is_bit_identical_to_the_fused_kernel(gpu, oracle, t, K, T):
     """LN + Q/K/V (three segments, scale / bias epilogues, F16 destinations for K and V = the KV-cache store) — src/whisper.cpp:2529-2598"""
     ctx, ka, torch = gpu
@@ -123,7 +123,7 @@ def test_layernorm_qkv_through_planes_is_bit_identical_to_the_fused_kernel(gpu, 
 
 
 @pytest.mark.parametrize("t", list(QT))
-@pytest.mark.parametrize("K,N,T", [(5120, 1280, 5), (5120, 1280, 8), (1280, 1280, 3), (2048, 512, 6), (1280, 5120, 2)])
+@pytest.mark.parametrize("K,N,T", [(5120, 1280, 5), (5120, 1280, 8), (1280, 1280, 3), (2048, 512, 6), (1280, 5120, 2), (5120, 1280, 16), (5120, 1280, 11), (1280, 5120, 32), (2048, 512, 24)])
 def test_plain_mat_vec_through_planes_with_per_column_pointers(gpu, oracle, t, K, N, T):
     """fc2 / any bias + residual projection: columns written to SCATTERED destinations (what a cross-state batch does) equal the fused
     T = 1 result of every column, bit for bit"""
@@ -175,7 +175,8 @@ def test_plain_mat_vec_through_planes_with_per_column_pointers(gpu, oracle, t, K
 
 
 @pytest.mark.parametrize("t", ["q4_0", "q5_0", "q8_0"])
-@pytest.mark.parametrize("K,N,N2,T,only", [(1280, 5120, 1280, 5, True), (1280, 5120, 1280, 8, False), (512, 2048, 512, 3, True), (384, 1536, 384, 1, False)])
+@pytest.mark.parametrize("K,N,N2,T,only", [(1280, 5120, 1280, 5, True), (1280, 5120, 1280, 8, False), (512, 2048, 512, 3, True), (384, 1536, 384, 1, False),
+                                            (1280, 5120, 1280, 16, True), (1280, 5120, 1280, 13, False), (512, 2048, 512, 32, True)])
 def test_producer_epilogue_writes_the_next_mat_vecs_planes(gpu, oracle, t, K, N, N2, T, only):
     """LN + fc1 + bias + GELU whose epilogue leaves the Q8_0 planes of its result; fc2 reads them (src/whisper.cpp:2787-2830).
     Equal, bit for bit, to fused fc1 (F32 result) -> fused fc2 for every column alone."""
@@ -294,12 +295,13 @@ def test_attention_combine_through_planes_is_bit_identical_to_the_fused_projecti
     assert np.array_equal(ya.cpu().numpy().view(np.uint32), yb.cpu().numpy().view(np.uint32))
 
 
-@pytest.mark.parametrize("t", ["q5_0", "q8_0"])
-def test_vocabulary_projection_over_planes_with_per_state_destinations(gpu, oracle, t):
-    """final LayerNorm + logits (N = 51866 goes to k_gemv8) for 8 columns that belong to 8 states"""
+@pytest.mark.parametrize("T", [8, 16, 29])
+@pytest.mark.parametrize("t", ["q5_0", "q8_0", "q4_K"])          # (Q4_K: no k_vocab — T > 8 goes image by image through k_gemv8)
+def test_vocabulary_projection_over_planes_with_per_state_destinations(gpu, oracle, t, T):
+    """final LayerNorm + logits (N = 51866: k_vocab) for T columns that belong to T states (T > 8: images of 8 columns)"""
     ctx, ka, torch = gpu
     tid = QT[t]
-    K, N, T = 1280, 51866, 8
+    K, N = 1280, 51866
     rng = np.random.default_rng(5 + tid)
     x = (rng.standard_normal((T, K)) * 2).astype(np.float32)
     lw = (1 + 0.1 * rng.standard_normal(K)).astype(np.float32)
@@ -307,7 +309,7 @@ def test_vocabulary_projection_over_planes_with_per_state_destinations(gpu, orac
     _, planar = quantize(oracle, ka, tid, (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32))
     x_d, lw_d, lb_d, w_d = dev(torch, x), dev(torch, lw), dev(torch, lb), dev(torch, planar)
     alone = []
-    for c in (0, 3, 7):
+    for c in (0, 3, 7, T // 2 + 1, T - 1):
         y = torch.zeros((1, N), dtype=torch.float32, device="cuda:0")
         d = ka.GemvDesc()
         d.x, d.x_nb1, d.K, d.T, d.nseg, d.has_norm, d.eps, d.ln_w, d.ln_b = x_d.data_ptr() + c * K * 4, K * 4, K, 1, 1, 1, 1e-5, lw_d.data_ptr(), lb_d.data_ptr()
@@ -375,7 +377,8 @@ def test_vocabulary_projection_mirror_rows_equal_the_destination_rows(gpu, oracl
         assert np.array_equal(got[c].view(np.uint32), m[c].view(np.uint32)), (t, K, T, c, int((got[c] != m[c]).sum()))
 
 
-@pytest.mark.parametrize("S,H,kvs,masked", [(8, 20, (1, 17, 128, 129, 200, 255, 256, 77), True), (3, 8, (1536, 1536, 1536), False), (2, 6, (300, 5), True)])
+@pytest.mark.parametrize("S,H,kvs,masked", [(8, 20, (1, 17, 128, 129, 200, 255, 256, 77), True), (3, 8, (1536, 1536, 1536), False), (2, 6, (300, 5), True),
+                                            (16, 20, tuple(range(3, 448, 28)), True), (19, 8, (1500,) * 19, False)])
 def test_multi_state_attention_is_bit_identical_to_one_launch_per_state(gpu, S, H, kvs, masked):
     ctx, ka, torch = gpu
     D = 64
@@ -419,7 +422,8 @@ def test_multi_state_attention_is_bit_identical_to_one_launch_per_state(gpu, S, 
 
 
 @pytest.mark.parametrize("S,H,kvs,masked", [(8, 20, (1, 17, 128, 129, 200, 255, 256, 448), True), (5, 8, (33, 512, 64, 300, 2), True), (3, 6, (100, 100, 100), False),
-                                            (8, 20, (1500,) * 8, False), (4, 8, (1500, 513, 1024, 1025), True), (3, 6, (1536, 7, 900), False)])
+                                            (8, 20, (1500,) * 8, False), (4, 8, (1500, 513, 1024, 1025), True), (3, 6, (1536, 7, 900), False),
+                                            (16, 20, tuple(range(5, 448, 28)), True), (11, 8, (40,) * 11, True), (32, 6, tuple(range(1, 449, 14)), True)])
 def test_self_attention_straight_to_planes_is_bit_identical_to_partials_combine_quantize(gpu, S, H, kvs, masked):
     """mi355x_flash_attn_planes (one launch; one, two or three rounds of 512 keys: self-attention and the 1500 keys of cross-attention) writes
     the same Q8_0 plane bytes as multi-state attention partials -> mi355x_act_prepare"""
@@ -494,7 +498,7 @@ def test_multi_state_step_head_matches_get_rows_and_cast(gpu, oracle, t):
 # ---------------------------------------------------------------------------------------------------------------
 # the whole thing through the unmodified reference host: S whisper_states on one device, one C++ thread each (native harness)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("arch,qtype,streams", [("base.en", "q5_0", 4), ("base.en", "q4_k", 8), ("large-v3-2l", "q8_0", 8)])
+@pytest.mark.parametrize("arch,qtype,streams", [("base.en", "q5_0", 4), ("base.en", "q4_k", 8), ("large-v3-2l", "q8_0", 8), ("base.en", "q5_0", 16), ("large-v3-2l", "q8_0", 11)])
 def test_cross_state_batching_is_bit_identical_to_one_launch_chain_per_state(arch, qtype, streams):
     """every stream's final logits with the plugin's cross-state batching (the states' decode steps as the columns of one launch chain)
     equal, bit for bit, the same streams run with one launch chain per state — and merged chains did carry several columns"""
@@ -512,6 +516,8 @@ def test_cross_state_batching_is_bit_identical_to_one_launch_chain_per_state(arc
         if batching:
             st = r["batch_stats"]
             assert st["chains"] > 0 and st["columns"] > 1.5 * st["chains"] and st["fallbacks"] == 0, st
+            if streams > 8:
+                assert st["columns"] > 8 * st["chains"], st                 # chains of more than one image of 8 columns did run
         else:
             assert r["batch_stats"]["chains"] == 0, r["batch_stats"]
     h.run(m, use_gpu=True, n_devices=1, streams=1, n_decode=1, steps=1, warmup=0, batching=0)      # leave the switch off for whoever runs next

@@ -189,7 +189,7 @@ def test_committed_pmc_traffic_covers_the_benchmarked_kernels():
     """bench.py looks the dominant kernel up in profiles/pmc_traffic.json by its demangled name without the argument list"""
     k = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["kernels"]
     for name in ("void k_fattn_dec<1>", "void k_gemv_row<6, 1, 1, 2, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 4>",
-                 "void k_vocab<6, 1, 5>", "void k_gemv_q<6, 8, 1, true, 1, false, false>"):
+                 "void k_vocab<6, 1, 5, 1>", "void k_gemv_q<6, 8, 1, true, 1, false, false, false>"):
         assert name in k and k[name]["hbm_bytes_per_launch"] > 0, name
     ring = [n for n in k if n.startswith("void k_gemm_f16_ring<64, 4")]      # (r03: a third template argument, the tile's row count)
     assert ring and k[ring[0]]["hbm_bytes_per_launch"] > 0
@@ -208,8 +208,8 @@ def test_no_kernel_spills_to_scratch():
     assert not spilled, spilled[:10]
     by = {k["demangled"]: k for k in ks}
     for name in ("k_gemv_row<6, 1, 1, 0, true, 1>", "k_gemv_row<6, 1, 1, 1, true, 1>", "k_gemv_row<6, 1, 1, 1, false, 1>", "k_gemv_row<6, 1, 1, 2, true, 1>",
-                 "k_gemv_q<6, 8, 1, true, 1, false, false>", "k_gemv_q<6, 8, 3, true, 1, false, false>", "k_gemv_q<6, 8, 1, true, 1, false, true>",
-                 "k_gemv_q<6, 8, 1, false, 1, false, true>", "k_gemv_q<6, 8, 1, true, 4, true, true>"):
+                 "k_gemv_q<6, 8, 1, true, 1, false, false, false>", "k_gemv_q<6, 8, 3, true, 1, false, false, false>", "k_gemv_q<6, 8, 1, true, 1, false, true, false>",
+                 "k_gemv_q<6, 8, 1, false, 1, false, true, false>", "k_gemv_q<6, 8, 1, true, 4, true, true, false>"):
         assert by[name]["vgpr_count"] <= 128, (name, by[name])
     assert by["k_gemm_f16_ring<64, 4, 128>"]["agpr_count"] == 32 and by["k_gemm_f16_ring<128, 2, 128>"]["agpr_count"] == 64      # accumulators live in AGPRs
 
@@ -248,8 +248,8 @@ def test_ring_gemm_loop_never_drains_the_dma_queue(tmp_path):
 @pytest.mark.parametrize("mangled,min_loads", [("_Z10k_gemv_rowILi6ELi1ELi1ELi1ELb1ELi1EEv6DGArgs", 8),      # LN + mat-vec
                                                ("_Z10k_gemv_rowILi6ELi1ELi1ELi2ELb1ELi1EEv6DGArgs", 27),     # attention combine + mat-vec
                                                ("_Z10k_gemv_rowILi6ELi1ELi1ELi1ELb0ELi1EEv6DGArgs", 8),      # LN + Q/K/V
-                                               ("_Z8k_gemv_qILi6ELi8ELi1ELb1ELi1ELb0ELb0EEv6QGArgs", 10),        # mat-vec over pre-quantized planes (T <= 8)
-                                               ("_Z8k_gemv_qILi6ELi8ELi1ELb0ELi1ELb0ELb1EEv6QGArgs", 12)])       # LN of 8 columns + Q/K/V in the plane kernel
+                                               ("_Z8k_gemv_qILi6ELi8ELi1ELb1ELi1ELb0ELb0ELb0EEv6QGArgs", 10),        # mat-vec over pre-quantized planes (T <= 8)
+                                               ("_Z8k_gemv_qILi6ELi8ELi1ELb0ELi1ELb0ELb1ELb0EEv6QGArgs", 12)])       # LN of 8 columns + Q/K/V in the plane kernel
 def test_decode_matvec_issues_all_loads_in_one_burst(mangled, min_loads):
     """ISA of the built decode kernels: every global load of the kernel body is issued before the FIRST vmcnt wait, and that
     wait is a counted one that leaves the weight stream in flight.  This is the property that took the projection inside

@@ -1557,7 +1557,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         static const int planes_min_t = getenv("GGML_MI355X_PLANES_MIN_T") ? atoi(getenv("GGML_MI355X_PLANES_MIN_T")) : 3;
         if (b->fuse && !b->exact && (n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_NORM || n->op == GGML_OP_FLASH_ATTN_EXT)) {
             const int64_t Tn = n->op == GGML_OP_FLASH_ATTN_EXT ? n->src[0]->ne[1] : (n->op == GGML_OP_MUL_MAT ? n->src[1]->ne[1] : ggml_nrows(n->src[0]));
-            if (Tn >= planes_min_t && Tn <= MI355X_MAX_COLS) {
+            if (Tn >= planes_min_t && Tn <= MI355X_IMG_COLS) {
                 mi_colset cs; cs.S = 1; cs.T = (int) Tn; cs.g[0] = g; cs.owner[0] = b;
                 int end = i, rc2 = 0; bool took = false;
                 if (n->op == GGML_OP_NORM) { ln_chain c; parse_ln_chain(g, i, true, c); took = q_ln_gemv(b->k, cs, b->qs, i, c, end, rc2); }
@@ -1871,8 +1871,9 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
 
 static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     static const double window_ms = getenv("GGML_MI355X_BATCH_WINDOW_US") ? atof(getenv("GGML_MI355X_BATCH_WINDOW_US")) * 1e-3 : 3.0;
-    // columns per merged chain (2..8): with fewer columns than decoding states several chains run side by side (MI_BATCH_LANES streams)
-    static const int max_cols = std::max(2, std::min(MI355X_MAX_COLS, getenv("GGML_MI355X_BATCH_COLS") ? atoi(getenv("GGML_MI355X_BATCH_COLS")) : MI355X_MAX_COLS));
+    // columns per merged chain (2..32, default 16): with fewer columns than decoding states several chains run side by side (MI_BATCH_LANES
+    // streams).  More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still read once per chain step.
+    static const int max_cols = std::max(2, std::min(MI355X_MAX_COLS, getenv("GGML_MI355X_BATCH_COLS") ? atoi(getenv("GGML_MI355X_BATCH_COLS")) : 16));
     mi_batch_group & grp = g_batch[b->device];
     mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
     std::unique_lock<std::mutex> lk(grp.m);
@@ -2203,7 +2204,7 @@ int ggml_backend_mi355x_debug_walk(void * cgraph, int S, int64_t * out6) {
         int end = i, rc = 0; bool took = false;
         if (n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_NORM || n->op == GGML_OP_FLASH_ATTN_EXT) {
             const int64_t Tn = n->op == GGML_OP_FLASH_ATTN_EXT ? n->src[0]->ne[1] : (n->op == GGML_OP_MUL_MAT ? n->src[1]->ne[1] : ggml_nrows(n->src[0]));
-            if (Tn >= 1 && Tn <= MI355X_MAX_COLS) {
+            if (Tn >= 1 && Tn <= MI355X_IMG_COLS) {
                 mi_colset cs; cs.S = 1; cs.T = (int) Tn; cs.g[0] = g;
                 if (n->op == GGML_OP_NORM) { ln_chain c; parse_ln_chain(g, i, true, c); took = q_ln_gemv(nullptr, cs, qs, i, c, end, rc); if (took) out6[1]++; }
                 else if (n->op == GGML_OP_FLASH_ATTN_EXT) { took = q_attn_proj(nullptr, cs, qs, i, end, rc); if (took) out6[2]++; }

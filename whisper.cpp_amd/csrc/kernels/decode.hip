@@ -143,32 +143,73 @@ __global__ void __launch_bounds__(256) k_gemv8(const DGArgs a) {
     } else if (a.has_norm) {
         // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine: mean, then variance of (x - mean), y = (x-mean)*rsqrt(var+eps)*w + b
         float part[T];
+        // K <= 2048: the reduction TREE of k_act_prepare MODE 1 (decode_q.hip) — element e4 belongs to "virtual wave" e4 / 64, whose 64
+        // float4 are summed by one wave_sum, and the (up to 8) wave sums are added in wave order — so that a column normalised here
+        // (own chain, T = 1) and in a cross-state batch (k_act_prepare -> planes) carries the same bits (round 4: the strided per-thread
+        // sums used before differed from it in the last place for some columns: Q4_K vocabulary projection, K = 1280).  Larger K keeps
+        // the strided form (no plane pipeline there).
+        const bool vtree = K4 <= 512;
+        const int nvw = (K4 + 63) >> 6;
         #pragma unroll
         for (int t = 0; t < T; t++) {
-            float s = 0.0f;
-            for (int e4 = tid; e4 < K4; e4 += nthreads) { const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4); s += (v.x + v.y) + (v.z + v.w); }
-            s = wave_sum(s);
-            if (lane == 0) red[wave*8 + t] = s;
+            if (vtree) {
+                for (int vw = wave; vw < nvw; vw += nwaves) {
+                    const int e4 = vw*64 + lane;
+                    float p = 0.0f;
+                    if (e4 < K4) { const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4); p += (v.x + v.y) + (v.z + v.w); }
+                    p = wave_sum(p);
+                    if (lane == 0) red[vw*8 + t] = p;
+                }
+            } else {
+                float s = 0.0f;
+                for (int e4 = tid; e4 < K4; e4 += nthreads) { const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4); s += (v.x + v.y) + (v.z + v.w); }
+                s = wave_sum(s);
+                if (lane == 0) red[wave*8 + t] = s;
+            }
         }
         __syncthreads();
         float mean[T];
         #pragma unroll
-        for (int t = 0; t < T; t++) { float s = 0.0f; for (int w = 0; w < nwaves; w++) s += red[w*8 + t]; mean[t] = s / K; }
+        for (int t = 0; t < T; t++) {
+            float s = 0.0f;
+            if (vtree) { for (int w = 0; w < 8; w++) { const float pw = red[(w < nvw ? w : 0)*8 + t]; s += w < nvw ? pw : 0.0f; } }
+            else for (int w = 0; w < nwaves; w++) s += red[w*8 + t];
+            mean[t] = s / K;
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int t = 0; t < T; t++) {
+            if (vtree) {
+                for (int vw = wave; vw < nvw; vw += nwaves) {
+                    const int e4 = vw*64 + lane;
+                    float p = 0.0f;
+                    if (e4 < K4) {
+                        const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4);
+                        const float d0 = v.x - mean[t], d1 = v.y - mean[t], d2 = v.z - mean[t], d3 = v.w - mean[t];
+                        p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+                    }
+                    p = wave_sum(p);
+                    if (lane == 0) red[vw*8 + t] = p;
+                }
+            } else {
+                float s = 0.0f;
+                for (int e4 = tid; e4 < K4; e4 += nthreads) {
+                    const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4);
+                    const float d0 = v.x - mean[t], d1 = v.y - mean[t], d2 = v.z - mean[t], d3 = v.w - mean[t];
+                    s += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+                }
+                s = wave_sum(s);
+                if (lane == 0) red[wave*8 + t] = s;
+            }
+        }
         __syncthreads();
         #pragma unroll
         for (int t = 0; t < T; t++) {
             float s = 0.0f;
-            for (int e4 = tid; e4 < K4; e4 += nthreads) {
-                const float4 v = *(const float4 *) (stage + (size_t) t*K + e4*4);
-                const float d0 = v.x - mean[t], d1 = v.y - mean[t], d2 = v.z - mean[t], d3 = v.w - mean[t];
-                s += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
-            }
-            s = wave_sum(s);
-            if (lane == 0) red[wave*8 + t] = s;
+            if (vtree) { for (int w = 0; w < 8; w++) { const float pw = red[(w < nvw ? w : 0)*8 + t]; s += w < nvw ? pw : 0.0f; } }
+            else for (int w = 0; w < nwaves; w++) s += red[w*8 + t];
+            part[t] = 1.0f / sqrtf(s / K + a.eps);
         }
-        __syncthreads();
-        #pragma unroll
-        for (int t = 0; t < T; t++) { float s = 0.0f; for (int w = 0; w < nwaves; w++) s += red[w*8 + t]; part[t] = 1.0f / sqrtf(s / K + a.eps); }
         for (int idx = tid; idx < T*K4; idx += nthreads) {
             const int t = idx / K4, e4 = idx - t*K4;
             float mt = mean[0], sc = part[0];

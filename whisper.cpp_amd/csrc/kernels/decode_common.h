@@ -205,6 +205,13 @@ static inline __host__ __device__ size_t dg_act_bytes(int wt, int K, int T) {
     return wt == MI355X_TYPE_Q4_K ? (size_t) T * ((size_t) K + (K/256)*4 + (K/32)*4) : (size_t) T * (K/32) * 40;
 }
 
+// Planes of more than 8 columns (cross-state batches): ceil(T/8) images of <= 8 columns back to back, image g at g * dg_img_stride
+// (mi355x_kernels.h: MI355X_IMG_COLS).  T <= 8: one image, the layout above.
+static inline __host__ __device__ size_t dg_img_stride(int wt, int K) { return (dg_act_bytes(wt, K, MI355X_IMG_COLS) + 15) & ~(size_t) 15; }
+static inline __host__ __device__ size_t dg_planes_bytes(int wt, int K, int T) {
+    const int G = (T + MI355X_IMG_COLS - 1) / MI355X_IMG_COLS;
+    return (size_t) (G - 1) * dg_img_stride(wt, K) + ((dg_act_bytes(wt, K, T - MI355X_IMG_COLS*(G - 1)) + 15) & ~(size_t) 15);
+}
 
 // waves (= rows) per workgroup of k_gemv_row: enough threads for one float4 activation slot each when K <= 2048
 static inline int gemv_row_waves(int K) {

@@ -56,11 +56,13 @@ __global__ void __launch_bounds__(512) k_act_prepare(const APArgs a) {
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     const int K = a.K, K4 = K >> 2, T = a.T;
     const int t = blockIdx.x;
+    // column t lives in image t / 8 (of min(8, T - 8 (t / 8)) columns) as column t % 8
+    const int ti = t & (MI355X_IMG_COLS - 1), Ti = T - (t - ti) < MI355X_IMG_COLS ? T - (t - ti) : MI355X_IMG_COLS;
     uint32_t * lo, * hi; float * dx; int * sx;
-    planes_of<Q4K>(a.planes, K, T, lo, hi, dx, sx);
+    planes_of<Q4K>((char *) a.planes + (size_t) (t >> 3) * dg_img_stride(Q4K ? MI355X_TYPE_Q4_K : MI355X_TYPE_Q8_0, K), K, Ti, lo, hi, dx, sx);
     auto act_store = [&](const float v[4], int e) {
-        if constexpr (Q4K) dg_q8_K_store(v, e, t, K, T, lo, dx, sx);
-        else               dg_q8_0_store(v, e, t, K >> 5, lo, hi, dx, sx);
+        if constexpr (Q4K) dg_q8_K_store(v, e, ti, K, Ti, lo, dx, sx);
+        else               dg_q8_0_store(v, e, ti, K >> 5, lo, hi, dx, sx);
     };
     float4 xr[XS];
     if constexpr (MODE == 2) {
@@ -135,10 +137,10 @@ __global__ void __launch_bounds__(512) k_act_prepare(const APArgs a) {
     }
 }
 
-extern "C" size_t mi355x_act_planes_bytes(int wtype, int K, int T) { return (dg_act_bytes(wtype, K, T) + 15) & ~(size_t) 15; }
+extern "C" size_t mi355x_act_planes_bytes(int wtype, int K, int T) { return dg_planes_bytes(wtype, K, T); }
 
 extern "C" void * mi355x_act_scratch(mi355x_ctx * ctx, int which) {
-    const size_t each = (size_t) 192 << 10;          // >= planes of K = 8192, T = 8 (83 KB), read in whole 16-byte words
+    const size_t each = (size_t) 384 << 10;          // >= planes of K = 8192, T = 32 (4 images of 83 KB), read in whole 16-byte words
     if (!ctx->qact) {
         (void) hipSetDevice(ctx->device);
         if (hipMalloc(&ctx->qact, 2 * each) != hipSuccess) { (void) hipGetLastError(); ctx->qact = nullptr; return nullptr; }
@@ -174,7 +176,7 @@ extern "C" int mi355x_act_prepare(mi355x_ctx * ctx, const mi355x_act_desc * d, v
             mode = 1;
         }
     }
-    const double bytes = (double) T * K * 4 + (double) dg_act_bytes(wt, K, T);
+    const double bytes = (double) T * K * 4 + (double) dg_planes_bytes(wt, K, T);
     const dim3 grid(T);
     if (K <= 2048) {
         const dim3 block(64 * gemv_row_waves(K));
@@ -251,14 +253,20 @@ __device__ __forceinline__ void wblk_dot_q4k_rt(const wblk<MI355X_TYPE_Q4_K> & r
 // LN: no planes come in; the prologue is k_act_prepare MODE 1 for all T columns at once (LayerNorm + affine of cols.x[t], then the
 // quantizer), statement for statement, written to the LDS image instead of HBM — one dependent launch less per LayerNorm.  The
 // weights are requested first and stay in flight under it.  K <= 2048 (NU == 1).
-template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT, bool LN>
+// MG: more than one image (T > 8).  MG = false is the single-image kernel: no image loop, no prefetch registers.
+template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT, bool LN, bool MG>
 __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QGArgs a) {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
     constexpr int CP = LN ? 1 : (TMAX * (Q4K ? NU*4096*9/8 + 256 : NU*64*40) / 16 + 255) / 256;       // uint4 copy slots per thread (>= 256 threads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
-    const int K = a.K, T = a.T, nb = Q4K ? K >> 6 : K >> 5, nsb = K >> 8;
+    const int K = a.K, nb = Q4K ? K >> 6 : K >> 5, nsb = K >> 8;
+    // T columns = G images of <= 8 columns (TMAX < 8: one image).  The weights are loaded once and stay in registers; the images pass
+    // through LDS one after the other (the next one is requested while the current one is used).
+    const int Tall = a.T, G = MG ? (Tall + MI355X_IMG_COLS - 1) / MI355X_IMG_COLS : 1;
+    const size_t istride = dg_img_stride(WT, K);
+    int T = Tall < MI355X_IMG_COLS ? Tall : MI355X_IMG_COLS;          // columns of the current image
     const int ntot = a.ntot;
     const int grow = __builtin_amdgcn_readfirstlane((blockIdx.x * nwaves + wave) * R);
     int s = 0;
@@ -271,30 +279,35 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
     const QSeg & sgr = NSEG1 ? a.seg[0] : a.seg[s];
     struct { const void * w; int64_t nbt; const float * bias; float scale; int has_scale, gelu, dst_f16; } sg;
     sg.w = sgr.w; sg.nbt = sgr.nbt; sg.bias = sgr.bias; sg.scale = sgr.scale; sg.has_scale = sgr.has_scale; sg.gelu = sgr.gelu; sg.dst_f16 = sgr.dst_f16;
-    // this lane's column in the epilogue: lane r*TMAX + t finishes (row r, column t)
-    const int tl = lane % TMAX, tcol = tl < T ? tl : T - 1;
+    // this lane's column in the epilogue: lane r*TMAX + t finishes (row r, column t of the image)
+    const int tl = lane % TMAX;
     const int rlane = lane / TMAX < R ? lane / TMAX : R - 1;
-    void * dcol; const float * rcol;
     // per-column pointer tables: read straight from the kernarg segment (constant address space, scalar loads).  Taking the
     // address of the by-value argument `a` instead would force a private (scratch) copy of it.
     typedef const QGArgs __attribute__((address_space(4))) * kargs_t;
     const kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
-    {
-        const int sc = NSEG1 ? 0 : s;
-        void * d0 = ka->cols.dst[sc][0]; const float * r0 = ka->cols.res[sc][0];
+    const int sc = NSEG1 ? 0 : s;
+    // ---- destination / residual column of the lane in image gi_ (T_ columns) ----
+    int tcol; void * dcol; const float * rcol;
+    auto pick_cols = [&](int gi_, int T_) {
+        tcol = tl < T_ ? tl : T_ - 1;
+        const int c0 = gi_ * MI355X_IMG_COLS;
+        void * d0 = ka->cols.dst[sc][c0]; const float * r0 = ka->cols.res[sc][c0];
         dcol = d0; rcol = r0;
         #pragma unroll
         for (int t = 1; t < TMAX; t++) {
-            void * dv = ka->cols.dst[sc][t]; const float * rv = ka->cols.res[sc][t];
+            void * dv = ka->cols.dst[sc][c0 + t]; const float * rv = ka->cols.res[sc][c0 + t];
             asm volatile("" :: "s"(dv), "s"(rv));
             dcol = tcol == t ? dv : dcol; rcol = tcol == t ? rv : rcol;
         }
         asm volatile("" :: "s"(d0), "s"(r0));
-    }
+    };
+    pick_cols(0, T);
     asm volatile("" :: "s"(sg.w), "s"(sg.nbt), "s"(sg.bias), "s"(sg.scale), "s"(sg.has_scale), "s"(sg.gelu), "s"(sg.dst_f16), "s"(a.gelu_tab), "s"(a.planes));
 
     // ---- the load burst: plane image (L2), bias / residual, weights (HBM) last; clamped addresses, no predicates ----
-    const int n16 = (int) (((Q4K ? (size_t) T * ((size_t) K + nsb*4 + (K >> 5)*4) : (size_t) T * nb * 40) + 15) >> 4);
+    auto img_n16 = [&](int Ti) { return (int) (((Q4K ? (size_t) Ti * ((size_t) K + nsb*4 + (K >> 5)*4) : (size_t) Ti * nb * 40) + 15) >> 4); };
+    int n16 = img_n16(T);
     u32x4 cp[CP];
     float4 xr[LN ? TMAX : 1], lw, lb;
     const int K4 = K >> 2;
@@ -316,7 +329,8 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
     __builtin_amdgcn_sched_barrier(0);
     const float * bptr = sg.bias ? sg.bias + row + rlane : (const float *) a.gelu_tab;
     const float * rptr = rcol ? rcol + row + rlane : (const float *) a.gelu_tab;
-    const float bias_v = *bptr, res_v = *rptr;
+    const float bias_v = *bptr;
+    float res_v = *rptr;
     __builtin_amdgcn_sched_barrier(0);
     wblk<WT> wr[R][NU];
     {
@@ -335,196 +349,228 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- plane image -> LDS ----
-    // (unconditional stores: surplus slots land in one dummy word behind the image.  A predicated store in this loop makes the
-    //  compiler turn the predicate into a loop exit, keep the loop rolled and park cp[] in scratch memory.)
-    if constexpr (LN) {
-        __shared__ float red[2][TMAX][16];
-        uint32_t * plo, * phi; float * pdx; int * psx;
-        planes_of<Q4K>(smem, K, T, plo, phi, pdx, psx);
-        #pragma unroll
-        for (int tt = 0; tt < TMAX; tt++) {
-            float p = 0.0f;
-            if (tid < K4) p += (xr[tt].x + xr[tt].y) + (xr[tt].z + xr[tt].w);
-            p = wave_sum(p);
-            if (lane == 0) red[0][tt][wave] = p;
-        }
-        __syncthreads();
-        float mean[TMAX];
-        #pragma unroll
-        for (int tt = 0; tt < TMAX; tt++) {
-            float rs = 0.0f;
-            #pragma unroll
-            for (int w = 0; w < 8; w++) { const float pw = red[0][tt][w]; rs += w < nwaves ? pw : 0.0f; }
-            mean[tt] = rs / K;
-            float p = 0.0f;
-            if (tid < K4) {
-                const float d0 = xr[tt].x - mean[tt], d1 = xr[tt].y - mean[tt], d2 = xr[tt].z - mean[tt], d3 = xr[tt].w - mean[tt];
-                p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+    for (int gi = 0; ; gi++) {
+        // ---- plane image -> LDS ----
+        // (unconditional stores: surplus slots land in one dummy word behind the image.  A predicated store in this loop makes the
+        //  compiler turn the predicate into a loop exit, keep the loop rolled and park cp[] in scratch memory.)
+        if constexpr (LN) {
+            __shared__ float red[2][TMAX][16];
+            uint32_t * plo, * phi; float * pdx; int * psx;
+            planes_of<Q4K>(smem, K, T, plo, phi, pdx, psx);
+            if (gi > 0) {
+                const int e4c = tid < K4 ? tid : K4 - 1;
+                #pragma unroll
+                for (int tt = 0; tt < TMAX; tt++) {
+                    const float * xp = ka->cols.x[gi * MI355X_IMG_COLS + tt];
+                    xr[tt] = *(const float4 *) ((const char *) xp + (size_t) e4c*16);
+                }
             }
-            p = wave_sum(p);
-            if (lane == 0) red[1][tt][wave] = p;
-        }
-        __syncthreads();
-        #pragma unroll
-        for (int tt = 0; tt < TMAX; tt++) {
-            float rs = 0.0f;
-            #pragma unroll
-            for (int w = 0; w < 8; w++) { const float pw = red[1][tt][w]; rs += w < nwaves ? pw : 0.0f; }
-            const float rstd = 1.0f / sqrtf(rs / K + a.eps);
-            if (tt < T && tid < K4) {
-                float o[4] = { (xr[tt].x - mean[tt]) * rstd, (xr[tt].y - mean[tt]) * rstd, (xr[tt].z - mean[tt]) * rstd, (xr[tt].w - mean[tt]) * rstd };
-                o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
-                o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
-                if constexpr (Q4K) dg_q8_K_store(o, tid*4, tt, K, T, plo, pdx, psx);
-                else               dg_q8_0_store(o, tid*4, tt, K >> 5, plo, phi, pdx, psx);
-            }
-        }
-    } else {
-        #pragma unroll
-        for (int i = 0; i < CP; i++) {
-            const int idx = tid + i*nthreads;
-            ((u32x4 *) smem)[idx < n16 ? idx : n16] = cp[i];
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);          // nothing that needs the WEIGHTS may move above the barrier: they are still in flight while the planes settle
-    const uint4 * alo = (const uint4 *) smem;
-    const uint4 * ahi = alo + (size_t) T*nb;
-    const float * dx = Q4K ? (const float *) (smem + (size_t) T*K) : (const float *) (ahi + (size_t) T*nb);
-    const int *   sx = Q4K ? (const int *) (dx + T*nsb) : (const int *) (dx + T*nb);
-
-    // ---- dot products: lane handles units lane (+64, +128) of the wave's rows; clamped duplicates carry weight 0 ----
-    float acc[R][TMAX];
-    #pragma unroll
-    for (int r = 0; r < R; r++)
-        #pragma unroll
-        for (int t = 0; t < TMAX; t++) acc[r][t] = 0.0f;
-    if constexpr (Q4K) {
-        #pragma unroll
-        for (int r = 0; r < R; r++) {
-            float accm[TMAX];
-            #pragma unroll
-            for (int t = 0; t < TMAX; t++) accm[t] = 0.0f;
-            #pragma unroll
-            for (int u = 0; u < NU; u++) {
-                const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
-                wblk_dot_q4k_rt<TMAX>(wr[r][u], gc, g < nb ? 1.0f : 0.0f, nb, nsb, T, alo, dx, sx, acc[r], accm);
-            }
-            #pragma unroll
-            for (int t = 0; t < TMAX; t++) acc[r][t] += accm[t];
-        }
-    } else {
-        #pragma unroll
-        for (int u = 0; u < NU; u++) {
-            const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
-            uint32_t vlo[R][4], vhi[R][4];
-            float dw[R];
-            #pragma unroll
-            for (int r = 0; r < R; r++) {
-                wblk_unpack<WT>(wr[r][u], vlo[r], vhi[r]);
-                dw[r] = g < nb ? h2f(wr[r][u].d) : 0.0f;
-            }
-            constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
             #pragma unroll
             for (int tt = 0; tt < TMAX; tt++) {
-                const int t = tt < T ? tt : T - 1;
-                const uint4 al = alo[(size_t) t*nb + gc], ah = ahi[(size_t) t*nb + gc];
-                const int sxv = off ? sx[t*nb + gc] : 0;
-                const float dxv = dx[t*nb + gc];
+                float p = 0.0f;
+                if (tid < K4) p += (xr[tt].x + xr[tt].y) + (xr[tt].z + xr[tt].w);
+                p = wave_sum(p);
+                if (lane == 0) red[0][tt][wave] = p;
+            }
+            __syncthreads();
+            float mean[TMAX];
+            #pragma unroll
+            for (int tt = 0; tt < TMAX; tt++) {
+                float rs = 0.0f;
                 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    int sum = 0;
-                    sum = __builtin_amdgcn_sdot4((int) vlo[r][0], (int) al.x, sum, false);
-                    sum = __builtin_amdgcn_sdot4((int) vlo[r][1], (int) al.y, sum, false);
-                    sum = __builtin_amdgcn_sdot4((int) vlo[r][2], (int) al.z, sum, false);
-                    sum = __builtin_amdgcn_sdot4((int) vlo[r][3], (int) al.w, sum, false);
-                    sum = __builtin_amdgcn_sdot4((int) vhi[r][0], (int) ah.x, sum, false);
-                    sum = __builtin_amdgcn_sdot4((int) vhi[r][1], (int) ah.y, sum, false);
-                    sum = __builtin_amdgcn_sdot4((int) vhi[r][2], (int) ah.z, sum, false);
-                    sum = __builtin_amdgcn_sdot4((int) vhi[r][3], (int) ah.w, sum, false);
-                    if (off) sum -= off * sxv;
-                    acc[r][tt] = fmaf(dw[r] * dxv, (float) sum, acc[r][tt]);
+                for (int w = 0; w < 8; w++) { const float pw = red[0][tt][w]; rs += w < nwaves ? pw : 0.0f; }
+                mean[tt] = rs / K;
+                float p = 0.0f;
+                if (tid < K4) {
+                    const float d0 = xr[tt].x - mean[tt], d1 = xr[tt].y - mean[tt], d2 = xr[tt].z - mean[tt], d3 = xr[tt].w - mean[tt];
+                    p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
+                }
+                p = wave_sum(p);
+                if (lane == 0) red[1][tt][wave] = p;
+            }
+            __syncthreads();
+            #pragma unroll
+            for (int tt = 0; tt < TMAX; tt++) {
+                float rs = 0.0f;
+                #pragma unroll
+                for (int w = 0; w < 8; w++) { const float pw = red[1][tt][w]; rs += w < nwaves ? pw : 0.0f; }
+                const float rstd = 1.0f / sqrtf(rs / K + a.eps);
+                if (tt < T && tid < K4) {
+                    float o[4] = { (xr[tt].x - mean[tt]) * rstd, (xr[tt].y - mean[tt]) * rstd, (xr[tt].z - mean[tt]) * rstd, (xr[tt].w - mean[tt]) * rstd };
+                    o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
+                    o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
+                    if constexpr (Q4K) dg_q8_K_store(o, tid*4, tt, K, T, plo, pdx, psx);
+                    else               dg_q8_0_store(o, tid*4, tt, K >> 5, plo, phi, pdx, psx);
+                }
+            }
+        } else {
+            #pragma unroll
+            for (int i = 0; i < CP; i++) {
+                const int idx = tid + i*nthreads;
+                ((u32x4 *) smem)[idx < n16 ? idx : n16] = cp[i];
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);          // nothing that needs the WEIGHTS may move above the barrier: they are still in flight while the planes settle
+        const int Tn = Tall - (gi + 1) * MI355X_IMG_COLS < MI355X_IMG_COLS ? Tall - (gi + 1) * MI355X_IMG_COLS : MI355X_IMG_COLS;      // columns of the next image
+        if constexpr (!LN && MG) {
+            if (gi + 1 < G) {           // the next image: in flight under this image's dots
+                n16 = img_n16(Tn);
+                const u32x4 * nxt = (const u32x4 *) ((const char *) a.planes + (size_t) (gi + 1) * istride);
+                #pragma unroll
+                for (int i = 0; i < CP; i++) {
+                    const int idx = tid + i*nthreads;
+                    cp[i] = nxt[idx < n16 ? idx : n16 - 1];
                 }
             }
         }
-    }
-    #pragma unroll
-    for (int r = 0; r < R; r++)
+        const uint4 * alo = (const uint4 *) smem;
+        const uint4 * ahi = alo + (size_t) T*nb;
+        const float * dx = Q4K ? (const float *) (smem + (size_t) T*K) : (const float *) (ahi + (size_t) T*nb);
+        const int *   sx = Q4K ? (const int *) (dx + T*nsb) : (const int *) (dx + T*nb);
+
+        // ---- dot products: lane handles units lane (+64, +128) of the wave's rows; clamped duplicates carry weight 0 ----
+        float acc[R][TMAX];
         #pragma unroll
-        for (int t = 0; t < TMAX; t++) acc[r][t] = wave_sum(acc[r][t]);
-    float v = acc[0][0];
-    #pragma unroll
-    for (int r = 0; r < R; r++)
+        for (int r = 0; r < R; r++)
+            #pragma unroll
+            for (int t = 0; t < TMAX; t++) acc[r][t] = 0.0f;
+        if constexpr (Q4K) {
+            #pragma unroll
+            for (int r = 0; r < R; r++) {
+                float accm[TMAX];
+                #pragma unroll
+                for (int t = 0; t < TMAX; t++) accm[t] = 0.0f;
+                #pragma unroll
+                for (int u = 0; u < NU; u++) {
+                    const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+                    wblk_dot_q4k_rt<TMAX>(wr[r][u], gc, g < nb ? 1.0f : 0.0f, nb, nsb, T, alo, dx, sx, acc[r], accm);
+                }
+                #pragma unroll
+                for (int t = 0; t < TMAX; t++) acc[r][t] += accm[t];
+            }
+        } else {
+            #pragma unroll
+            for (int u = 0; u < NU; u++) {
+                const int g = lane + 64*u, gc = g < nb ? g : nb - 1;
+                uint32_t vlo[R][4], vhi[R][4];
+                float dw[R];
+                #pragma unroll
+                for (int r = 0; r < R; r++) {
+                    wblk_unpack<WT>(wr[r][u], vlo[r], vhi[r]);
+                    dw[r] = g < nb ? h2f(wr[r][u].d) : 0.0f;
+                }
+                constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+                #pragma unroll
+                for (int tt = 0; tt < TMAX; tt++) {
+                    const int t = tt < T ? tt : T - 1;
+                    const uint4 al = alo[(size_t) t*nb + gc], ah = ahi[(size_t) t*nb + gc];
+                    const int sxv = off ? sx[t*nb + gc] : 0;
+                    const float dxv = dx[t*nb + gc];
+                    #pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        int sum = 0;
+                        sum = __builtin_amdgcn_sdot4((int) vlo[r][0], (int) al.x, sum, false);
+                        sum = __builtin_amdgcn_sdot4((int) vlo[r][1], (int) al.y, sum, false);
+                        sum = __builtin_amdgcn_sdot4((int) vlo[r][2], (int) al.z, sum, false);
+                        sum = __builtin_amdgcn_sdot4((int) vlo[r][3], (int) al.w, sum, false);
+                        sum = __builtin_amdgcn_sdot4((int) vhi[r][0], (int) ah.x, sum, false);
+                        sum = __builtin_amdgcn_sdot4((int) vhi[r][1], (int) ah.y, sum, false);
+                        sum = __builtin_amdgcn_sdot4((int) vhi[r][2], (int) ah.z, sum, false);
+                        sum = __builtin_amdgcn_sdot4((int) vhi[r][3], (int) ah.w, sum, false);
+                        if (off) sum -= off * sxv;
+                        acc[r][tt] = fmaf(dw[r] * dxv, (float) sum, acc[r][tt]);
+                    }
+                }
+            }
+        }
         #pragma unroll
-        for (int t = 0; t < TMAX; t++) if (r + t > 0) v = (lane == r*TMAX + t) ? acc[r][t] : v;
-    const bool mine = rok && lane < R*TMAX && tl < T;
-    if (mine) {
-        if (sg.bias)      v = v + bias_v;
-        if (sg.has_scale) v = v * sg.scale;
-        if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
-        if (rcol)         v = v + res_v;
-    }
-    if constexpr (POUT) {
-        // the 32 rows of this workgroup are one Q8_0 block of the result for every column: tile[t][32] -> quantize -> planes of K' = ntot
-        float * tile = (float *) (smem + (((size_t) n16 + 1) << 4));
-        if (mine) tile[tcol*32 + wave*R + rlane] = v;
-        if (mine && !a.planes_only) {
-            if (sg.dst_f16) ((uint16_t *) dcol)[row + rlane] = f2h(v); else ((float *) dcol)[row + rlane] = v;
-        }
-        __syncthreads();
-        if (tid < T*8) {
-            const int t = tid >> 3, q = tid & 7;
-            const float4 x4 = *(const float4 *) (tile + t*32 + q*4);
-            const float xv[4] = { x4.x, x4.y, x4.z, x4.w };
-            const int nbo = ntot >> 5;
-            uint32_t * olo = (uint32_t *) a.planes_out, * ohi = olo + (size_t) T*nbo*4;
-            float * odx = (float *) (ohi + (size_t) T*nbo*4);
-            int * osx = (int *) (odx + T*nbo);
-            dg_q8_0_store(xv, (int) blockIdx.x*32 + q*4, t, nbo, olo, ohi, odx, osx);
-        }
-    } else {
+        for (int r = 0; r < R; r++)
+            #pragma unroll
+            for (int t = 0; t < TMAX; t++) acc[r][t] = wave_sum(acc[r][t]);
+        float v = acc[0][0];
+        #pragma unroll
+        for (int r = 0; r < R; r++)
+            #pragma unroll
+            for (int t = 0; t < TMAX; t++) if (r + t > 0) v = (lane == r*TMAX + t) ? acc[r][t] : v;
+        const bool mine = rok && lane < R*TMAX && tl < T;
         if (mine) {
-            if (sg.dst_f16) ((uint16_t *) dcol)[row + rlane] = f2h(v); else ((float *) dcol)[row + rlane] = v;
+            if (sg.bias)      v = v + bias_v;
+            if (sg.has_scale) v = v * sg.scale;
+            if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
+            if (rcol)         v = v + res_v;
         }
+        if constexpr (POUT) {
+            // the 32 rows of this workgroup are one Q8_0 block of the result for every column: tile[t][32] -> quantize -> planes of K' = ntot
+            // (behind the largest image + its dummy word: the image of a later group never reaches it)
+            float * tile = (float *) (smem + (((size_t) img_n16(Tall < MI355X_IMG_COLS ? Tall : MI355X_IMG_COLS) + 1) << 4));
+            if (mine) tile[tcol*32 + wave*R + rlane] = v;
+            if (mine && !a.planes_only) {
+                if (sg.dst_f16) ((uint16_t *) dcol)[row + rlane] = f2h(v); else ((float *) dcol)[row + rlane] = v;
+            }
+            __syncthreads();
+            if (tid < T*8) {
+                const int t = tid >> 3, q = tid & 7;
+                const float4 x4 = *(const float4 *) (tile + t*32 + q*4);
+                const float xv[4] = { x4.x, x4.y, x4.z, x4.w };
+                const int nbo = ntot >> 5;
+                uint32_t * olo = (uint32_t *) ((char *) a.planes_out + (size_t) gi * dg_img_stride(MI355X_TYPE_Q8_0, ntot)), * ohi = olo + (size_t) T*nbo*4;
+                float * odx = (float *) (ohi + (size_t) T*nbo*4);
+                int * osx = (int *) (odx + T*nbo);
+                dg_q8_0_store(xv, (int) blockIdx.x*32 + q*4, t, nbo, olo, ohi, odx, osx);
+            }
+        } else {
+            if (mine) {
+                if (sg.dst_f16) ((uint16_t *) dcol)[row + rlane] = f2h(v); else ((float *) dcol)[row + rlane] = v;
+            }
+        }
+        if (!MG || gi + 1 >= G) break;
+        __syncthreads();                        // every wave is done with this image (and with the result tile) before the next one lands
+        T = Tn;
+        pick_cols(gi + 1, T);
+        res_v = *(rcol ? rcol + row + rlane : (const float *) a.gelu_tab);
     }
 }
 
-template <int WT, int TMAX, int NU>
+template <int WT, int TMAX, int NU, bool MG>
 static int launch_gemv_q_v(mi355x_ctx * ctx, const QGArgs & k, bool nseg1, bool pout, bool ln, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv_q";
     if constexpr (NU == 1) {
         if (ln) {
             if constexpr (WT != MI355X_TYPE_Q4_K) {
-                if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, true>, grid, block, lds, k, bytes, flops);
-                if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, true>, grid, block, lds, k, bytes, flops);
+                if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, true, MG>, grid, block, lds, k, bytes, flops);
             }
             if (pout) return MI355X_E_UNSUPPORTED;
-            if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, true>, grid, block, lds, k, bytes, flops);
-            return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, true>, grid, block, lds, k, bytes, flops);
+            if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, true, MG>, grid, block, lds, k, bytes, flops);
+            return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, true, MG>, grid, block, lds, k, bytes, flops);
         }
     }
     if (ln) return MI355X_E_UNSUPPORTED;
     if constexpr (NU == 1 && WT != MI355X_TYPE_Q4_K) {
-        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, false>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
-        if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, false>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
+        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, false, MG>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
+        if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, false, MG>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
     }
     if (pout) return MI355X_E_UNSUPPORTED;
-    if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, false>, grid, block, lds, k, bytes, flops);
-    if constexpr (NU == 1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, false>, grid, block, lds, k, bytes, flops);
+    if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, false, MG>, grid, block, lds, k, bytes, flops);
+    if constexpr (NU == 1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, false, MG>, grid, block, lds, k, bytes, flops);
     return MI355X_E_UNSUPPORTED;
 }
 template <int WT>
 static int launch_gemv_q(mi355x_ctx * ctx, const QGArgs & k, int nu, bool nseg1, bool pout, bool ln, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     constexpr int NUBIG = WT == MI355X_TYPE_Q4_K ? 2 : 3;
     if (k.T <= 4) {
-        if (nu == 1) return launch_gemv_q_v<WT, 4, 1>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
+        if (nu == 1) return launch_gemv_q_v<WT, 4, 1, false>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
         if (pout || ln) return MI355X_E_UNSUPPORTED;
-        return launch_gemv_q_v<WT, 4, NUBIG>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
+        return launch_gemv_q_v<WT, 4, NUBIG, false>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
     }
-    if (nu == 1) return launch_gemv_q_v<WT, 8, 1>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
+    if (k.T <= MI355X_IMG_COLS) {
+        if (nu == 1) return launch_gemv_q_v<WT, 8, 1, false>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
+        if (pout || ln) return MI355X_E_UNSUPPORTED;
+        return launch_gemv_q_v<WT, 8, NUBIG, false>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
+    }
+    if (nu == 1) return launch_gemv_q_v<WT, 8, 1, true>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
     if (pout || ln) return MI355X_E_UNSUPPORTED;
-    return launch_gemv_q_v<WT, 8, NUBIG>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
+    return launch_gemv_q_v<WT, 8, NUBIG, true>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
 }
 
 // mat-vec over pre-quantized activation planes; MI355X_E_UNSUPPORTED: the caller tries k_gemv8 (which copies the same image)
@@ -579,14 +625,15 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         if (q4k || d->nseg != 1 || ntot % 32 || nu != 1 || ((uintptr_t) d->planes_out % 16)) return MI355X_E_UNSUPPORTED;
         k.planes_out = d->planes_out; k.planes_only = d->planes_out_only;
     }
-    const size_t img = (dg_act_bytes(wt, K, T) + 15) & ~(size_t) 15;
-    const size_t lds = img + 16 + (pout ? (size_t) MI355X_MAX_COLS * 32 * 4 : 0);      // image | dummy word | result tile
+    const size_t img = (dg_act_bytes(wt, K, T < MI355X_IMG_COLS ? T : MI355X_IMG_COLS) + 15) & ~(size_t) 15;      // one image of <= 8 columns at a time
+    const size_t lds = img + 16 + (pout ? (size_t) MI355X_IMG_COLS * 32 * 4 : 0);      // image | dummy word | result tile
     if (lds > 64 * 1024) return MI355X_E_UNSUPPORTED;
     // the 32 rows of a planes-out workgroup: 8 waves x 4 rows or 16 waves x 2 rows (GGML_MI355X_POUT_ROWS; more waves = more loads in flight per CU)
     static const int pout_rows = getenv("GGML_MI355X_POUT_ROWS") && atoi(getenv("GGML_MI355X_POUT_ROWS")) == 2 ? 2 : 4;
-    const int waves = pout ? 32 / pout_rows : gemv_row_waves(K), rpb = pout ? 32 : waves;
+    const int prows = ln ? 4 : pout_rows;                 // (the LayerNorm form keeps T float4 per thread: 8 waves x 4 rows only)
+    const int waves = pout ? 32 / prows : gemv_row_waves(K), rpb = pout ? 32 : waves;
     const dim3 grid((ntot + rpb - 1) / rpb), block(64 * waves);
-    const double bytes = wbytes + (ln ? (double) T*K*4 : (double) dg_act_bytes(wt, K, T)) + (double) ntot*T*4;
+    const double bytes = wbytes + (ln ? (double) T*K*4 : (double) dg_planes_bytes(wt, K, T)) + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;
     switch (wt) {
         case MI355X_TYPE_Q4_0: return launch_gemv_q<MI355X_TYPE_Q4_0>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
@@ -619,13 +666,15 @@ struct VArgs {
     void * dstcol[MI355X_MAX_COLS]; void * mircol[MI355X_MAX_COLS];
 };
 
-template <int WT, int TMAX, int U>
+// NG: images of 8 columns (T > 8: cross-state batches, prepared planes only); the row groups' weights are unpacked once and meet every image.
+template <int WT, int TMAX, int U, int NG>
 __global__ void __launch_bounds__(512) k_vocab(const VArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[2][TMAX][8];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r8 = lane >> 3, j8 = lane & 7;
-    const int K = a.K, T = a.T, N = a.N;
+    const int K = a.K, Tall = a.T, N = a.N;
+    const int T = NG == 1 ? Tall : MI355X_IMG_COLS;          // columns of image 0 (NG > 1: full)
     constexpr int nb = U * 8;
     const int ngroups = (N + 7) >> 3;
     const int stride = gridDim.x * 8;
@@ -634,7 +683,7 @@ __global__ void __launch_bounds__(512) k_vocab(const VArgs a) {
     // ---- loads: activations (L2) first, then two row groups of weights (HBM) ----
     const int K4 = K >> 2, e4c = tid < K4 ? tid : K4 - 1;
     float4 xr[TMAX], lw, lb;
-    if (a.has_norm) {
+    if (NG == 1 && a.has_norm) {
         #pragma unroll
         for (int tt = 0; tt < TMAX; tt++) xr[tt] = *(const float4 *) ((const char *) a.x + (int64_t) (tt < T ? tt : T - 1)*a.x_nb1 + (size_t) e4c*16);
         lw = *(const float4 *) (a.ln_w + e4c*4); lb = *(const float4 *) (a.ln_b + e4c*4);
@@ -654,7 +703,7 @@ __global__ void __launch_bounds__(512) k_vocab(const VArgs a) {
     // ---- prologue: activation planes in LDS ----
     uint32_t * plo, * phi; float * pdx; int * psx;
     planes_of<false>(smem, K, T, plo, phi, pdx, psx);
-    if (a.has_norm) {
+    if (NG == 1 && a.has_norm) {
         // k_act_prepare MODE 1, all columns at once (blockDim 512: waves >= K4/64 contribute zeros)
         #pragma unroll
         for (int tt = 0; tt < TMAX; tt++) {
@@ -694,24 +743,29 @@ __global__ void __launch_bounds__(512) k_vocab(const VArgs a) {
             }
         }
     } else {
-        const int n16 = (int) ((dg_act_bytes(WT, K, T) + 15) >> 4);
+        const int n16 = (int) (dg_planes_bytes(WT, K, Tall) >> 4);          // all images, as they lie in HBM
         for (int idx = tid; idx < n16; idx += 512) ((u32x4 *) smem)[idx] = ((const u32x4 *) a.xq)[idx];
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    const uint4 * alo = (const uint4 *) plo, * ahi = (const uint4 *) phi;
     constexpr int off = WT == MI355X_TYPE_Q5_0 ? 16 : (WT == MI355X_TYPE_Q4_0 ? 8 : 0);
+    const size_t istride = dg_img_stride(WT, K);
 
     // T = 1: this lane's activation blocks never change
     uint4 ral[TMAX == 1 ? U : 1], rah[TMAX == 1 ? U : 1]; float rdx[TMAX == 1 ? U : 1]; int rsx[TMAX == 1 ? U : 1];
     if constexpr (TMAX == 1) {
+        const uint4 * alo = (const uint4 *) plo, * ahi = (const uint4 *) phi;
         #pragma unroll
         for (int u = 0; u < U; u++) { const int g = j8 + 8*u; ral[u] = alo[g]; rah[u] = ahi[g]; rdx[u] = pdx[g]; rsx[u] = off * psx[g]; }
     }
-    // this lane's destination column (lane j8 == t finishes column t)
-    float * dcol = (float *) a.dstcol[0]; float * mcol = (float *) a.mircol[0];
+    // this lane's destination columns (lane j8 == t finishes column t of every image)
+    float * dcol[NG], * mcol[NG];
     #pragma unroll
-    for (int t = 1; t < TMAX; t++) { dcol = j8 == t ? (float *) a.dstcol[t] : dcol; mcol = j8 == t ? (float *) a.mircol[t] : mcol; }
+    for (int gi = 0; gi < NG; gi++) {
+        dcol[gi] = (float *) a.dstcol[gi*MI355X_IMG_COLS]; mcol[gi] = (float *) a.mircol[gi*MI355X_IMG_COLS];
+        #pragma unroll
+        for (int t = 1; t < TMAX; t++) { dcol[gi] = j8 == t ? (float *) a.dstcol[gi*MI355X_IMG_COLS + t] : dcol[gi]; mcol[gi] = j8 == t ? (float *) a.mircol[gi*MI355X_IMG_COLS + t] : mcol[gi]; }
+    }
 
     for (; grp < ngroups; grp += 2*stride) {
       #pragma unroll
@@ -719,66 +773,81 @@ __global__ void __launch_bounds__(512) k_vocab(const VArgs a) {
         const int g_ = grp + half*stride;
         if (g_ >= ngroups) break;
         wblk<WT> * buf = half == 0 ? A : B;
-        float acc[TMAX];
-        #pragma unroll
-        for (int t = 0; t < TMAX; t++) acc[t] = 0.0f;
-        #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int g = j8 + 8*u;
-            uint32_t vlo[4], vhi[4];
-            wblk_unpack<WT>(buf[u], vlo, vhi);
-            const float dw = h2f(buf[u].d);
+        const int row = g_*8 + r8;
+        // the row group's weights are unpacked once and meet every image (NG > 1: image after image, the compiler kept from interleaving them)
+        uint32_t vlo[U][4], vhi[U][4]; float dw[U];
+        if constexpr (NG > 1) {
             #pragma unroll
-            for (int tt = 0; tt < TMAX; tt++) {
-                uint4 al, ah; float dxv; int sxo;
-                if constexpr (TMAX == 1) { al = ral[u]; ah = rah[u]; dxv = rdx[u]; sxo = rsx[u]; }
-                else { const int t = tt < T ? tt : T - 1; al = alo[(size_t) t*nb + g]; ah = ahi[(size_t) t*nb + g]; dxv = pdx[t*nb + g]; sxo = off ? off * psx[t*nb + g] : 0; }
-                int sum = 0;
-                sum = __builtin_amdgcn_sdot4((int) vlo[0], (int) al.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[1], (int) al.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[2], (int) al.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vlo[3], (int) al.w, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[0], (int) ah.x, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[1], (int) ah.y, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[2], (int) ah.z, sum, false);
-                sum = __builtin_amdgcn_sdot4((int) vhi[3], (int) ah.w, sum, false);
-                if (off) sum -= sxo;
-                acc[tt] = fmaf(dw * dxv, (float) sum, acc[tt]);
-                if constexpr (TMAX > 2) __builtin_amdgcn_sched_barrier(0);      // (keeps the LDS reads of later columns from being hoisted: registers)
-            }
-            if constexpr (TMAX == 2) __builtin_amdgcn_sched_barrier(0);
+            for (int u = 0; u < U; u++) { wblk_unpack<WT>(buf[u], vlo[u], vhi[u]); dw[u] = h2f(buf[u].d); }
         }
         #pragma unroll
-        for (int t = 0; t < TMAX; t++) acc[t] = group_sum<8>(acc[t]);
-        float v = acc[0];
-        #pragma unroll
-        for (int t = 1; t < TMAX; t++) v = (j8 == t) ? acc[t] : v;
-        const int row = g_*8 + r8;
-        if (row < N && j8 < T) {
-            dcol[row] = v;
-            if (mcol) mcol[row] = v;
+        for (int gi = 0; gi < NG; gi++) {
+            const int Ti = NG == 1 ? T : (Tall - gi*MI355X_IMG_COLS < MI355X_IMG_COLS ? Tall - gi*MI355X_IMG_COLS : MI355X_IMG_COLS);
+            const uint4 * alo = (const uint4 *) (smem + gi*istride), * ahi = alo + (size_t) Ti*nb;
+            const float * idx_ = (const float *) (ahi + (size_t) Ti*nb);
+            const int * isx = (const int *) (idx_ + Ti*nb);
+            float acc[TMAX];
+            #pragma unroll
+            for (int t = 0; t < TMAX; t++) acc[t] = 0.0f;
+            #pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int g = j8 + 8*u;
+                if constexpr (NG == 1) { wblk_unpack<WT>(buf[u], vlo[u], vhi[u]); dw[u] = h2f(buf[u].d); }      // (one image: unpacked where it is used — registers)
+                #pragma unroll
+                for (int tt = 0; tt < TMAX; tt++) {
+                    uint4 al, ah; float dxv; int sxo;
+                    if constexpr (TMAX == 1) { al = ral[u]; ah = rah[u]; dxv = rdx[u]; sxo = rsx[u]; }
+                    else { const int t = tt < Ti ? tt : Ti - 1; al = alo[(size_t) t*nb + g]; ah = ahi[(size_t) t*nb + g]; dxv = idx_[t*nb + g]; sxo = off ? off * isx[t*nb + g] : 0; }
+                    int sum = 0;
+                    sum = __builtin_amdgcn_sdot4((int) vlo[u][0], (int) al.x, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[u][1], (int) al.y, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[u][2], (int) al.z, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vlo[u][3], (int) al.w, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[u][0], (int) ah.x, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[u][1], (int) ah.y, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[u][2], (int) ah.z, sum, false);
+                    sum = __builtin_amdgcn_sdot4((int) vhi[u][3], (int) ah.w, sum, false);
+                    if (off) sum -= sxo;
+                    acc[tt] = fmaf(dw[u] * dxv, (float) sum, acc[tt]);
+                    if constexpr (TMAX > 2) __builtin_amdgcn_sched_barrier(0);      // (keeps the LDS reads of later columns from being hoisted: registers)
+                }
+                if constexpr (TMAX == 2) __builtin_amdgcn_sched_barrier(0);
+            }
+            #pragma unroll
+            for (int t = 0; t < TMAX; t++) acc[t] = group_sum<8>(acc[t]);
+            float v = acc[0];
+            #pragma unroll
+            for (int t = 1; t < TMAX; t++) v = (j8 == t) ? acc[t] : v;
+            if (row < N && j8 < Ti) {
+                dcol[gi][row] = v;
+                if (mcol[gi]) mcol[gi][row] = v;
+            }
+            if constexpr (NG > 1) __builtin_amdgcn_sched_barrier(0);
         }
         load_group(buf, g_ + 2*stride);
       }
     }
 }
 
-template <int WT, int TMAX>
+template <int WT, int TMAX, int NG>
 static int launch_vocab_u(mi355x_ctx * ctx, const VArgs & k, int U, dim3 grid, uint32_t lds, double bytes, double flops) {
     switch (U) {
-        case 2: return emit(ctx, "vocab", k_vocab<WT, TMAX, 2>, grid, dim3(512), lds, k, bytes, flops);
-        case 3: return emit(ctx, "vocab", k_vocab<WT, TMAX, 3>, grid, dim3(512), lds, k, bytes, flops);
-        case 4: return emit(ctx, "vocab", k_vocab<WT, TMAX, 4>, grid, dim3(512), lds, k, bytes, flops);
-        case 5: return emit(ctx, "vocab", k_vocab<WT, TMAX, 5>, grid, dim3(512), lds, k, bytes, flops);
+        case 2: return emit(ctx, "vocab", k_vocab<WT, TMAX, 2, NG>, grid, dim3(512), lds, k, bytes, flops);
+        case 3: return emit(ctx, "vocab", k_vocab<WT, TMAX, 3, NG>, grid, dim3(512), lds, k, bytes, flops);
+        case 4: return emit(ctx, "vocab", k_vocab<WT, TMAX, 4, NG>, grid, dim3(512), lds, k, bytes, flops);
+        case 5: return emit(ctx, "vocab", k_vocab<WT, TMAX, 5, NG>, grid, dim3(512), lds, k, bytes, flops);
     }
     return MI355X_E_UNSUPPORTED;
 }
 template <int WT>
 static int launch_vocab(mi355x_ctx * ctx, const VArgs & k, int U, dim3 grid, uint32_t lds, double bytes, double flops) {
-    if (k.T == 1) return launch_vocab_u<WT, 1>(ctx, k, U, grid, lds, bytes, flops);
-    if (k.T == 2) return launch_vocab_u<WT, 2>(ctx, k, U, grid, lds, bytes, flops);
-    if (k.T <= 4) return launch_vocab_u<WT, 4>(ctx, k, U, grid, lds, bytes, flops);
-    return launch_vocab_u<WT, 8>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T == 1) return launch_vocab_u<WT, 1, 1>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T == 2) return launch_vocab_u<WT, 2, 1>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T <= 4) return launch_vocab_u<WT, 4, 1>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T <= 8) return launch_vocab_u<WT, 8, 1>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T <= 16) return launch_vocab_u<WT, 8, 2>(ctx, k, U, grid, lds, bytes, flops);
+    if (k.T <= 24) return launch_vocab_u<WT, 8, 3>(ctx, k, U, grid, lds, bytes, flops);
+    return launch_vocab_u<WT, 8, 4>(ctx, k, U, grid, lds, bytes, flops);
 }
 
 // the vocabulary projection: MI355X_E_UNSUPPORTED = not this shape (the caller goes on to k_gemv8)
@@ -807,7 +876,8 @@ int mi355x_vocab(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         k.mircol[t] = mirror ? d->cols->mirror[tc] : nullptr;
         if (!k.dstcol[t] || ((uintptr_t) k.dstcol[t] % 4) || (mirror && !k.mircol[t])) return MI355X_E_UNSUPPORTED;
     }
-    const size_t lds = ((dg_act_bytes(wt, K, T) + 15) & ~(size_t) 15) + 16;
+    if (T > MI355X_IMG_COLS && !planes) return MI355X_E_UNSUPPORTED;          // more than one image: prepared planes only
+    const size_t lds = dg_planes_bytes(wt, K, T) + 16;
     if (lds > 64 * 1024) return MI355X_E_UNSUPPORTED;
     // 8-wave workgroups, every wave walking 4 row groups with two of them in flight (measured, large-v3 Q5_0, HBM-cold, rocprofv3:
     // 4 groups per wave = 203 workgroups 11.1 us, one workgroup per CU 11.6, 2 groups per wave 12.3, 1 per wave 14.1, 8 per wave 15.2;
@@ -1108,11 +1178,13 @@ __global__ void __launch_bounds__(1024) k_fattn_self_q(const FDMArgs a) {
         // the head's 64 values = blocks 2h and 2h + 1 of column si: lane j quantizes values 4j .. 4j + 3 (8 lanes per block)
         const float4 x4 = *(const float4 *) &xo[tid*4];
         const float xv[4] = { x4.x, x4.y, x4.z, x4.w };
-        const int K = a.H*64, T = a.S, nb = K >> 5;
-        uint32_t * lo = (uint32_t *) a.part_o, * hi = lo + (size_t) T*nb*4;
+        // (column si = column si % 8 of image si / 8)
+        const int K = a.H*64, nb = K >> 5;
+        const int ti = si & (MI355X_IMG_COLS - 1), T = a.S - (si - ti) < MI355X_IMG_COLS ? a.S - (si - ti) : MI355X_IMG_COLS;
+        uint32_t * lo = (uint32_t *) ((char *) a.part_o + (size_t) (si >> 3) * dg_img_stride(MI355X_TYPE_Q8_0, K)), * hi = lo + (size_t) T*nb*4;
         float * dx = (float *) (hi + (size_t) T*nb*4);
         int * sx = (int *) (dx + T*nb);
-        dg_q8_0_store(xv, hq*64 + tid*4, si, nb, lo, hi, dx, sx);
+        dg_q8_0_store(xv, hq*64 + tid*4, ti, nb, lo, hi, dx, sx);
     }
 }
 

@@ -357,7 +357,9 @@ static int launch_gemv_T(mi355x_ctx * ctx, const GemvArgs & k, int T, dim3 grid,
 
 extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     ctx->last_mirrored = 0;
-    if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > 8) return MI355X_E_UNSUPPORTED;
+    if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > MI355X_MAX_COLS) return MI355X_E_UNSUPPORTED;
+    // more than 8 columns: the plane kernels only (images of 8 columns, decode_q.hip)
+    if (d->T > MI355X_IMG_COLS && !d->x_planes && !(!d->x && d->has_norm && d->cols && d->cols->x[0])) return MI355X_E_UNSUPPORTED;
     for (int s = 0; s < d->nseg; s++) if (d->seg[s].ep.bias_per_col) return MI355X_E_UNSUPPORTED;      // (MFMA path only)
     {   // the vocabulary projection has its own kernel (LayerNorm form or prepared planes)
         const int rc = mi355x_vocab(ctx, d);
@@ -365,7 +367,39 @@ extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     }
     if (d->x_planes) {   // activations already quantized (decode_q.hip pipeline): lean plane kernel, else the generic k_gemv8 on the same planes
         const int rc = mi355x_gemv_q(ctx, d);
-        return rc != MI355X_E_UNSUPPORTED ? rc : mi355x_gemv8(ctx, d);
+        if (rc != MI355X_E_UNSUPPORTED) return rc;
+        if (d->T <= MI355X_IMG_COLS) return mi355x_gemv8(ctx, d);
+        // more than one image and no kernel that walks them itself (e.g. the vocabulary projection of a Q4_K model): image by image through
+        // the <= 8-column paths — same per-column arithmetic, the weights are read once per image instead of once
+        const int wt = d->seg[0].wtype;
+        const size_t istride = mi355x_act_planes_bytes(wt, d->K, MI355X_IMG_COLS);          // (= one full image)
+        bool mirrored = true;
+        for (int c0 = 0; c0 < d->T; c0 += MI355X_IMG_COLS) {
+            mi355x_gemv_desc sub = *d;
+            mi355x_gemv_cols cols;
+            sub.T = d->T - c0 < MI355X_IMG_COLS ? d->T - c0 : MI355X_IMG_COLS;
+            sub.x_planes = (const char *) d->x_planes + (size_t) (c0 / MI355X_IMG_COLS) * istride;
+            if (d->cols) {
+                memset(&cols, 0, sizeof(cols));
+                for (int s = 0; s < d->nseg; s++) for (int t = 0; t < sub.T; t++) { cols.dst[s][t] = d->cols->dst[s][c0 + t]; cols.res[s][t] = d->cols->res[s][c0 + t]; }
+                for (int t = 0; t < sub.T; t++) { cols.mirror[t] = d->cols->mirror[c0 + t]; cols.x[t] = d->cols->x[c0 + t]; }
+                sub.cols = &cols;
+            } else {
+                for (int s = 0; s < d->nseg; s++) {
+                    if (sub.seg[s].dst) sub.seg[s].dst = (char *) sub.seg[s].dst + (int64_t) c0 * sub.seg[s].dst_nb1;
+                    if (sub.seg[s].ep.residual) sub.seg[s].ep.residual = (const float *) ((const char *) sub.seg[s].ep.residual + (int64_t) c0 * sub.seg[s].ep.residual_nb1);
+                }
+            }
+            if (d->planes_out) {
+                int ntot = 0; for (int s = 0; s < d->nseg; s++) ntot += d->seg[s].N;
+                sub.planes_out = (char *) d->planes_out + (size_t) (c0 / MI355X_IMG_COLS) * mi355x_act_planes_bytes(MI355X_TYPE_Q8_0, ntot, MI355X_IMG_COLS);
+            }
+            const int r2 = mi355x_gemv_fused(ctx, &sub);
+            if (r2) return r2;              // (MI355X_E_UNSUPPORTED on the first image: nothing was launched; the <= 8-column paths do not differ between images)
+            mirrored = mirrored && ctx->last_mirrored;
+        }
+        ctx->last_mirrored = mirrored ? 1 : 0;
+        return 0;
     }
     if (!d->x && d->has_norm && d->cols && d->cols->x[0]) return mi355x_gemv_q(ctx, d);      // the plane kernel's LayerNorm form (no planes in HBM)
     {   // the lean decode kernels (decode.hip) take every quantized shape of the whisper graphs; what is left for k_gemv below:

@@ -355,6 +355,8 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
     for (int e = tid; e < 2 * (ZB / 4); e += 256) ((uint32_t *) (lds + (e / (ZB / 4)) * STAGE + OFF_Z))[e % (ZB / 4)] = 0u;
     if (tid < 16) ((uint32_t *) (lds + 2*STAGE))[tid] = ((tid & 1) ? 0xF0u : 0u) | ((tid & 2) ? 0xF000u : 0u) | ((tid & 4) ? 0xF00000u : 0u) | ((tid & 8) ? 0xF0000000u : 0u);
     load_tile(0);
+    if constexpr (WT == MI355X_TYPE_Q5_0) __syncthreads();      // the table must be complete before ANY thread unpacks with it (round 4: without this barrier
+                                                                 // the first tile raced with the 16 threads that write it — wrong bytes only under load)
     store_tile(0, lds);
     __syncthreads();
 

@@ -57,7 +57,8 @@ class GemvDesc(C.Structure):
                 ("reserved3", C.c_int32), ("cols", C.c_void_p)]
 
 
-MAX_COLS = 8
+MAX_COLS = 32          # mi355x_kernels.h: MI355X_MAX_COLS (more than IMG_COLS = 8 columns travel as images of 8)
+IMG_COLS = 8
 
 
 class GemvCols(C.Structure):          # mi355x_gemv_cols: [segment][column] destinations / residuals
