@@ -149,8 +149,9 @@ MI355X_API int mi355x_gemm_f16act_prep(mi355x_ctx * ctx, const mi355x_tensor * A
  * the CPU's own integer sums, f32 summation in ascending block order.  The weight is read in its block-quantized planar layout and
  * unpacked per workgroup into an LDS int8 tile; no f16 / int8 copy of a weight exists.
  *
- * Activation ROWS of x [K, T] (csrc/kernels/qrows.h): q[T][K] int8 | d[T][K/32] f32 for Q4_0 / Q5_0 / Q8_0 weights (Q8_0 blocks,
- * arch/x86/quants.c:302-398), q[T][K] int8 | d[T][K/256] f32 | bsum[T][K/32] i32 for Q4_K weights (Q8_K blocks, ggml-quants.c:2768-2805);
+ * Activation ROWS of x [K, T] (csrc/kernels/qrows.h): q[T][K] int8 | d[K/32][T] f32 for Q4_0 / Q5_0 / Q8_0 weights (Q8_0 blocks,
+ * arch/x86/quants.c:302-398), q[T][K] int8 | d[K/256][T] f32 | bsum[K/32][T] i32 for Q4_K weights (Q8_K blocks, ggml-quants.c:2768-2805) —
+ * the scale arrays are BLOCK-major (one block's scales of consecutive columns are contiguous);
  * mi355x_act_rows_bytes gives the size.  Producers: mi355x_prep_act / mi355x_norm_prep with mode 3 (Q8_0 rows) or 4 (Q8_K rows),
  * mi355x_flash_attn_ext_prep_rows, mi355x_gemm_q8act_prep (the epilogue of the GEMM that produces x).  K % 128 == 0.
  * mi355x_gemm_q8act_prep: the epilogue ALSO leaves the Q8_0 rows of the F32 result (K' = M, M % 128 == 0) in prep_rows_out — the

@@ -17,20 +17,25 @@ batchtest)
     ;;
 scaling)
     stage "stream scaling, batched, large-v3 Q5_0"
-    { echo "# GGML_MI355X_BATCH_COLS=16"; GGML_MI355X_BATCH_COLS=16 timeout 600 python3 scripts/stream_scaling.py --streams 8,12,16 --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
-      echo "# GGML_MI355X_BATCH_COLS=32"; GGML_MI355X_BATCH_COLS=32 timeout 600 python3 scripts/stream_scaling.py --streams 16,24,32 --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
+    { echo "# GGML_MI355X_BATCH_COLS=16"; GGML_MI355X_BATCH_COLS=16 timeout 600 python3 scripts/stream_scaling.py --streams ${SCALING_16:-8,12,16} --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
+      echo "# GGML_MI355X_BATCH_COLS=32"; GGML_MI355X_BATCH_COLS=32 timeout 600 python3 scripts/stream_scaling.py --streams ${SCALING_32:-16,24,32} --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
     } > "$OUT/stream_scaling_cols.txt" 2>&1
     cut -c1-260 "$OUT/stream_scaling_cols.txt"
     ;;
 xplant)
     stage "x-planted token parity + fault controls"
-    timeout 2400 python3 -m pytest tests/test_gpu.py -m gpu -q -p no:cacheprovider -k "cross_attention_carried" > "$OUT/pytest_xplant.txt" 2>&1
+    timeout 2400 python3 -m pytest tests/test_gpu.py -m gpu -q -p no:cacheprovider -k "${XPLANT_SEL:-cross_attention_carried}" > "$OUT/pytest_xplant.txt" 2>&1
     echo "exit=$?"; tail -30 "$OUT/pytest_xplant.txt"
     ;;
 streams)
     stage "concurrent streams == serial (incl. 12 and 16 streams)"
     timeout 1800 python3 -m pytest tests/test_gpu.py -m gpu -q -p no:cacheprovider -k "concurrent_streams" > "$OUT/pytest_streams.txt" 2>&1
     echo "exit=$?"; tail -30 "$OUT/pytest_streams.txt"
+    ;;
+scaling16)
+    stage "16 streams, columns per chain 8 / 10 / 12 / 16"
+    { for cols in 8 10 12 16; do echo "# GGML_MI355X_BATCH_COLS=$cols"; GGML_MI355X_BATCH_COLS=$cols timeout 300 python3 scripts/stream_scaling.py --streams 16 --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'; done; } > "$OUT/stream_scaling_16.txt" 2>&1
+    cut -c1-260 "$OUT/stream_scaling_16.txt"
     ;;
 trace)
     stage "rocprofv3 kernel trace of 16 batched streams (large-v3 Q5_0, 64 steps per chunk)"
@@ -43,7 +48,7 @@ trace)
     ;;
 xcd)
     stage "XCD-local teams probe"
-    timeout 120 scripts/_bin/xcd_team_probe 32 2>&1 | tee "$OUT/xcd_team_probe.txt"
+    { timeout 120 scripts/_bin/xcd_team_probe 32 11; echo; timeout 120 scripts/_bin/xcd_team_probe 32 16; } 2>&1 | tee "$OUT/xcd_team_probe.txt"
     ;;
 esac; done
 echo; echo "=== done === $(date +%T)"

@@ -85,7 +85,7 @@ def planted_token(pos: int) -> int:
 #     contribute at the level of a random-weight model
 # sign(s_p) picks a_p or b_p; the margin is ~ g * |s_p| * (proj_a - proj_b) / rms(x).  (f, g, c) per architecture were calibrated
 # with the reference CPU path (scripts/xplant_calibrate.py; profiles/r04_xplant_calibration.txt).
-XPLANT = {"base.en": (20.0, 80.0, 1.0, 0.1), "large-v3-turbo": (16.0, 120.0, 1.0, 0.1), "large-v3": (40.0, 300.0, 1.0, 0.1)}      # (f, g, c, w); calibrated architectures only
+XPLANT = {"base.en": (80.0, 160.0, 1.0, 0.1), "large-v3-turbo": (64.0, 480.0, 1.0, 0.1), "large-v3": (80.0, 600.0, 1.0, 0.1)}      # (f, g, c, w); calibrated architectures only
 
 
 def xplant_tables(te: np.ndarray, n_text_ctx: int, seed: int):

@@ -493,6 +493,14 @@ def test_multi_state_step_head_matches_get_rows_and_cast(gpu, oracle, t):
     for ref, dst, m_ref, m16 in want:
         assert np.array_equal(ref.cpu().numpy()[0].view(np.uint32), dst.cpu().numpy().view(np.uint32))
         assert np.array_equal(m_ref.view(np.uint16), m16.cpu().numpy().view(np.uint16))
+    # a token id outside the table (the reference's get_rows asserts): that state's embedding is NaN, visibly wrong, never the stale vector
+    # of the previous step; the other states of the launch are untouched
+    bad = dev(torch, np.array([V + 7], np.int32))
+    st[1].tok = bad.data_ptr()
+    ctx.check(ka.lib().mi355x_decode_head_multi(ctx.h, S, st, C.byref(tte), C.byref(tpe)), "decode_head_multi")
+    ctx.sync()
+    assert np.isnan(want[1][1].cpu().numpy()).all()
+    assert np.array_equal(want[0][0].cpu().numpy()[0].view(np.uint32), want[0][1].cpu().numpy().view(np.uint32))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -152,7 +152,7 @@ def _write_trace(path, steps=6, per_step=5, first_gap_outlier=True):
 
 def test_trace_anatomy_reports_median_gaps(tmp_path):
     """scripts/summarize_trace.py: per-position mean AND median gap — the mean alone turned one 9.6 ms outlier into a
-    phantom '30-40 us stall at the start of every step' """
+    phantom '30-40 us stall at the start of every step' (HISTORY.md section 3)"""
     d = tmp_path / "prof"
     d.mkdir()
     _write_trace(d / "x_kernel_trace.csv")
@@ -253,7 +253,7 @@ def test_ring_gemm_loop_never_drains_the_dma_queue(tmp_path):
 def test_decode_matvec_issues_all_loads_in_one_burst(mangled, min_loads):
     """ISA of the built decode kernels: every global load of the kernel body is issued before the FIRST vmcnt wait, and that
     wait is a counted one that leaves the weight stream in flight.  This is the property that took the projection inside
-    the real graph from 7.9 to 4.5 us (hipcc serializes predicated loads behind `s_waitcnt vmcnt(0)` and
+    the real graph from 7.9 to 4.5 us (HISTORY.md section 3: hipcc serializes predicated loads behind `s_waitcnt vmcnt(0)` and
     sinks loads to their first use unless the order is pinned)."""
     sys.path.insert(0, str(ROOT / "scripts"))
     import kernel_resources as kr

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -535,7 +536,9 @@ static inline double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static std::vector<mi_backend_ctx *> g_backends;           // live backends (guarded by g_weights_mtx)
+static std::vector<mi_backend_ctx *> g_backends;           // live backends (guarded by g_weights_mtx; the mirror look-ups below only share g_backends_rw)
+static std::shared_mutex g_backends_rw;                     // writers (backend init / free) hold it exclusively IN ADDITION to g_weights_mtx: every stream's per-step
+                                                            // uploads and logits reads scan the list, and must not serialise on one process-wide mutex
 static thread_local mi_backend_ctx * t_last_backend = nullptr;    // the backend whose graph_compute this host thread called last (one thread per whisper_state)
 
 #define MI_MIRROR_CAP ((size_t) 2 << 20)
@@ -544,7 +547,8 @@ static char * mi_mirror_dev(mi_backend_ctx * b) {             // device address 
     if (!g_mirror_on) return nullptr;
     if (!b->mirror_host) {
         void * h = nullptr, * d = nullptr;
-        if (hipHostMalloc(&h, MI_MIRROR_CAP, hipHostMallocDefault) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+        // (explicitly coherent: the host reads rows the device wrote, ordered only by an event wait — must hold with HIP_HOST_COHERENT=0 too)
+        if (hipHostMalloc(&h, MI_MIRROR_CAP, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
         if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void) hipGetLastError(); (void) hipHostFree(h); return nullptr; }
         b->mirror_host = (char *) h; b->mirror_dev = (char *) d;
     }
@@ -552,13 +556,13 @@ static char * mi_mirror_dev(mi_backend_ctx * b) {             // device address 
 }
 // a write to [p, p + n) of `device` memory that did not come from the mirroring kernel: mirrors of that range are stale
 static void mi_mirror_invalidate(int device, const void * p, size_t n) {
-    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    std::shared_lock<std::shared_mutex> lk(g_backends_rw);
     for (auto * b : g_backends)
         if (b->device == device && b->mirror_state.load() != 0 && (const char *) b->mirror_src < (const char *) p + n && (const char *) p < (const char *) b->mirror_src + b->mirror_bytes) b->mirror_state.store(0);
 }
 // read [src, src + size) from a valid mirror instead of the device; false: no mirror holds it
 static bool mi_mirror_read(int device, const void * src, void * dst, size_t size) {
-    std::lock_guard<std::mutex> lk(g_weights_mtx);
+    std::shared_lock<std::shared_mutex> lk(g_backends_rw);          // (shared: several streams copy their rows at the same time)
     for (auto * b : g_backends) {
         if (b->device != device || b->mirror_state.load() != 2) continue;
         const char * s0 = (const char *) b->mirror_src;
@@ -1673,6 +1677,7 @@ static void mi_backend_free(ggml_backend_t backend) {
     if (b->act_alt) (void) hipFree(b->act_alt);
     {
         std::lock_guard<std::mutex> lk(g_weights_mtx);
+        std::unique_lock<std::shared_mutex> wl(g_backends_rw);
         for (size_t i = 0; i < g_backends.size(); i++) if (g_backends[i] == b) { g_backends.erase(g_backends.begin() + i); break; }
         g_total_stats[0] += b->n_graph_compute;
         g_total_host_ms[3] += b->t_eager_ms;
@@ -2003,7 +2008,7 @@ static ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) 
     b->fuse = env_flag("GGML_MI355X_FUSE", true); b->prof = env_flag("GGML_MI355X_PROF", false);
     b->exact = env_flag("GGML_MI355X_EXACT", false);
     if (b->prof) mi355x_prof_enable(k, 1);
-    { std::lock_guard<std::mutex> lk(g_weights_mtx); g_backends.push_back(b); }
+    { std::lock_guard<std::mutex> lk(g_weights_mtx); std::unique_lock<std::shared_mutex> wl(g_backends_rw); g_backends.push_back(b); }
     return new ggml_backend{ mi_guid(), mi_backend_iface, dev, b };
 }
 static ggml_backend_buffer_type_t mi_dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi_device_ctx *) dev->context)->buft; }

@@ -1237,10 +1237,15 @@ __global__ void __launch_bounds__(256) k_decode_head_multi(const HeadArgs a) {
     const mi355x_head_state & st = a.st[b];
     if (!st.tok) return;
     const int32_t row = *st.tok, ar = *st.pos;
-    if (row < 0 || row >= a.te_rows || ar < 0 || ar >= a.pe_rows) return;
-    const float * addrow = (const float *) (a.pe + (int64_t) ar*a.pe_nb1);
     float * dst = st.dst;
     const int ne0 = a.ne0;
+    if (row < 0 || row >= a.te_rows || ar < 0 || ar >= a.pe_rows) {
+        // an id or position outside the tables (the reference's get_rows asserts, ggml-cpu/ops.cpp:4850-5017): the state's embedding becomes NaN,
+        // so that its logits are visibly wrong instead of the previous step's stale vector; other states are unaffected
+        for (int i = threadIdx.x; i < ne0; i += 256) dst[i] = __uint_as_float(0x7FC00000u);
+        return;
+    }
+    const float * addrow = (const float *) (a.pe + (int64_t) ar*a.pe_nb1);
     if constexpr (TYPE == MI355X_TYPE_F32 || TYPE == MI355X_TYPE_F16) {
         const char * src = a.te + (int64_t) row*a.te_nb1;
         for (int i = threadIdx.x; i < ne0; i += 256) {
