@@ -32,6 +32,13 @@ streams)
     timeout 1800 python3 -m pytest tests/test_gpu.py -m gpu -q -p no:cacheprovider -k "concurrent_streams" > "$OUT/pytest_streams.txt" 2>&1
     echo "exit=$?"; tail -30 "$OUT/pytest_streams.txt"
     ;;
+scalingauto)
+    stage "stream scaling with the default chain widths (+ cross-attention straight to planes at 16 streams)"
+    { echo "# default"; timeout 900 python3 scripts/stream_scaling.py --streams ${AUTO_STREAMS:-8,12,16,24,32} --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
+      echo "# GGML_MI355X_ATTN_PLANES_MAX_KV=1536"; GGML_MI355X_ATTN_PLANES_MAX_KV=1536 timeout 300 python3 scripts/stream_scaling.py --streams 16 --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'
+    } > "$OUT/stream_scaling_auto.txt" 2>&1
+    cut -c1-260 "$OUT/stream_scaling_auto.txt"
+    ;;
 scaling16)
     stage "16 streams, columns per chain 8 / 10 / 12 / 16"
     { for cols in 8 10 12 16; do echo "# GGML_MI355X_BATCH_COLS=$cols"; GGML_MI355X_BATCH_COLS=$cols timeout 300 python3 scripts/stream_scaling.py --streams 16 --batching 1 --steps 2 2>&1 | grep -v '^{"arch"'; done; } > "$OUT/stream_scaling_16.txt" 2>&1

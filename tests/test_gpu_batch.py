@@ -7,6 +7,7 @@ per-column destination pointers.  That is what makes a cross-state batch (severa
 one launch chain) indistinguishable from running every state alone.  The oracle (CPU restatement) pins the values themselves.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,10 @@ from conftest import nmse, ptr
 from test_gpu import QT, dev, gpu, quantize  # noqa: F401  (gpu is a fixture)
 
 pytestmark = pytest.mark.gpu
+
+# whole-model tests below: ONE chain as wide as the states allow (the default splits them two thirds / one third over two chains; that
+# arrangement is covered by tests/test_gpu.py::test_concurrent_streams_on_one_gpu_match_serial).  Read once per process by the plugin.
+os.environ.setdefault("GGML_MI355X_BATCH_COLS", "32")
 
 
 def _planes(ctx, ka, which=0):

@@ -1876,13 +1876,17 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
 
 static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     static const double window_ms = getenv("GGML_MI355X_BATCH_WINDOW_US") ? atof(getenv("GGML_MI355X_BATCH_WINDOW_US")) * 1e-3 : 3.0;
-    // columns per merged chain (2..32, default 16): with fewer columns than decoding states several chains run side by side (MI_BATCH_LANES
-    // streams).  More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still read once per chain step.
-    static const int max_cols = std::max(2, std::min(MI355X_MAX_COLS, getenv("GGML_MI355X_BATCH_COLS") ? atoi(getenv("GGML_MI355X_BATCH_COLS")) : 16));
+    // columns per merged chain.  GGML_MI355X_BATCH_COLS=n (2..32) fixes it; by default about two thirds of the decoding states (at least 8) ride one
+    // chain and the rest a second one next to it (MI_BATCH_LANES streams): measured on large-v3 Q5_0 (profiles/r04_stream_scaling.txt), two chains of
+    // unequal width fill each other's launch gaps — 16 states as 12 + 4: 13.9 chunks/s, as 8 + 8: 12.5, as one chain of 16: 12.9; 24 as 16 + 8: 16.7;
+    // 12 as 8 + 4: 13.2, as one chain: 10.6.  More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still
+    // read once per chain step.
+    static const int env_cols = getenv("GGML_MI355X_BATCH_COLS") ? std::max(2, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_COLS")))) : 0;
     mi_batch_group & grp = g_batch[b->device];
     mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
     std::unique_lock<std::mutex> lk(grp.m);
     if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
+    auto cols_cap = [&]() { return env_cols ? env_cols : std::min(MI355X_MAX_COLS, std::max(MI355X_IMG_COLS, (2 * (int) grp.members.size() + 2) / 3)); };
     if ((int) grp.members.size() < mi_batch_min_states()) {
         // too few decoding states for a merged chain to pay: this step runs on the state's own stream (it stays counted)
         bool idle = true;
@@ -1901,7 +1905,7 @@ static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
             // states that are on their way through a running chain come back later: the set to wait for is everybody else
             int in_flight = 0;
             for (int i = 0; i < MI_BATCH_LANES; i++) if (grp.lanes[i].busy) in_flight += grp.lane_cols[i];
-            const int want = std::max(1, std::min<int>((int) grp.members.size() - in_flight, max_cols));
+            const int want = std::max(1, std::min<int>((int) grp.members.size() - in_flight, cols_cap()));
             if ((int) grp.waiting.size() >= want) lead = true;
             else if (grp.waiting.front() == &me && now_ms() > std::max(arrived, grp.last_finish_ms) + window_ms) {
                 // the window closed: whoever is counted but neither here nor a column of a running chain is dropped (it rejoins with its
@@ -1921,6 +1925,7 @@ static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
         }
         mi_batch_member * mem[MI355X_MAX_COLS];
         int n = 0;
+        const int max_cols = cols_cap();
         while (n < max_cols && !grp.waiting.empty()) { mem[n] = grp.waiting.front(); mem[n]->state = 1; mem[n]->b->in_flight = true; grp.waiting.erase(grp.waiting.begin()); n++; }
         mi_batch_group::lane & ln = grp.lanes[lane];
         ln.busy = true; grp.lane_cols[lane] = n;
