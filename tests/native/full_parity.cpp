@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 static void log_quiet(enum ggml_log_level level, const char * text, void *) { if (level == GGML_LOG_LEVEL_ERROR) fputs(text, stderr); }
@@ -32,11 +33,18 @@ static std::vector<float> synth_pcm(int n) {
 
 // greedy runs: the logits every decoding step sampled from (whisper's own hook, include/whisper.h:474-482: called once per decoder and
 // step, before the sampler's filters), so that a divergence of two back ends can be judged by the margin at the step where it happens
-struct step_logits { std::vector<std::vector<float>> rows; int n_vocab = 0; };
-static void capture_logits(struct whisper_context * ctx, struct whisper_state *, const whisper_token_data *, int, float * logits, void * ud) {
+// beam runs: the hook is called once per DECODER and step with that decoder's token history; the history (hashed) keys the row, so that the
+// rows both back ends computed for the SAME history — whichever beams each of them kept — can be compared
+struct step_logits { std::vector<std::vector<float>> rows; std::vector<uint64_t> key; std::vector<int> len; int n_vocab = 0; };
+static void capture_logits(struct whisper_context * ctx, struct whisper_state *, const whisper_token_data * tokens, int n_tokens, float * logits, void * ud) {
     step_logits * sl = (step_logits *) ud;
+    static std::mutex mtx;                                  // (beam search processes its decoders on several threads: src/whisper.cpp:7500-7545)
+    std::lock_guard<std::mutex> lk(mtx);
     if (!sl->n_vocab) sl->n_vocab = whisper_n_vocab(ctx);
-    if (sl->rows.size() < 512) sl->rows.emplace_back(logits, logits + sl->n_vocab);
+    if (sl->rows.size() >= 640) return;
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < n_tokens; i++) { h ^= (uint64_t) (uint32_t) tokens[i].id; h *= 1099511628211ull; }
+    sl->rows.emplace_back(logits, logits + sl->n_vocab); sl->key.push_back(h); sl->len.push_back(n_tokens);
 }
 
 static std::vector<int> run(const char * model, bool gpu, int strategy, int beam, const std::vector<float> & pcm, int max_tokens, int n_threads = 8, step_logits * cap = nullptr) {
@@ -72,14 +80,14 @@ int main(int argc, char ** argv) {
     for (const auto & m : modes) {
         const bool greedy = m.beam == 1;
         step_logits la, lb;
-        const std::vector<int> a = run(argv[1], false, m.strategy, m.beam, pcm, max_tokens, 8, greedy ? &la : nullptr);
+        const std::vector<int> a = run(argv[1], false, m.strategy, m.beam, pcm, max_tokens, 8, &la);
         // self-test with FULL_PARITY_THREADS_B=n: reference CPU path with 8 threads against the reference CPU path with n
         // threads (different f32 summation order only) — how stable free-running decoding of this model is in the reference itself
         const int tb = selftest && getenv("FULL_PARITY_THREADS_B") ? atoi(getenv("FULL_PARITY_THREADS_B")) : 8;
         // self-test with FULL_PARITY_PERTURB=eps: the reference against itself on the signal scaled by (1 + eps)
         std::vector<float> pcm_b = pcm;
         if (selftest && getenv("FULL_PARITY_PERTURB")) { const float e = 1.0f + (float) atof(getenv("FULL_PARITY_PERTURB")); for (auto & x : pcm_b) x *= e; }
-        const std::vector<int> b = run(argv[1], !selftest, m.strategy, m.beam, pcm_b, max_tokens, tb, greedy ? &lb : nullptr);
+        const std::vector<int> b = run(argv[1], !selftest, m.strategy, m.beam, pcm_b, max_tokens, tb, &lb);
         size_t same = 0; while (same < a.size() && same < b.size() && a[same] == b[same]) same++;
         printf(",\n \"%s\": {\"n_cpu\": %zu, \"n_gpu\": %zu, \"identical_prefix\": %zu, ", m.name, a.size(), b.size(), same);
         if (greedy) {
@@ -100,6 +108,21 @@ int main(int argc, char ** argv) {
             }
             printf("\"steps_compared\": %zu, \"min_margin\": %.6g, \"max_logit_diff\": %.6g, \"divergence_margin\": %.6g, \"divergence_logit_diff\": %.6g, ",
                    n, n ? min_margin : -1.0, max_diff, div_margin, div_diff);
+        }
+        if (!greedy) {
+            // rows computed for the same decoder history on both sides (5 decoders per step; the kept beams may differ from some step on)
+            size_t common = 0; int deepest = 0; double max_diff = 0;
+            for (size_t i = 0; i < la.rows.size(); i++) {
+                for (size_t j = 0; j < lb.rows.size(); j++) {
+                    if (la.key[i] != lb.key[j] || la.len[i] != lb.len[j]) continue;
+                    const std::vector<float> & x = la.rows[i], & y = lb.rows[j];
+                    for (size_t k = 0; k < x.size(); k++) if (std::isfinite(x[k]) && std::isfinite(y[k])) max_diff = std::max(max_diff, (double) fabsf(x[k] - y[k]));
+                    common++; deepest = std::max(deepest, la.len[i]);
+                    break;
+                }
+            }
+            printf("\"rows_cpu\": %zu, \"rows_gpu\": %zu, \"common_histories\": %zu, \"deepest_common_history\": %d, \"max_logit_diff_common\": %.6g, ",
+                   la.rows.size(), lb.rows.size(), common, deepest, max_diff);
         }
         printf("\"cpu\": [");
         for (size_t i = 0; i < a.size(); i++) printf("%s%d", i ? ", " : "", a[i]);

@@ -803,6 +803,16 @@ def _greedy_divergence_is_a_near_tie(g):
         assert g["divergence_margin"] >= 0 and g["divergence_margin"] <= 4 * g["divergence_logit_diff"], g
 
 
+def _beam_rows_of_common_histories_agree(g):
+    """beam search (VERDICT r03 next #2c): whisper's logits_filter_callback is called once per DECODER and step with that decoder's token
+    history; full_parity.cpp keys every captured row by its history, so the rows both back ends computed for the SAME history — the 5-token
+    batched decode steps with the beams' KV-cache copies behind them — are compared whichever beams each side kept afterwards (on
+    random-weight models the kept beams part ways at near-ties: tests/test_host.py::test_reference_beam_search_is_unstable_...).  Asserted:
+    the first steps' histories are common (>= the 5 decoders of step one), and every common row agrees like the greedy rows do."""
+    assert g["rows_cpu"] >= 5 and g["rows_gpu"] >= 5 and g["common_histories"] >= 5, g
+    assert g["max_logit_diff_common"] < 0.5, g
+
+
 PLANTED_CASES = [("base.en", "q5_0"), ("large-v3-turbo", "q8_0"), ("large-v3", "q5_0")]
 
 
@@ -911,8 +921,9 @@ def test_plugin_whisper_full_pipeline(plugin_env, arch, qtype):
     d = _full_parity(plugin_env, arch, qtype, exact=False)
     for mode in ("greedy", "beam5"):
         g = d[mode]
-        assert g["n_cpu"] > 4 and g["n_cpu"] == g["n_gpu"], g
+        assert g["n_cpu"] > 4 and g["n_gpu"] > 4, g
     _greedy_divergence_is_a_near_tie(d["greedy"])
+    _beam_rows_of_common_histories_agree(d["beam5"])
 
 
 @pytest.mark.parametrize("arch,qtype", FULL_CASES)
@@ -924,8 +935,9 @@ def test_plugin_whisper_full_pipeline_reference_exact_mode(plugin_env, arch, qty
     d = _full_parity(plugin_env, arch, qtype, exact=True)
     for mode in ("greedy", "beam5"):
         g = d[mode]
-        assert g["n_cpu"] > 4 and g["n_cpu"] == g["n_gpu"], g
+        assert g["n_cpu"] > 4 and g["n_gpu"] > 4, g
     _greedy_divergence_is_a_near_tie(d["greedy"])
+    _beam_rows_of_common_histories_agree(d["beam5"])
 
 
 def test_layer_bisect_locates_the_difference(plugin_env):
@@ -958,7 +970,7 @@ def test_concurrent_streams_on_one_gpu_match_serial(arch, qtype, streams):
     each stream's logits — the row of EVERY decode step — must be bit-identical to the same stream running alone.  With 8 streams
     the concurrent leg runs as merged launch chains (cross-state batching is on by default from 5 decoding states): large-v3 Q5_0 x 8
     is BASELINE.json configs[3] at full size, batched versus own chain over all steps; 12 and 16 streams run with the default chain widths
-    (two thirds of the states on one chain — 8 and 11 columns, the latter two images of 8 columns, mi355x_kernels.h: MI355X_IMG_COLS — the rest
+    (60 % of the states on one chain — 8 and 10 columns, the latter two images of 8 columns, mi355x_kernels.h: MI355X_IMG_COLS — the rest
     on a second chain beside it); 16 streams of large-v3 Q5_0 is the verdict's configuration."""
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_check.py"), arch, qtype, str(streams), "12"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))

@@ -1876,17 +1876,23 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
 
 static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     static const double window_ms = getenv("GGML_MI355X_BATCH_WINDOW_US") ? atof(getenv("GGML_MI355X_BATCH_WINDOW_US")) * 1e-3 : 3.0;
-    // columns per merged chain.  GGML_MI355X_BATCH_COLS=n (2..32) fixes it; by default about two thirds of the decoding states (at least 8) ride one
-    // chain and the rest a second one next to it (MI_BATCH_LANES streams): measured on large-v3 Q5_0 (profiles/r04_stream_scaling.txt), two chains of
-    // unequal width fill each other's launch gaps — 16 states as 12 + 4: 13.9 chunks/s, as 8 + 8: 12.5, as one chain of 16: 12.9; 24 as 16 + 8: 16.7;
-    // 12 as 8 + 4: 13.2, as one chain: 10.6.  More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still
-    // read once per chain step.
+    // columns per merged chain.  GGML_MI355X_BATCH_COLS=n (2..32) fixes it; by default 60 % of the decoding states (at least 6) ride one chain and
+    // the rest a second one next to it (MI_BATCH_LANES streams): two chains of unequal width fill each other's launch gaps.  Measured on large-v3
+    // Q5_0 (profiles/r04_stream_scaling.txt, r04_chain_split_sweep.txt): 16 states as 10 + 6: 14.2 chunks/s, 12 + 4: 13.9, 8 + 8: 11.5-12.5, one
+    // chain of 16: 12.9; 32 as 20 + 12: 18.0, 16 + 16: 15.3; 8 as 6 + 2: 10.0, one chain of 8: 9.3; three or more chains (40 %): 11.0 at 32.
+    // More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still read once per chain step.
     static const int env_cols = getenv("GGML_MI355X_BATCH_COLS") ? std::max(2, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_COLS")))) : 0;
     mi_batch_group & grp = g_batch[b->device];
     mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
     std::unique_lock<std::mutex> lk(grp.m);
     if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
-    auto cols_cap = [&]() { return env_cols ? env_cols : std::min(MI355X_MAX_COLS, std::max(MI355X_IMG_COLS, (2 * (int) grp.members.size() + 2) / 3)); };
+    // (A-B switches of that rule: GGML_MI355X_BATCH_SPLIT_PCT = the share of the decoding states a chain may carry, _SPLIT_MIN = its floor)
+    static const int split_pct = getenv("GGML_MI355X_BATCH_SPLIT_PCT") ? std::max(10, std::min(100, atoi(getenv("GGML_MI355X_BATCH_SPLIT_PCT")))) : 60;
+    static const int split_min = getenv("GGML_MI355X_BATCH_SPLIT_MIN") ? std::max(1, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_SPLIT_MIN")))) : 6;
+    auto cols_cap = [&]() {
+        if (env_cols) return env_cols;
+        return std::min(MI355X_MAX_COLS, std::max(split_min, (split_pct * (int) grp.members.size() + 99) / 100));
+    };
     if ((int) grp.members.size() < mi_batch_min_states()) {
         // too few decoding states for a merged chain to pay: this step runs on the state's own stream (it stays counted)
         bool idle = true;
