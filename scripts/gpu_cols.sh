@@ -55,7 +55,7 @@ trace)
     ;;
 xcd)
     stage "XCD-local teams probe"
-    { timeout 120 scripts/_bin/xcd_team_probe 32 11; echo; timeout 120 scripts/_bin/xcd_team_probe 32 16; } 2>&1 | tee "$OUT/xcd_team_probe.txt"
+    { timeout 120 scripts/probes/_bin/xcd_team_probe 32 11; echo; timeout 120 scripts/probes/_bin/xcd_team_probe 32 16; } 2>&1 | tee "$OUT/xcd_team_probe.txt"
     ;;
 esac; done
 echo; echo "=== done === $(date +%T)"

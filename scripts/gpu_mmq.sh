@@ -13,7 +13,7 @@ ok=1
 for s in $STAGES; do case $s in
 probe)
     stage "hardware probe"
-    timeout 60 scripts/_bin/mmq_probe 2>&1 | tee "$OUT/mmq_probe.txt"
+    timeout 60 scripts/probes/_bin/mmq_probe 2>&1 | tee "$OUT/mmq_probe.txt"
     ;;
 mmqtest)
     stage "pytest tests/test_gpu_mmq.py + mul_mat_vs_oracle"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel resource table of the BUILT kernel library (no GPU needed): VGPRs, AGPRs, SGPRs, scratch (private segment) and
 static LDS of every gfx950 kernel in whisper.cpp_amd/lib/libmi355x_kernels.so, read from the code objects' metadata.
-  python scripts/kernel_resources.py [--json]        (tests/test_host.py asserts on it; profiles/r01_kernel_resources.txt)
+  python scripts/kernel_resources.py [--json]        (tests/test_host.py asserts on it; profiles/archive/r01_kernel_resources.txt)
 """
 import json
 import re

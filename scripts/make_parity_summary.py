@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/rNN_parity_summary.json from the per-model JSON files the GPU tests leave in gpurun_out/ (tests/native/model_parity.cpp,
-full_parity.cpp, lang_detect.cpp).   usage: make_parity_summary.py <gpurun_out> > profiles/r02_parity_summary.json"""
+full_parity.cpp, lang_detect.cpp).   usage: make_parity_summary.py <gpurun_out> > profiles/archive/r02_parity_summary.json"""
 import json
 import sys
 from pathlib import Path

@@ -2,7 +2,7 @@
 // "cheap experiment first").  For each candidate layout of "the 32 CUs of XCD x" a stream is created with that mask, a 512-block
 // kernel records HW_REG_XCC_ID per block, and the histogram over XCDs is printed.  Also times a 1280-wave dependent launch chain on a
 // masked stream against an unmasked one (what one XCD sustains alone).
-//   hipcc --offload-arch=gfx950 -O3 scripts/cumask_probe.hip -o scripts/_bin/cumask_probe && scripts/_bin/cumask_probe
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/cumask_probe.hip -o scripts/probes/_bin/cumask_probe && scripts/probes/_bin/cumask_probe
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <chrono>

@@ -7,7 +7,7 @@
 //   C  y = x * rcp-free sigmoid via exp2: x / (1 + exp2(-2u log2 e)) with the hardware v_exp_f32
 // For each: entries whose f16 rounding differs from the table, and how many of those a margin rule would have sent to the table
 // ("unsafe": the f32 result lies within `margin` f32-ulps-of-y, scaled by |x / y| for A, of an f16 rounding boundary).
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/gelu_probe.hip -o /tmp/gelu_probe && /tmp/gelu_probe
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off scripts/probes/gelu_probe.hip -o /tmp/gelu_probe && /tmp/gelu_probe
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>

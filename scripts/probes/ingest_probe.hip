@@ -1,7 +1,7 @@
 // Probe: how long does it take G workgroups to pull a fixed 3.4 MB (one decoder layer's Q / K / V weights, Q5_0) out of HBM when every load
 // is in flight at once?  The fused "LN + Q/K/V + self-attention, one workgroup per head" kernel would use 20 workgroups of 16 waves
 // (170 KB each) where the mat-vec today uses 240 workgroups of 5 waves (14 KB each).  Buffers rotate through 64 copies (HBM-cold).
-//   hipcc --offload-arch=gfx950 -O3 scripts/ingest_probe.hip -o /tmp/ingest_probe && /tmp/ingest_probe
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/ingest_probe.hip -o /tmp/ingest_probe && /tmp/ingest_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -7,7 +7,7 @@
 //     parameters sit in a device-resident block;
 //   * inside the kernel: s_memtime at the first instruction vs. after the LAST dword of the argument struct has
 //     arrived (kernarg fetch latency), and after one dependent global load.
-//   hipcc --offload-arch=gfx950 -O2 scripts/launch_probe.hip -o scripts/_bin/launch_probe
+//   hipcc --offload-arch=gfx950 -O2 scripts/probes/launch_probe.hip -o scripts/probes/_bin/launch_probe
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

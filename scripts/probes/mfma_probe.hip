@@ -9,7 +9,7 @@
 //   4  body 3 + the step's LDS-DMA (global_load_lds, 2-stage ring: vmcnt(0) before the barrier)
 //   5  body 3 + LDS-DMA with a 4-stage ring (vmcnt(2 stages))
 //   6  s_barrier only
-//   hipcc --offload-arch=gfx950 -O3 scripts/mfma_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/mfma_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

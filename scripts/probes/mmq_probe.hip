@@ -3,7 +3,7 @@
 //     K positions on both sides — and D has column = lane & 31 (B index), row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) (A index)
 //  2. v_mfma_f32_32x32x16_f16 with only element 0 of lanes 0..31 non-zero on both sides is the rank-1 product a[m]*b[n], exact in f32
 //  3. v_perm_b32 selector bytes 0x0C / 0x0D give 0x00 / 0xFF
-//   hipcc --offload-arch=gfx950 -O2 -o scripts/_bin/mmq_probe scripts/mmq_probe.hip
+//   hipcc --offload-arch=gfx950 -O2 -o scripts/probes/_bin/mmq_probe scripts/probes/mmq_probe.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

@@ -13,7 +13,7 @@
 //       as 8-byte {value, tag} granules (batched sc1 polls, no fences, no flags), quantize, take their rows from LDS, publish.
 //       C0 = the same engine with the loader starting at the stage's own top (no run-ahead): isolates the prefetch credit.
 // Every spin is bounded: a lost granule sets an error code instead of hanging the GPU.
-//   hipcc --offload-arch=gfx950 -O3 scripts/persist_probe.hip -o scripts/_bin/persist_probe && scripts/_bin/persist_probe [layers]
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/persist_probe.hip -o scripts/probes/_bin/persist_probe && scripts/probes/_bin/persist_probe [layers]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

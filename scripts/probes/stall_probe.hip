@@ -1,7 +1,7 @@
 // Probe for the ~30 us stall seen before the first chip-wide kernel of every decode step.
 // Launches [small, wide, wide] after a host-idle period of D microseconds and lets rocprofv3 --kernel-trace show where
 // the gap lands; mode 1 keeps one wave per CU spinning on a host flag during the idle period.
-//   hipcc --offload-arch=gfx950 -O2 scripts/stall_probe.hip -o gpurun_out/stall_probe
+//   hipcc --offload-arch=gfx950 -O2 scripts/probes/stall_probe.hip -o gpurun_out/stall_probe
 //   rocprofv3 --kernel-trace -f csv -d out -o p -- ./stall_probe
 #include <hip/hip_runtime.h>
 #include <chrono>

@@ -2,7 +2,7 @@
 // k_gemv8<6, 1, 8> (VERDICT r02 next #7 asks for 4.4 TB/s = 10.4 us).  8 distinct buffers (365 MB > the 256 MB Infinity Cache) are read
 // round-robin by a trivial kernel: every thread sums `U` 16-byte loads issued back to back (nt), one store per wave.  Grid shapes from
 // "everything in flight at once" to a few waves per CU walking the buffer.  hipEvent-bracketed single launches, median of 64.
-//   hipcc --offload-arch=gfx950 -O3 scripts/stream_probe.hip -o scripts/_bin/stream_probe && scripts/_bin/stream_probe
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/stream_probe.hip -o scripts/probes/_bin/stream_probe && scripts/probes/_bin/stream_probe
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>

@@ -7,7 +7,7 @@
 //   c  a 1-thread kernel behind the chain writes a sequence number to pinned host memory, host spins on it
 //   d  the LAST kernel of the chain writes the word itself (one workgroup: no arrival counting needed)
 //   e  hipStreamWriteValue32 behind the chain, host spins on the word
-//   hipcc --offload-arch=gfx950 -O3 scripts/sync_probe.hip -o scripts/_bin/sync_probe && scripts/_bin/sync_probe
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/sync_probe.hip -o scripts/probes/_bin/sync_probe && scripts/probes/_bin/sync_probe
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>

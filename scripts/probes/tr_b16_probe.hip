@@ -1,6 +1,6 @@
 // Probe: what does gfx950's ds_read_b64_tr_b16 deliver?  LDS holds u16 element i at byte 2i; lane l reads from byte address l*8 (4 elements
 // of its own), and from a [4 rows][16 cols] block with a 128-byte row pitch (the V tile of the attention kernel).  Prints, per lane, the four
-// elements it received.   hipcc --offload-arch=gfx950 -O2 scripts/tr_b16_probe.hip -o /tmp/tr_probe && /tmp/tr_probe
+// elements it received.   hipcc --offload-arch=gfx950 -O2 scripts/probes/tr_b16_probe.hip -o /tmp/tr_probe && /tmp/tr_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

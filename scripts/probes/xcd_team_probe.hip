@@ -1,7 +1,7 @@
 // XCD-local teams: the last untested single-column design.
 // A batch-1 decode step is 32 layers x 7 dependent stages (mat-vecs whose input is the whole output of the previous one).  The launch
 // chain pays ~4.06 us per stage whatever the bytes (profiles/r03b_kernel_trace_summary_*.txt); the device-wide persistent kernels of
-// scripts/persist_probe.hip lost to it because their all-to-all exchange crosses the XCDs (per-XCD L2s are not coherent: every granule
+// scripts/probes/persist_probe.hip lost to it because their all-to-all exchange crosses the XCDs (per-XCD L2s are not coherent: every granule
 // is a fabric write, every poll a fabric read).  Here the GPU is cut along its L2s instead:
 //   * ONE launch of 256 workgroups (one per CU, 8 waves); a workgroup reads HW_REG_XCC_ID and joins the TEAM of its XCD (32 CUs);
 //   * every team runs ONE stream's chain on its own: a stage's rows are split over the team's 32 workgroups, the activation vector is
@@ -14,7 +14,7 @@
 // Question to answer with a number: us per stage per team with all 8 teams running, against the 4.06 us launch chain that serves ONE
 // stream (or 8 columns in ~2.5 ms per step when merged: 9.35 chunks/s for 8 streams).  8 teams at S us per stage are
 // 8 / (224 * S us) tokens per second; break-even with twice the merged chains' 9.35 chunks/s (4790 tokens/s) is S = 7.5 us.
-//   hipcc --offload-arch=gfx950 -O3 scripts/xcd_team_probe.hip -o scripts/_bin/xcd_team_probe && scripts/_bin/xcd_team_probe [layers] [sixteenths of a weight row read: 11]
+//   hipcc --offload-arch=gfx950 -O3 scripts/probes/xcd_team_probe.hip -o scripts/probes/_bin/xcd_team_probe && scripts/probes/_bin/xcd_team_probe [layers] [sixteenths of a weight row read: 11]
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

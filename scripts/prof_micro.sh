@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel durations of the stand-alone probes: vocabulary projection (scripts/logits_bench.py) and the read-once stream ceiling (scripts/stream_probe.hip)
+# rocprofv3 kernel durations of the stand-alone probes: vocabulary projection (scripts/logits_bench.py) and the read-once stream ceiling (scripts/probes/stream_probe.hip)
 set -u
 cd "$(dirname "$0")/.."
 ROOT=$PWD; OUT=$ROOT/gpurun_out; mkdir -p "$OUT"
@@ -22,7 +22,7 @@ for cfg in ${CFGS:-GGML_MI355X_VOCAB_GROUPS=2 GGML_MI355X_VOCAB_KERNEL=0,GGML_MI
     echo "logits $cfg ${LB_ARGS:-}: $(tail -1 "$OUT/prof_logits_$cfg.json" | cut -c1-120)"; summ "$OUT/prof_logits_$cfg" "k_gemv8"; summ "$OUT/prof_logits_$cfg" "k_vocab"
 done
 if [ -z "${NO_STREAM:-}" ]; then
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace -f csv -d "$OUT/prof_stream" -o s -- "$ROOT/scripts/_bin/stream_probe" > "$OUT/prof_stream.txt" 2> "$OUT/prof_stream.err" )
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace -f csv -d "$OUT/prof_stream" -o s -- "$ROOT/scripts/probes/_bin/stream_probe" > "$OUT/prof_stream.txt" 2> "$OUT/prof_stream.err" )
 summ "$OUT/prof_stream" k_read
 fi
 rm -rf "$OUT"/prof_logits_*/ "$OUT"/prof_stream/

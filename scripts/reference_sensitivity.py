@@ -2,7 +2,7 @@
 """How far does the REFERENCE move against itself?  (no plugin, no GPU: tests/native/bin/model_parity and layer_bisect self-tests)
   * mel input scaled by (1 + eps), eps = 1e-7 and 1e-6: one f32 rounding and ten
   * 8 threads against 2 threads (its single-token flash attention is split over the threads, ggml-cpu/ops.cpp:9117-9150)
-Writes profiles/r02_reference_self_sensitivity.json — the floor the model-level parity tolerances are set against."""
+Writes profiles/archive/r02_reference_self_sensitivity.json — the floor the model-level parity tolerances are set against."""
 import json
 import os
 import subprocess
@@ -37,5 +37,5 @@ for arch, qtype in (("micro", "q5_0"), ("base.en", "q5_0"), ("base.en", "q8_0"))
         out["cases"].append({"model": f"{arch} {qtype}", "perturbation": f"whisper_full on pcm * (1 + {eps})",
                              "greedy_identical_prefix": f"{d['greedy']['identical_prefix']}/{d['greedy']['n_cpu']}",
                              "beam5_identical_prefix": f"{d['beam5']['identical_prefix']}/{d['beam5']['n_cpu']}"})
-(ROOT / "profiles" / "r02_reference_self_sensitivity.json").write_text(json.dumps(out, indent=1))
+(ROOT / "profiles" / "archive" / "r02_reference_self_sensitivity.json").write_text(json.dumps(out, indent=1))
 print(json.dumps(out["cases"], indent=1))

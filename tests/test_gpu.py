@@ -700,7 +700,7 @@ MODEL_CASES = [("micro", "q5_0"), ("tiny.en", "f16"), ("base.en", "q5_0"), ("bas
 #  (1) the reference is discretely sensitive to perturbations of one f32 rounding: scaling its own mel input by (1 + 1e-7) moves its
 #      own logits by 1.1e-4 NMSE on a Q5_0 model (its int8 activation rounding decides discretely) and by 4e-7 on the F16 model;
 #      at (1 + 1e-6) its own free-running greedy sequence leaves itself after 21 of 40 tokens (model_parity self-test,
-#      MODEL_PARITY_PERTURB; tests/test_host.py::test_reference_is_sensitive_to_one_ulp, profiles/r02_reference_self_sensitivity.json).
+#      MODEL_PARITY_PERTURB; tests/test_host.py::test_reference_is_sensitive_to_one_ulp, profiles/archive/r02_reference_self_sensitivity.json).
 #      The plugin's single-token rows sit exactly on that floor (1.0e-4 .. 4.5e-4 quantized, 1e-6 F16): TOL_SINGLE.
 #  (2) its flash attention keeps the running output in F16 on the vec path (ops.cpp:8629-8643): over the 1536 cross-attention keys of
 #      a 2..63-token step that is ~3e-5 NMSE per attention, ~1e-3 at the logits of a 32-layer model; single-token steps are split over
@@ -964,14 +964,15 @@ def test_layer_bisect_locates_the_difference(plugin_env):
 
 
 @pytest.mark.parametrize("arch,qtype,streams", [("base.en", "q5_0", 4), ("large-v3-2l", "q8_0", 3), ("base.en", "q5_0", 8), ("large-v3", "q5_0", 8),
-                                                ("base.en", "q4_k", 12), ("large-v3", "q5_0", 16)])
+                                                ("base.en", "q4_k", 12), ("large-v3-2l", "q4_k", 8), ("large-v3", "q5_0", 16)])
 def test_concurrent_streams_on_one_gpu_match_serial(arch, qtype, streams):
     """several whisper_states on one context, one host thread each (the whisper_full_parallel arrangement, W:7848-7869):
     each stream's logits — the row of EVERY decode step — must be bit-identical to the same stream running alone.  With 8 streams
     the concurrent leg runs as merged launch chains (cross-state batching is on by default from 5 decoding states): large-v3 Q5_0 x 8
     is BASELINE.json configs[3] at full size, batched versus own chain over all steps; 12 and 16 streams run with the default chain widths
     (60 % of the states on one chain — 8 and 10 columns, the latter two images of 8 columns, mi355x_kernels.h: MI355X_IMG_COLS — the rest
-    on a second chain beside it); 16 streams of large-v3 Q5_0 is the verdict's configuration."""
+    on a second chain beside it); 16 streams of large-v3 Q5_0 is the verdict's configuration; large-v3-2l Q4_K covers the Q8_K planes and the
+    k_gemv8 vocabulary projection at K = 1280 (round 4: its LayerNorm summed in another tree than the batched form's)."""
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_check.py"), arch, qtype, str(streams), "12"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]

@@ -63,7 +63,7 @@ extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
     // GGML_MI355X_XCD_STREAMS=1 (experiment): the n-th context of a device gets a stream whose CU mask is ONE XCD
     // (n mod 8), so that up to eight concurrent decode streams each own an XCD (own L2, no interleaving of their dependent launch
     // chains on shared CUs).  Mask layout: GGML_MI355X_XCD_MASK_LAYOUT=0 bit (8k + x) = k-th CU of XCD x (default, what the
-    // driver's symmetric mapping implies), 1 = bits [32x, 32x + 32); scripts/cumask_probe.hip measures which one is right.
+    // driver's symmetric mapping implies), 1 = bits [32x, 32x + 32); scripts/probes/cumask_probe.hip measures which one is right.
     static const int xcd_streams = getenv("GGML_MI355X_XCD_STREAMS") ? atoi(getenv("GGML_MI355X_XCD_STREAMS")) : 0;
     bool have_stream = false;
     if (xcd_streams > 0) {

@@ -41,7 +41,7 @@ __device__ __forceinline__ int k_off(int row, int slot) { return row*128 + ((slo
 // p = exp2(s*c - m*c), c = scale*log2(e), running maximum kept on the raw scores (scale > 0 is checked on the host).
 // VTR: the V tile stays ROW-major in LDS ([key][64 d], 192-byte pitch, two ds_write_b128 per thread and tile) and the P.V fragment
 // is gathered by ds_read_b64_tr_b16, gfx950's transposing LDS read: lane i of a 16-lane group supplies the 8-byte chunk
-// (row i/4, columns 4(i%4)...) of a 4 x 16 block at any row pitch and receives column i of it (scripts/tr_b16_probe.hip,
+// (row i/4, columns 4(i%4)...) of a 4 x 16 block at any row pitch and receives column i of it (scripts/probes/tr_b16_probe.hip,
 // profiles/r03b_tr_b16_probe.txt) — the two 4-key column segments per lane the fragment consists of.  The 192-byte pitch puts the
 // four rows of a 32-lane half on disjoint bank spans (0 / 48 / 32 / 16 dwords mod 64).  !VTR: V transposed on its way into LDS by
 // 16 ds_write_b16 per thread and tile (136-byte pitch), plain ds_read_b64 of the fragment.
