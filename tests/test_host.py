@@ -193,6 +193,8 @@ def test_committed_pmc_traffic_covers_the_benchmarked_kernels():
         assert name in k and k[name]["hbm_bytes_per_launch"] > 0, name
     ring = [n for n in k if n.startswith("void k_gemm_f16_ring<64, 4")]      # (r03: a third template argument, the tile's row count)
     assert ring and k[ring[0]]["hbm_bytes_per_launch"] > 0
+    mmq = [n for n in k if n.startswith("void k_mmq<6, ")]                   # (r04: the int8 tile GEMM carries the encoder)
+    assert mmq and k[mmq[0]]["hbm_bytes_per_launch"] > 0
 
 
 def test_no_kernel_spills_to_scratch():
