@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--qtype", default="q5_0")
-    ap.add_argument("--what", default="fc1,fc2,oproj,qkv")
+    ap.add_argument("--what", default="fc1,fc2,oproj,qkv", help="fc1,fc2,oproj,qkv,fixed")
     ap.add_argument("--T", type=int, default=1500)
     ap.add_argument("--anatomy", action="store_true", help="time the kernel with parts of its K-step switched off (GGML_MI355X_MMQ_DBG)")
     a = ap.parse_args()
@@ -126,6 +126,25 @@ def main():
             return rc or L.mi355x_flush(ctx.h)
         timed(label, "f16 ring on an f16 weight copy", {}, ring, 2.0 * T * M * K, a.iters)
 
+    if "fixed" in what:
+        # what a launch costs before its first and after its last K-step: one-K-step products (K = 128) and K = 256 for the slope, with the
+        # epilogues of the encoder's products (plain F32 store; bias + table GELU + the next GEMM's rows; bias + residual)
+        xs = torch.randn((T, 256), device="cuda:0", generator=g)
+        for K in (128, 256):
+            rk = torch.zeros(L.mi355x_act_rows_bytes(tid, K, T), dtype=torch.uint8, device="cuda:0")
+            xk = xs[:, :K].contiguous()
+            torch.cuda.synchronize()
+            ctx.check(L.mi355x_prep_act(ctx.h, xk.data_ptr(), K * 4, 0, rk.data_ptr(), K, T, 4 if tid == ka.Q4_K else 3), "rows")
+            ctx.sync()
+            ak = xk.to(torch.float16)
+            ep0 = ka.Epilogue()
+            epg = ka.Epilogue(); epg.bias, epg.gelu = bias.data_ptr(), 1
+            epr = ka.Epilogue(); epr.bias, epr.residual, epr.residual_nb1 = bias.data_ptr(), res.data_ptr(), n * 4
+            if tid != ka.Q4_K or K % 256 == 0:
+                cases(f"M5120K{K}", 4 * n, K, rk, ak, ep0, False)
+                cases(f"+gelu,prep", 4 * n, K, rk, ak, epg, True)
+                cases(f"M1280K{K}", n, K, rk, ak, ep0, False)
+                cases(f"+bias,res", n, K, rk, ak, epr, False)
     if "fc1" in what:
         ep = ka.Epilogue()
         ep.bias, ep.gelu = bias.data_ptr(), 1
