@@ -990,6 +990,20 @@ def test_concurrent_streams_on_one_gpu_match_serial(arch, qtype, streams):
         assert d["batch_stats"]["chains"] == 0, d["batch_stats"]
 
 
+def test_a_merged_chain_rejected_half_way_is_repeated_on_the_states_own_chains():
+    """a kernel-side rejection in the MIDDLE of a merged launch chain — after the step head and half the layers have
+    been launched — must not fail the streams in it.  GGML_MI355X_TEST_FAULT=reject:3 makes the third merged chain of the process report
+    one (csrc/backend/ggml_mi355x.cpp: mi_test_fault): the chain drains, every member repeats the step on its own chain, that graph shape
+    stops batching — and every stream's logits of EVERY step still equal the serial run's, bit for bit."""
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_check.py"), "base.en", "q5_0", "8", "12"], env=dict(os.environ, GGML_MI355X_TEST_FAULT="reject:3"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["errors"] == [] and d["finite"], d
+    assert d["rows_compared"] == 8 * 12 and d["mismatching_rows"] == 0, d
+    assert d["batch_stats"]["fallbacks"] >= 1 and d["batch_stats"]["chains"] >= 2, d["batch_stats"]      # two chains left merged, the third was rejected
+
+
 def test_bench_smoke():
     """bench.py end to end on a small model: one JSON line with the contract's keys, roofline measured live"""
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--arch", "base.en", "--qtype", "q5_0", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],

@@ -938,12 +938,15 @@ static int  run_node(mi_backend_ctx * b, const ggml_tensor * n);
 // (W_o . attention + bias) that is added to the residual stream, src/whisper.cpp:2703-2770 — by `factor`, for steps of up to 8 columns.
 // Cross-attention = the FLASH_ATTN_EXT nodes without a mask (decoder self-attention carries one; encoder attention has > 8 columns and
 // never passes here).  Unset: the factor is exactly 1 and nothing changes.
-struct mi_test_fault { int layer = -2; float factor = 1.0f; };
+// "reject:<n>": the n-th merged launch chain of the process (cross-state batching, counted from 1) reports a kernel-side rejection half-way
+// through its walk — the mid-chain path of mi_compute_batch (drain, every member repeats the step on its own chain, the shape stops batching).
+struct mi_test_fault { int layer = -2; float factor = 1.0f; int reject_chain = 0; };
 static const mi_test_fault & mi_fault() {
     static const mi_test_fault f = [] {
         mi_test_fault t;
         const char * e = getenv("GGML_MI355X_TEST_FAULT");
         if (e && !strncmp(e, "xattn:", 6)) { int l = 0; float x = 1.0f; if (sscanf(e + 6, "%d:%f", &l, &x) == 2) { t.layer = l; t.factor = x; } }
+        if (e && !strncmp(e, "reject:", 7)) t.reject_chain = atoi(e + 7);
         return t;
     }();
     return f;
@@ -1469,9 +1472,12 @@ static bool q_mm(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int i, in
 static int mi_walk_batch(mi355x_ctx * k, const mi_colset & cs) {
     const ggml_cgraph * g = cs.g[0];
     mi_qstate qs;
+    static std::atomic<int> n_real_walks{0};
+    const bool inject_reject = k && mi_fault().reject_chain > 0 && ++n_real_walks == mi_fault().reject_chain;      // (TEST fault injection, see mi_test_fault)
     for (int i = 0; i < g->n_nodes; i++) {
         const ggml_tensor * n = g->nodes[i];
         if (op_is_empty(n) || ggml_is_empty(n) || !(n->flags & GGML_TENSOR_FLAG_COMPUTE)) continue;
+        if (inject_reject && i > g->n_nodes / 2) { mi355x_flush(k); GGML_LOG_WARN("ggml-mi355x: TEST fault: merged chain rejected at node %d of %d\n", i, g->n_nodes); return (int) hipErrorInvalidValue; }
         int end = i, rc = 0;
         bool took = false;
         if (n->op == GGML_OP_GET_ROWS) {
