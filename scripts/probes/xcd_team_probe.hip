@@ -11,6 +11,8 @@
 //   * the first weight rows of the NEXT stage are requested before a wave starts polling for the current stage's input.
 // Same arithmetic as persist_probe's chains (int8 weights x per-32-block int8 activations, tanh, stage 3 also streams 7.86 MB of
 // per-stream "cross K/V"), results checked bit for bit against a launch chain.  Every spin is bounded.
+// Findings (profiles/r04_xcd_team_probe.txt): exchange alone 1.8 us per stage; row streaming 8.6-10.1 us per stage whatever the team count or bytes;
+// 8 teams = 1.43-1.53 x the merged chains: below the 2 x bar.
 // Question to answer with a number: us per stage per team with all 8 teams running, against the 4.06 us launch chain that serves ONE
 // stream (or 8 columns in ~2.5 ms per step when merged: 9.35 chunks/s for 8 streams).  8 teams at S us per stage are
 // 8 / (224 * S us) tokens per second; break-even with twice the merged chains' 9.35 chunks/s (4790 tokens/s) is S = 7.5 us.
@@ -44,6 +46,8 @@ struct Chain {
     int * team_count;            // [NXCD]
     int * err;
     int n_layers, active_teams, sc1_stores, prefetch;
+    int rows_mode;               // 0: one row at a time (first edition); 1: batches of rows, two batches in flight
+    int anatomy;                 // 0: the real thing; 1: no exchange (a stage does not wait for its input: loads + arithmetic only); 2: exchange only (no weight rows)
     int frac16;                  // sixteenths of a row's bytes that are read: 16 = int8 weights, 11 = the bytes of Q5_0 (0.6875 B per weight)
 };
 
@@ -133,7 +137,69 @@ __device__ __forceinline__ void store_gran(unsigned long long * p, unsigned long
     else     asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");          // plain: the line stays in this XCD's L2
 }
 
-__global__ void __launch_bounds__(NTT) k_teams(const Chain c, const float * x0, float * y_out) {
+// ---- rows in BATCHES (team kernel, rows_mode 1): a wave requests RB rows at once and, before it reduces them, the next RB rows — in
+// straight-line code, so that the compiler's counted vmcnt waits leave the younger batch in flight (the row-at-a-time loop above ends up
+// behind a vmcnt(0) per row: one memory round trip per row, 1.2 us — what the first edition of this probe measured as "the team").
+template <int KB, bool EXTRA> struct RowT { int4 w[KB][2]; int4 e[EXTRA ? 6 : 1]; };
+template <int KB, bool EXTRA> __device__ __forceinline__ void rowt_load(RowT<KB, EXTRA> & r, const int8_t * w, int nb, const int8_t * e, int lane) {
+#pragma unroll
+    for (int i = 0; i < KB; i++) { const int b = lane + i * 64, bc = b < nb ? b : nb - 1; r.w[i][0] = ((const int4 *) (w + (size_t) bc * 32))[0]; r.w[i][1] = ((const int4 *) (w + (size_t) bc * 32))[1]; }
+    if (EXTRA) {
+#pragma unroll
+        for (int i = 0; i < EXTRA_ROW / 1024; i++) r.e[i] = *(const int4 *) (e + lane * 16 + i * 1024);
+    }
+}
+template <int KB, bool EXTRA> __device__ __forceinline__ float rowt_value(const RowT<KB, EXTRA> & r, int nb, const int8_t * xs, const float * xd, int lane) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        const int b = lane + i * 64;
+        if (b < nb) { const int4 * xp = (const int4 *) (xs + b * 32); acc = fmaf(xd[b] * (1.0f / 64.0f), (float) dot32(r.w[i][0], r.w[i][1], xp[0], xp[1]), acc); }
+    }
+    acc = wave_sum(acc);
+    float ex = 0.0f;
+    if (EXTRA) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < EXTRA_ROW / 1024; i++) s += (r.e[i].x & 1) + (r.e[i].y & 1) + (r.e[i].z & 1) + (r.e[i].w & 1);
+        ex = (float) wave_sum_i(s) * 1e-9f;
+    }
+    return tanhf(acc + ex);
+}
+struct StageCtx { const int8_t * wbase; const int8_t * extra; int K, nb, per, r0, wave, lane; const int8_t * xs; const float * xd; unsigned long long * go; unsigned tag; int sc1; float * y_last; };
+template <int KB, bool EXTRA, int RB> __device__ __forceinline__ void batch_load(RowT<KB, EXTRA> * R, const StageCtx & q, int b) {
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        int i = q.wave + NWT * (b * RB + j); i = i < q.per ? i : q.per - 1;            // past the end: the last row again (never published)
+        const int row = q.r0 + i;
+        rowt_load<KB, EXTRA>(R[j], q.wbase + (size_t) row * q.K, q.nb, EXTRA ? q.extra + (size_t) row * EXTRA_ROW : nullptr, q.lane);
+    }
+}
+template <int KB, bool EXTRA, int RB> __device__ __forceinline__ void batch_compute(const RowT<KB, EXTRA> * R, const StageCtx & q, int b) {
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        const int i = q.wave + NWT * (b * RB + j);
+        const float v = rowt_value<KB, EXTRA>(R[j], q.nb, q.xs, q.xd, q.lane);
+        if (q.lane == 0 && i < q.per) {
+            store_gran(q.go + q.r0 + i, ((unsigned long long) q.tag << 32) | (unsigned long long) __float_as_uint(v), q.sc1 != 0);
+            if (q.y_last) q.y_last[q.r0 + i] = v;
+        }
+    }
+}
+template <int KB, bool EXTRA, int RB> __device__ __forceinline__ void stage_rows(const StageCtx & q) {
+    const int mine = q.wave < q.per ? (q.per - q.wave + NWT - 1) / NWT : 0, nbatch = (mine + RB - 1) / RB;
+    RowT<KB, EXTRA> A[RB], B[RB];
+    if (nbatch > 0) batch_load<KB, EXTRA, RB>(A, q, 0);
+    for (int b = 0; b < nbatch; b += 2) {
+        if (b + 1 < nbatch) batch_load<KB, EXTRA, RB>(B, q, b + 1);
+        batch_compute<KB, EXTRA, RB>(A, q, b);
+        if (b + 2 < nbatch) batch_load<KB, EXTRA, RB>(A, q, b + 2);
+        if (b + 1 < nbatch) batch_compute<KB, EXTRA, RB>(B, q, b + 1);
+    }
+}
+
+
+template <int RM> __global__ void __launch_bounds__(NTT) k_teams(const Chain c, const float * x0, float * y_out) {
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];      // (sized so that one workgroup fits per CU)
     int8_t * xs = smem;
     float * xd = (float *) (smem + 5120);
@@ -153,12 +219,12 @@ __global__ void __launch_bounds__(NTT) k_teams(const Chain c, const float * x0, 
     const int total = c.n_layers * NSTAGE;
     unsigned tag = 1;
     bool failed = false;
-    Row cur, nxt;
+    Row cur, nxt;              // (RM == 0 only)
     auto first_row = [&](int s, Row & r) {
         const int per = stage_n(s) / TEAM, K = stage_k(s), i = wave;
         if (i < per) { const int row = rank * per + i; row_load(r, c.w + stage_woff(s) + (size_t) row * K, K, stage_extra(s) ? extra + (size_t) row * EXTRA_ROW : nullptr, lane, c.frac16); }
     };
-    first_row(0, cur);
+    if (RM == 0) first_row(0, cur);
     for (int t = 0; t < total; t++, tag++) {
         const int s = t % NSTAGE, N = stage_n(s), K = stage_k(s);
         // ---- input vector: x0 or the previous stage's granules of THIS team ----
@@ -178,7 +244,7 @@ __global__ void __launch_bounds__(NTT) k_teams(const Chain c, const float * x0, 
                     const int limit = failed ? 1 : (1 << 18);
                     do {
                         load_gran4(gr + base, q);
-                        ok = (unsigned) (q[0] >> 32) == want && (unsigned) (q[1] >> 32) == want && (unsigned) (q[2] >> 32) == want && (unsigned) (q[3] >> 32) == want;
+                        ok = c.anatomy == 1 || ((unsigned) (q[0] >> 32) == want && (unsigned) (q[1] >> 32) == want && (unsigned) (q[2] >> 32) == want && (unsigned) (q[3] >> 32) == want);
                         if (!ok) __builtin_amdgcn_s_sleep(1);
                     } while (!ok && ++spins < limit);
                     if (!ok) { failed = true; atomicExch(c.err, 1); }
@@ -193,6 +259,16 @@ __global__ void __launch_bounds__(NTT) k_teams(const Chain c, const float * x0, 
         const int per = N / TEAM, r0 = rank * per;
         unsigned long long * go = gran + (size_t) s * 5120;
         const int8_t * wbase = c.w + stage_woff(s);
+        if (c.anatomy == 2) {          // exchange only: publish this workgroup's granules without touching the weights
+            for (int i = tid; i < per; i += NTT) store_gran(go + r0 + i, ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(0.25f), c.sc1_stores != 0);
+        } else if constexpr (RM == 1) {
+            StageCtx q = { wbase, extra, K, eff_blocks(K, c.frac16), per, r0, wave, lane, xs, xd, go, tag, c.sc1_stores, t == total - 1 ? y_out + (size_t) xcc * 1280 : nullptr };
+            const int kb = (q.nb + 63) >> 6;
+            if (stage_extra(s))  stage_rows<1, true, 2>(q);
+            else if (kb == 1)    stage_rows<1, false, 8>(q);
+            else if (kb == 2)    stage_rows<2, false, 4>(q);
+            else                 stage_rows<3, false, 2>(q);
+        } else if constexpr (RM == 0)
         for (int i = wave; i < per; i += NWT) {
             const bool more = i + NWT < per;
             if (more) { const int row = r0 + i + NWT; row_load(nxt, wbase + (size_t) row * K, K, stage_extra(s) ? extra + (size_t) row * EXTRA_ROW : nullptr, lane, c.frac16); }
@@ -204,7 +280,7 @@ __global__ void __launch_bounds__(NTT) k_teams(const Chain c, const float * x0, 
             }
             cur = nxt;
         }
-        if (!c.prefetch && t + 1 < total) first_row((t + 1) % NSTAGE, cur);
+        if (RM == 0 && !c.prefetch && c.anatomy != 2 && t + 1 < total) first_row((t + 1) % NSTAGE, cur);
         __syncthreads();                                       // xs / xd are rewritten by the next stage
     }
 }
@@ -255,16 +331,25 @@ int main(int argc, char ** argv) {
 
     // ---- teams ----
     const size_t lds = 96 * 1024;                                  // > half of the CU's 160 KB: one workgroup per CU
-    CK(hipFuncSetAttribute((const void *) k_teams, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    struct V { const char * name; int teams, sc1, prefetch; } vs[] = {
-        { "8 teams, plain stores (XCD-local L2), next stage prefetched", 8, 0, 1 },
-        { "8 teams, plain stores (XCD-local L2), no prefetch",           8, 0, 0 },
-        { "8 teams, sc1 stores (what a device-wide exchange needs)",     8, 1, 1 },
-        { "1 team alone (the other 7 XCDs idle), prefetch",              1, 0, 1 },
-        { "4 teams, prefetch",                                           4, 0, 1 },
+    CK(hipFuncSetAttribute((const void *) k_teams<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    CK(hipFuncSetAttribute((const void *) k_teams<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    struct V { const char * name; int teams, sc1, prefetch, anatomy, rows_mode; } vs[] = {
+        { "8 teams, rows in batches (two batches in flight)",             8, 0, 0, 0, 1 },
+        { "8 teams, rows in batches, sc1 stores",                         8, 1, 0, 0, 1 },
+        { "4 teams, rows in batches",                                     4, 0, 0, 0, 1 },
+        { "1 team alone, rows in batches",                                1, 0, 0, 0, 1 },
+        { "anatomy: 8 teams, rows in batches, NO exchange",               8, 0, 0, 1, 1 },
+        { "first edition (one row at a time): 8 teams, next stage prefetched", 8, 0, 1, 0 },
+        { "8 teams, plain stores (XCD-local L2), no prefetch",           8, 0, 0, 0 },
+        { "8 teams, sc1 stores (what a device-wide exchange needs)",     8, 1, 1, 0 },
+        { "1 team alone (the other 7 XCDs idle), prefetch",              1, 0, 1, 0 },
+        { "4 teams, prefetch",                                           4, 0, 1, 0 },
+        { "anatomy: 8 teams, NO exchange (loads + arithmetic only)",      8, 0, 0, 1 },
+        { "anatomy: 8 teams, exchange ONLY (no weight rows)",             8, 0, 0, 2 },
+        { "anatomy: 1 team, NO exchange",                                 1, 0, 0, 1 },
     };
     for (const V & v : vs) {
-        c.active_teams = v.teams; c.sc1_stores = v.sc1; c.prefetch = v.prefetch;
+        c.active_teams = v.teams; c.sc1_stores = v.sc1; c.prefetch = v.prefetch; c.anatomy = v.anatomy; c.rows_mode = v.rows_mode;
         double best = 1e30; int herr = 0; int counts[NXCD];
         for (int rep = 0; rep < 6; rep++) {
             CK(hipMemsetAsync(c.gran, 0, (size_t) NXCD * NSTAGE * 5120 * 8, st));
@@ -272,7 +357,8 @@ int main(int argc, char ** argv) {
             CK(hipMemsetAsync(yteam, 0, NXCD * 1280 * 4, st));
             CK(hipStreamSynchronize(st));
             const double t0 = now_us();
-            k_teams<<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam);
+            if (v.rows_mode) k_teams<1><<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam);
+            else             k_teams<0><<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam);
             CK(hipStreamSynchronize(st));
             const double t = now_us() - t0;
             if (rep > 1 && t < best) best = t;
