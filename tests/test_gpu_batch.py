@@ -300,7 +300,7 @@ def test_attention_combine_through_planes_is_bit_identical_to_the_fused_projecti
     assert np.array_equal(ya.cpu().numpy().view(np.uint32), yb.cpu().numpy().view(np.uint32))
 
 
-@pytest.mark.parametrize("T", [8, 16, 29])
+@pytest.mark.parametrize("T", [8, 16, 20, 29])
 @pytest.mark.parametrize("t", ["q5_0", "q8_0", "q4_K"])          # (Q4_K: no k_vocab — T > 8 goes image by image through k_gemv8)
 def test_vocabulary_projection_over_planes_with_per_state_destinations(gpu, oracle, t, T):
     """final LayerNorm + logits (N = 51866: k_vocab) for T columns that belong to T states (T > 8: images of 8 columns)"""
