@@ -56,7 +56,7 @@ trace)
 pmc16)
     stage "rocprofv3 --pmc FETCH_SIZE of 16 batched streams in ONE chain of 16 columns (are the weights read once per step?)"
     rm -rf "$OUT/pmc16"; mkdir -p "$OUT/pmc16"
-    ( cd /tmp && GGML_MI355X_BATCH_COLS=16 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc16" -o p16 --output-format csv -- python3 "$ROOT/scripts/stream_scaling.py" --streams 16 --batching 1 --steps 1 --n-decode 12 > "$OUT/pmc16/run.log" 2>&1 )
+    ( cd /tmp && GGML_MI355X_BATCH_COLS=16 GGML_MI355X_BATCH_WINDOW_US=500000 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc16" -o p16 --output-format csv -- python3 "$ROOT/scripts/stream_scaling.py" --streams 16 --batching 1 --steps 1 --n-decode 12 > "$OUT/pmc16/run.log" 2>&1 )
     echo "exit=$?"
     python3 scripts/summarize_pmc.py "$OUT/pmc16" > "$OUT/pmc16_FETCH_SIZE.summary.txt" 2>&1; grep -E "k_gemv_q|k_vocab|k_fattn_dec_multi|k_act_prepare|Kernel|kernel" "$OUT/pmc16_FETCH_SIZE.summary.txt" | head -20 | cut -c1-220
     find "$OUT/pmc16" -name "*.csv" -size +20M -delete
