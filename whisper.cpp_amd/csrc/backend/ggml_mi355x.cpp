@@ -1882,10 +1882,11 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
 
 static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     static const double window_ms = getenv("GGML_MI355X_BATCH_WINDOW_US") ? atof(getenv("GGML_MI355X_BATCH_WINDOW_US")) * 1e-3 : 3.0;
-    // columns per merged chain.  GGML_MI355X_BATCH_COLS=n (2..32) fixes it; by default 60 % of the decoding states (at least 6) ride one chain and
+    // columns per merged chain.  GGML_MI355X_BATCH_COLS=n (2..32) fixes it; by default 60 % of the decoding states (at least 4) ride one chain and
     // the rest a second one next to it (MI_BATCH_LANES streams): two chains of unequal width fill each other's launch gaps.  Measured on large-v3
     // Q5_0 (profiles/r04_stream_scaling.txt, r04_chain_split_sweep.txt): 16 states as 10 + 6: 14.2 chunks/s, 12 + 4: 13.9, 8 + 8: 11.5-12.5, one
-    // chain of 16: 12.9; 32 as 20 + 12: 18.0, 16 + 16: 15.3; 8 as 6 + 2: 10.0, one chain of 8: 9.3; three or more chains (40 %): 11.0 at 32.
+    // chain of 16: 12.9; 32 as 20 + 12: 18.0, 16 + 16: 15.3; 8 as 5 + 3 or 6 + 2: 9.4-10.0, one chain of 8: 9.3; 6 as 4 + 2: 8.2, one chain of 6: 7.4; 7 as 5 + 2: 8.7, 6 + 1: 7.2; three or more chains
+    // (40 %): 11.0 at 32; chains of 3 + 2 at 5 states: 4.9 (one chain of 4 + a solo state: 6.6).
     // More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still read once per chain step.
     static const int env_cols = getenv("GGML_MI355X_BATCH_COLS") ? std::max(2, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_COLS")))) : 0;
     mi_batch_group & grp = g_batch[b->device];
@@ -1894,7 +1895,7 @@ static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
     // (A-B switches of that rule: GGML_MI355X_BATCH_SPLIT_PCT = the share of the decoding states a chain may carry, _SPLIT_MIN = its floor)
     static const int split_pct = getenv("GGML_MI355X_BATCH_SPLIT_PCT") ? std::max(10, std::min(100, atoi(getenv("GGML_MI355X_BATCH_SPLIT_PCT")))) : 60;
-    static const int split_min = getenv("GGML_MI355X_BATCH_SPLIT_MIN") ? std::max(1, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_SPLIT_MIN")))) : 6;
+    static const int split_min = getenv("GGML_MI355X_BATCH_SPLIT_MIN") ? std::max(1, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_SPLIT_MIN")))) : 4;
     auto cols_cap = [&]() {
         if (env_cols) return env_cols;
         return std::min(MI355X_MAX_COLS, std::max(split_min, (split_pct * (int) grp.members.size() + 99) / 100));
