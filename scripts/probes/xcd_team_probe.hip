@@ -11,8 +11,8 @@
 //   * the first weight rows of the NEXT stage are requested before a wave starts polling for the current stage's input.
 // Same arithmetic as persist_probe's chains (int8 weights x per-32-block int8 activations, tanh, stage 3 also streams 7.86 MB of
 // per-stream "cross K/V"), results checked bit for bit against a launch chain.  Every spin is bounded.
-// Findings (profiles/r04_xcd_team_probe.txt): exchange alone 1.8 us per stage; row streaming 8.6-10.1 us per stage whatever the team count or bytes;
-// 8 teams = 1.43-1.53 x the merged chains: below the 2 x bar.
+// Findings (profiles/r04_xcd_team_probe.txt): exchange alone 1.8 us per stage; rows requested after the exchange: 9.7-10.3 us per stage whatever the
+// team count or bytes; next stage's first batch requested BEFORE the exchange (k_teams3): 7.53 us = 4740 tokens/s with 8 teams = 1.98 x the merged chains.
 // Question to answer with a number: us per stage per team with all 8 teams running, against the 4.06 us launch chain that serves ONE
 // stream (or 8 columns in ~2.5 ms per step when merged: 9.35 chunks/s for 8 streams).  8 teams at S us per stage are
 // 8 / (224 * S us) tokens per second; break-even with twice the merged chains' 9.35 chunks/s (4790 tokens/s) is S = 7.5 us.
@@ -199,6 +199,162 @@ template <int KB, bool EXTRA, int RB> __device__ __forceinline__ void stage_rows
 }
 
 
+// ---- third edition: stages known at compile time, the NEXT stage's first batch of rows requested before the exchange ---------------------
+// A stage's weights do not depend on its input: the first batch of stage t + 1 is requested while stage t's last batch is still being
+// reduced, and lands while the team exchanges stage t's results (1.8 us) — the one memory round trip per stage that the editions above pay
+// after every exchange.  Register buffers are generic (16 x int4 each: X0 / X1 alternate as "first batch of this stage" / "first batch of the
+// next stage", Y is the stage's own second buffer); a row of type (KB, EX) takes 2 KB + 6 EX of them.
+#ifndef GBUF
+#define GBUF 16
+#endif
+template <int FR, int S> struct StT {
+    static constexpr int K = stage_k(S), N = stage_n(S), NB = ((K >> 5) * FR + 15) >> 4, KB = (NB + 63) >> 6, PER = N / TEAM;
+    static constexpr bool EX = stage_extra(S);
+    static constexpr int RW = 2 * KB + (EX ? 6 : 0), RB = GBUF / RW;                                    // int4 per row, rows per batch (8 / 4 / 2 / 2)
+    static constexpr int MINE_MAX = (PER + NWT - 1) / NWT, NBATCH = (MINE_MAX + RB - 1) / RB;      // (the same for every wave up to clamped duplicates)
+};
+struct TeamCtx { const Chain * c; const int8_t * extra; unsigned long long * gran; const float * x0; float * y_team; int8_t * xs; float * xd; int rank, wave, lane, tid; bool failed; int zero; };
+
+template <int KB, bool EX, int RB> __device__ __forceinline__ void gbatch_load(int4 (&R)[GBUF], const StageCtx & q, int b) {
+    constexpr int RW = 2 * KB + (EX ? 6 : 0);
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        int i = q.wave + NWT * (b * RB + j); i = i < q.per ? i : q.per - 1;            // past the end: the last row again (never published)
+        const int row = q.r0 + i;
+        const int8_t * w = q.wbase + (size_t) row * q.K;
+#pragma unroll
+        for (int k = 0; k < KB; k++) { const int blk = q.lane + k * 64, bc = blk < q.nb ? blk : q.nb - 1; R[j*RW + 2*k] = ((const int4 *) (w + (size_t) bc * 32))[0]; R[j*RW + 2*k + 1] = ((const int4 *) (w + (size_t) bc * 32))[1]; }
+        if (EX) {
+            const int8_t * e = q.extra + (size_t) row * EXTRA_ROW;
+#pragma unroll
+            for (int k = 0; k < EXTRA_ROW / 1024; k++) R[j*RW + 2*KB + k] = *(const int4 *) (e + q.lane * 16 + k * 1024);
+        }
+    }
+}
+template <int KB, bool EX, int RB> __device__ __forceinline__ void gbatch_compute(const int4 (&R)[GBUF], const StageCtx & q, int b) {
+    constexpr int RW = 2 * KB + (EX ? 6 : 0);
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        const int i = q.wave + NWT * (b * RB + j);
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KB; k++) {
+            const int blk = q.lane + k * 64;
+            if (blk < q.nb) { const int4 * xp = (const int4 *) (q.xs + blk * 32); acc = fmaf(q.xd[blk] * (1.0f / 64.0f), (float) dot32(R[j*RW + 2*k], R[j*RW + 2*k + 1], xp[0], xp[1]), acc); }
+        }
+        acc = wave_sum(acc);
+        float ex = 0.0f;
+        if (EX) {
+            int sm = 0;
+#pragma unroll
+            for (int k = 0; k < EXTRA_ROW / 1024; k++) { const int4 e = R[j*RW + 2*KB + k]; sm += (e.x & 1) + (e.y & 1) + (e.z & 1) + (e.w & 1); }
+            ex = (float) wave_sum_i(sm) * 1e-9f;
+        }
+        const float v = tanhf(acc + ex);
+        if (q.lane == 0 && i < q.per) {
+            store_gran(q.go + q.r0 + i, ((unsigned long long) q.tag << 32) | (unsigned long long) __float_as_uint(v), q.sc1 != 0);
+            if (q.y_last) q.y_last[q.r0 + i] = v;
+        }
+    }
+}
+template <int FR, int S> __device__ __forceinline__ StageCtx stage_ctx(const TeamCtx & T, unsigned tag, bool last) {
+    typedef StT<FR, S> P;
+    StageCtx q = { T.c->w + stage_woff(S) + T.zero, T.extra + T.zero, P::K, P::NB, P::PER, T.rank * P::PER, T.wave, T.lane, T.xs + T.zero, T.xd + T.zero, T.gran + (size_t) S * 5120 + T.zero, tag, T.c->sc1_stores, last ? T.y_team : nullptr };
+    return q;
+}
+// input of stage S: x0 (very first stage) or the granules of stage S - 1 with tag `want`
+template <int FR, int S> __device__ __forceinline__ void stage_input(TeamCtx & T, bool first, unsigned want) {
+    constexpr int K = StT<FR, S>::K;
+    const unsigned long long * gr = T.gran + (size_t) ((S + NSTAGE - 1) % NSTAGE) * 5120 + T.zero;
+    for (int base = T.tid * 4; base < ((K + NTT * 4 - 1) / (NTT * 4)) * NTT * 4; base += NTT * 4) {
+        const bool in = base < K;
+        float v[4] = { 0, 0, 0, 0 };
+        if (in) {
+            if (first) { v[0] = T.x0[base]; v[1] = T.x0[base + 1]; v[2] = T.x0[base + 2]; v[3] = T.x0[base + 3]; }
+            else {
+                unsigned long long q[4]; int spins = 0; bool ok;
+                const int limit = T.failed ? 1 : (1 << 18);
+                do {
+                    load_gran4(gr + base, q);
+                    ok = T.c->anatomy == 1 || ((unsigned) (q[0] >> 32) == want && (unsigned) (q[1] >> 32) == want && (unsigned) (q[2] >> 32) == want && (unsigned) (q[3] >> 32) == want);
+                    if (!ok) __builtin_amdgcn_s_sleep(1);
+                } while (!ok && ++spins < limit);
+                if (!ok) { T.failed = true; atomicExch(T.c->err, 1); }
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = __uint_as_float((unsigned) q[j]);
+            }
+        }
+        quant4(v[0], v[1], v[2], v[3], base, K, T.xs, T.xd);
+    }
+}
+// one stage: batches 0, 1, 2, ... of the stage alternate between the two register buffers, batch 0 (requested during the previous stage) sits
+// in `A`; the next stage's first batch is requested into whichever buffer does NOT hold this stage's last batch, before that batch is reduced
+template <int FR, int S> __device__ __forceinline__ void run_stage(TeamCtx & T, int4 (&A)[GBUF], int4 (&Bf)[GBUF], bool first, bool last, bool more, unsigned tag) {
+    typedef StT<FR, S> P; typedef StT<FR, (S + 1) % NSTAGE> Pn;
+    static_assert(P::NBATCH >= 1 && P::NBATCH <= 3, "batches per stage");
+    asm volatile("" : "+s"(T.zero));                      // (keeps this stage's address arithmetic inside the stage: see k_teams3)
+    stage_input<FR, S>(T, first, tag - 1);
+    __syncthreads();
+    const StageCtx q = stage_ctx<FR, S>(T, tag, last);
+    const StageCtx qn = stage_ctx<FR, (S + 1) % NSTAGE>(T, tag + 1, false);
+    if constexpr (P::NBATCH > 1) gbatch_load<P::KB, P::EX, P::RB>(Bf, q, 1); else { if (more) gbatch_load<Pn::KB, Pn::EX, Pn::RB>(Bf, qn, 0); }
+    gbatch_compute<P::KB, P::EX, P::RB>(A, q, 0);
+    if constexpr (P::NBATCH > 1) {
+        if constexpr (P::NBATCH > 2) gbatch_load<P::KB, P::EX, P::RB>(A, q, 2); else { if (more) gbatch_load<Pn::KB, Pn::EX, Pn::RB>(A, qn, 0); }
+        gbatch_compute<P::KB, P::EX, P::RB>(Bf, q, 1);
+    }
+    if constexpr (P::NBATCH > 2) {
+        if (more) gbatch_load<Pn::KB, Pn::EX, Pn::RB>(Bf, qn, 0);
+        gbatch_compute<P::KB, P::EX, P::RB>(A, q, 2);
+    }
+    __syncthreads();                                       // xs / xd are rewritten by the next stage
+}
+// the seven stages of a layer; PAR = which buffer holds the stage's first batch (it flips after a stage with an odd number of batches)
+template <int FR, int S, int PAR> struct LayerRun {
+    static constexpr int NEXT = PAR ^ (StT<FR, S>::NBATCH & 1);
+    static constexpr int END = LayerRun<FR, S + 1, NEXT>::END;
+    static __device__ __forceinline__ void go(TeamCtx & T, int4 (&X0)[GBUF], int4 (&X1)[GBUF], bool first_layer, bool last_layer, unsigned & tag) {
+        if constexpr (PAR) run_stage<FR, S>(T, X1, X0, first_layer && S == 0, false, true, tag); else run_stage<FR, S>(T, X0, X1, first_layer && S == 0, false, true, tag);
+        tag++;
+        LayerRun<FR, S + 1, NEXT>::go(T, X0, X1, first_layer, last_layer, tag);
+    }
+};
+template <int FR, int PAR> struct LayerRun<FR, NSTAGE - 1, PAR> {
+    static constexpr int END = PAR ^ (StT<FR, NSTAGE - 1>::NBATCH & 1);
+    static __device__ __forceinline__ void go(TeamCtx & T, int4 (&X0)[GBUF], int4 (&X1)[GBUF], bool, bool last_layer, unsigned & tag) {
+        if constexpr (PAR) run_stage<FR, NSTAGE - 1>(T, X1, X0, false, last_layer, !last_layer, tag); else run_stage<FR, NSTAGE - 1>(T, X0, X1, false, last_layer, !last_layer, tag);
+        tag++;
+    }
+};
+template <int FR> __global__ void __launch_bounds__(NTT) k_teams3(const Chain c, const float * x0, float * y_out) {
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    __shared__ int s_rank, s_xcc;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        s_xcc = (int) (v & 7);
+        s_rank = atomicAdd(c.team_count + s_xcc, 1);
+    }
+    __syncthreads();
+    const int xcc = s_xcc, rank = s_rank;
+    if (rank >= TEAM) { if (tid == 0) atomicExch(c.err, 2); return; }
+    if (xcc >= c.active_teams) return;
+    TeamCtx T = { &c, c.extra + (size_t) xcc * 1280 * EXTRA_ROW, c.gran + (size_t) xcc * NSTAGE * 5120, x0, y_out + (size_t) xcc * 1280, smem, (float *) (smem + 5120), rank, tid >> 6, tid & 63, tid, false, 0 };
+    int4 X0[GBUF], X1[GBUF];
+    { const StageCtx q0 = stage_ctx<FR, 0>(T, 1, false); gbatch_load<StT<FR, 0>::KB, StT<FR, 0>::EX, StT<FR, 0>::RB>(X0, q0, 0); }
+    unsigned tag = 1;
+    // a layer may end with the buffers' roles swapped (LayerRun<FR, 0, 0>::END == 1): two layers per trip bring them back (n_layers is even)
+    constexpr int LP = LayerRun<FR, 0, 0>::END;
+    for (int layer = 0; layer < c.n_layers; layer += 2) {
+        // (an opaque zero in every weight address: left alone, the compiler hoists the ~200 loop-invariant row addresses of the 14 unrolled stages
+        //  out of this loop and spills them)
+        asm volatile("" : "+s"(T.zero));
+        LayerRun<FR, 0, 0>::go(T, X0, X1, layer == 0, false, tag);
+        asm volatile("" : "+s"(T.zero));
+        LayerRun<FR, 0, LP>::go(T, X0, X1, false, layer + 2 >= c.n_layers, tag);
+    }
+}
+
 template <int RM> __global__ void __launch_bounds__(NTT) k_teams(const Chain c, const float * x0, float * y_out) {
     extern __shared__ __attribute__((aligned(16))) int8_t smem[];      // (sized so that one workgroup fits per CU)
     int8_t * xs = smem;
@@ -333,7 +489,14 @@ int main(int argc, char ** argv) {
     const size_t lds = 96 * 1024;                                  // > half of the CU's 160 KB: one workgroup per CU
     CK(hipFuncSetAttribute((const void *) k_teams<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     CK(hipFuncSetAttribute((const void *) k_teams<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    CK(hipFuncSetAttribute((const void *) k_teams3<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    CK(hipFuncSetAttribute((const void *) k_teams3<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     struct V { const char * name; int teams, sc1, prefetch, anatomy, rows_mode; } vs[] = {
+        { "8 teams, compile-time stages, next stage's first batch prefetched", 8, 0, 0, 0, 2 },
+        { "4 teams, compile-time stages + prefetch",                      4, 0, 0, 0, 2 },
+        { "1 team,  compile-time stages + prefetch",                      1, 0, 0, 0, 2 },
+        { "8 teams, compile-time stages + prefetch, sc1 stores",          8, 1, 0, 0, 2 },
+        { "anatomy: 8 teams, compile-time stages + prefetch, NO exchange", 8, 0, 0, 1, 2 },
         { "8 teams, rows in batches (two batches in flight)",             8, 0, 0, 0, 1 },
         { "8 teams, rows in batches, sc1 stores",                         8, 1, 0, 0, 1 },
         { "4 teams, rows in batches",                                     4, 0, 0, 0, 1 },
@@ -357,7 +520,8 @@ int main(int argc, char ** argv) {
             CK(hipMemsetAsync(yteam, 0, NXCD * 1280 * 4, st));
             CK(hipStreamSynchronize(st));
             const double t0 = now_us();
-            if (v.rows_mode) k_teams<1><<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam);
+            if (v.rows_mode == 2) { if (frac16 == 16) k_teams3<16><<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam); else k_teams3<11><<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam); }
+            else if (v.rows_mode) k_teams<1><<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam);
             else             k_teams<0><<<dim3(NXCD * TEAM), dim3(NTT), lds, st>>>(c, dx0, yteam);
             CK(hipStreamSynchronize(st));
             const double t = now_us() - t0;
