@@ -321,7 +321,6 @@ def main():
             legs.append((f"batched_{a.multi_stream}_streams", 1, a.multi_stream))
             if a.multi_stream == 8:
                 legs.append(("batched_16_streams", 1, 16))        # chains of 10 + 6 columns (images of 8) per step (16 streams >= 16 chunks/s)
-                legs.append(("batched_32_streams", 1, 32))        # chains of 20 + 12 columns
             for label, batching, ns in legs:
                 r = host_api.run(model, use_gpu=True, n_devices=1, streams=ns, n_decode=a.n_decode, steps=2, warmup=1, batching=batching)
                 if r["rc"] != 0:
