@@ -29,6 +29,36 @@ def test_kernel_library_exports_its_header():
     assert set(kernels_api.SYMBOLS) <= set(names)
 
 
+def test_activation_layout_sizes_are_host_functions_of_the_header():
+    """include/mi355x_kernels.h: sizes of the two quantized-activation layouts, computed on the host (no device needed).
+    PLANES (decode): 40 bytes per 32 features and column for the Q8_0 family, K + 4 K/256 + 4 K/32 per column for Q8_K (Q4_K weights); more than 8
+    columns = ceil(T/8) images of 8 columns back to back, image g at g * bytes(8 columns).  ROWS (wide products, csrc/kernels/qrows.h): int8 q[T][K] plus
+    one f32 scale per 32 (Q8_0) or per 256 elements and one i32 sum per 32 (Q8_K)."""
+    lib = C.CDLL(str(KERN))
+    lib.mi355x_act_planes_bytes.restype = C.c_size_t
+    lib.mi355x_act_planes_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.mi355x_act_rows_bytes.restype = C.c_size_t
+    lib.mi355x_act_rows_bytes.argtypes = [C.c_int, C.c_int64, C.c_int64]
+    Q5_0, Q4_K = 6, 12
+
+    def al16(n):
+        return (n + 15) // 16 * 16
+    for K in (384, 1280, 5120):
+        full = lib.mi355x_act_planes_bytes(Q5_0, K, 8)
+        assert full == 8 * (K // 32) * 40
+        for T in (1, 3, 8):
+            assert lib.mi355x_act_planes_bytes(Q5_0, K, T) == al16(T * (K // 32) * 40)
+        for T in (9, 12, 16, 17, 29, 32):
+            g = (T + 7) // 8
+            assert lib.mi355x_act_planes_bytes(Q5_0, K, T) == (g - 1) * full + al16((T - 8 * (g - 1)) * (K // 32) * 40), (K, T)
+        assert lib.mi355x_act_rows_bytes(Q5_0, K, 1500) == 1500 * K + 1500 * (K // 32) * 4
+    K = 1280
+    per_col = K + (K // 256) * 4 + (K // 32) * 4
+    assert lib.mi355x_act_planes_bytes(Q4_K, K, 8) == 8 * per_col
+    assert lib.mi355x_act_planes_bytes(Q4_K, K, 11) == 8 * per_col + al16(3 * per_col)
+    assert lib.mi355x_act_rows_bytes(Q4_K, K, 1500) == 1500 * K + 1500 * (K // 256) * 4 + 1500 * (K // 32) * 4
+
+
 def test_plugin_exports_ggml_entry_points():
     if not REFBASE.exists():
         pytest.skip("oracle/_ref not built (reference tree absent)")
