@@ -77,7 +77,9 @@ int main(int argc, char ** argv) {
     const std::vector<float> pcm = synth_pcm(16000 * 11);
     printf("{\"model\": \"%s\"", argv[1]);
     const struct { const char * name; int strategy, beam; } modes[] = { { "greedy", WHISPER_SAMPLING_GREEDY, 1 }, { "beam5", WHISPER_SAMPLING_BEAM_SEARCH, 5 } };
+    const char * only = getenv("FULL_PARITY_ONLY");          // "greedy" / "beam5": that sampler alone (the fault-injection legs of the tests need one)
     for (const auto & m : modes) {
+        if (only && strcmp(only, m.name)) continue;
         const bool greedy = m.beam == 1;
         step_logits la, lb;
         const std::vector<int> a = run(argv[1], false, m.strategy, m.beam, pcm, max_tokens, 8, &la);

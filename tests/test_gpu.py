@@ -817,7 +817,7 @@ def _beam_rows_of_common_histories_agree(g, tol):
     assert g["max_logit_diff_common"] < tol, g
 
 
-PLANTED_CASES = [("base.en", "q5_0"), ("large-v3-turbo", "q8_0"), ("large-v3", "q5_0")]
+PLANTED_CASES = [("base.en", "q5_0")]          # (r04: the large models run the x-planted form below — a test that can fail — instead; GPU-suite time)
 
 
 @pytest.mark.parametrize("arch,qtype", PLANTED_CASES)
@@ -841,11 +841,11 @@ def test_planted_large_margin_model_is_transcribed_token_for_token(plugin_env, a
 XPLANTED_CASES = [("base.en", "q5_0"), ("large-v3-turbo", "q8_0"), ("large-v3", "q5_0")]
 
 
-def _xplanted_parity_holds(d, cand_a, n=96):
+def _xplanted_parity_holds(d, cand_a, n=96, modes=("greedy", "beam5")):
     """greedy and beam-5 through whisper_full(): CPU == plugin, token for token; the greedy transcript is the a-candidates (beam search may
     prefer a sequence through other tokens — it must still be the SAME sequence on both back ends); moderate margins (not the 17-53 logits
     of the planted models)"""
-    for mode in ("greedy", "beam5"):
+    for mode in modes:
         g = d[mode]
         assert g["n_cpu"] >= n and g["cpu"][:n] == g["gpu"][:n], (mode, g["identical_prefix"], g["n_cpu"], g["n_gpu"])
     g = d["greedy"]
@@ -875,14 +875,16 @@ def test_cross_attention_carried_transcript_is_token_exact_and_the_test_can_fail
     d = _full_parity(plugin_env, arch, qtype, exact=False, plant="x", max_tokens="100")
     _xplanted_parity_holds(d, cand_a)
     rec = {"arch": arch, "qtype": qtype, "min_margin": d["greedy"]["min_margin"], "max_logit_diff": d["greedy"]["max_logit_diff"], "faults": {}}
-    for fault in (f"xattn:{last}:-1", f"xattn:{last}:0", f"xattn:{last}:1.01"):
-        df = _full_parity(dict(plugin_env, GGML_MI355X_TEST_FAULT=fault), arch, qtype, exact=False, plant="x", max_tokens="100")
+    # (the fault legs run the greedy sampler only — FULL_PARITY_ONLY — and the 1 % leg on the smallest model only: GPU-suite time)
+    faults = (f"xattn:{last}:-1", f"xattn:{last}:0") + ((f"xattn:{last}:1.01",) if arch == "base.en" else ())
+    for fault in faults:
+        df = _full_parity(dict(plugin_env, GGML_MI355X_TEST_FAULT=fault, FULL_PARITY_ONLY="greedy"), arch, qtype, exact=False, plant="x", max_tokens="100")
         g = df["greedy"]
         rec["faults"][fault] = {"identical_prefix": g["identical_prefix"], "max_logit_diff": g["max_logit_diff"]}
         if fault.endswith(":1.01"):
             continue                                                 # below the floor of any CPU-vs-plugin comparison: recorded only
         with pytest.raises(AssertionError):
-            _xplanted_parity_holds(df, cand_a)
+            _xplanted_parity_holds(df, cand_a, modes=("greedy",))
         if fault.endswith(":-1"):
             p0 = next(p for p in range(8) if cand_a[p] == d["greedy"]["cpu"][0])
             assert g["gpu"][:64] == cand_b[p0:p0 + 64], g["gpu"][:6]   # exactly the other candidate, everywhere
