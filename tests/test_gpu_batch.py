@@ -136,10 +136,13 @@ def test_plain_mat_vec_through_planes_with_per_column_pointers(gpu, oracle, t, K
     tid = QT[t]
     rng = np.random.default_rng(K + N + T + tid)
     x = rng.standard_normal((T, K)).astype(np.float32)
+    x[1::4] *= np.float32(1e-4)                # columns whose Q8_0 scales are f16 DENORMALS (amax / 127 ~ 2e-6): the matrix-core form (decode_mx.hip) forms dw * dx in an f16 MFMA
+    x[2::4, K // 2:] = 0                       # ... and columns with all-zero blocks (scale 0, sums 0)
     wf = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
     blocks, planar = quantize(oracle, ka, tid, wf)
     bias = (rng.standard_normal(N) * 0.1).astype(np.float32)
     res = rng.standard_normal((T, N)).astype(np.float32)
+    res[1::4] = 0                              # (the tiny columns are compared on their own, not under a residual of order 1)
     x_d, w_d, b_d, r_d = dev(torch, x), dev(torch, planar), dev(torch, bias), dev(torch, res)
     alone = []
     for c in range(T):

@@ -22,7 +22,7 @@ BUILD = ROOT / "build"
 REF = Path(os.environ.get("WHISPER_REF", "/root/reference"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-KERNEL_SRCS = ["ctx.hip", "elementwise.hip", "gemv.hip", "decode.hip", "decode_q.hip", "gemm_mfma.hip", "fattn.hip", "fattn_exact.hip", "mel.hip", "mul_mat.hip", "mmq.hip"]
+KERNEL_SRCS = ["ctx.hip", "elementwise.hip", "gemv.hip", "decode.hip", "decode_q.hip", "decode_mx.hip", "gemm_mfma.hip", "fattn.hip", "fattn_exact.hip", "mel.hip", "mul_mat.hip", "mmq.hip"]
 BACKEND_SRCS = ["ggml_mi355x.cpp"]
 
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",

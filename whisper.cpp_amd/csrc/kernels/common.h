@@ -80,6 +80,8 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
 // mat-vec over pre-quantized activation planes (decode_q.hip); MI355X_E_UNSUPPORTED => mi355x_gemv8 copies the same planes (k_gemv8)
 int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
 int mi355x_vocab(mi355x_ctx * ctx, const mi355x_gemv_desc * d);       // decode_q.hip: the vocabulary projection (N > 8192)
+// mat-vec over prepared planes on the matrix cores, 9..32 columns (decode_mx.hip); MI355X_E_UNSUPPORTED => mi355x_vocab / mi355x_gemv_q
+int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d);
 
 // ---------------------------------------------------------------------------------------------
 // tensor helpers (host)

@@ -361,6 +361,10 @@ extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     // more than 8 columns: the plane kernels only (images of 8 columns, decode_q.hip)
     if (d->T > MI355X_IMG_COLS && !d->x_planes && !(!d->x && d->has_norm && d->cols && d->cols->x[0])) return MI355X_E_UNSUPPORTED;
     for (int s = 0; s < d->nseg; s++) if (d->seg[s].ep.bias_per_col) return MI355X_E_UNSUPPORTED;      // (MFMA path only)
+    if (d->x_planes) {   // wide cross-state batches: the matrix-core form (decode_mx.hip), same summation trees as the kernels below
+        const int rc = mi355x_gemv_mx(ctx, d);
+        if (rc != MI355X_E_UNSUPPORTED) return rc;
+    }
     {   // the vocabulary projection has its own kernel (LayerNorm form or prepared planes)
         const int rc = mi355x_vocab(ctx, d);
         if (rc != MI355X_E_UNSUPPORTED) return rc;
