@@ -27,6 +27,9 @@
 // block dots, f32 scale-accumulate).  The reference's CUDA backend makes the same switch from mat-vec to tile kernels above 8 columns
 // (ggml-cuda/mmvq.cuh:3, mmq.cu:259).
 #include "decode_common.h"
+#include <atomic>
+
+#define MX_VOCAB_TILES 4        // row tiles (= waves) per workgroup of the vocabulary projection
 
 typedef int   i32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -44,62 +47,168 @@ struct MXArgs {
 #define MX_ROWS 16
 #define MX_PSTRIDE 20          // floats per column of a partial tile in LDS (16 rows + 4: the float4 stores of 8 lanes hit 32 different banks)
 
-// One pair's operands as they come from memory
-template <int WT, int CG> struct mx_pair {
-    u32x4 aq; uint32_t aqh; uint32_t add;          // this lane's 16 weight bytes (Q8_0) / 16 bytes of nibbles, high bits, the pair's two f16 scales
-    u32x4 bq[CG]; float2 bdx[CG];                  // this lane's 16 activation bytes per column group, the pair's two activation scales
+// ---- wave-private staging area of one UNIT (8 neighbouring blocks of the tile's 16 rows and of every column) --------------------------
+// A lane of the MFMA needs 16 bytes of ITS row / column: 64 lanes in 16 (rows) or 32 (column planes) different cache lines per load
+// instruction, which the texture-address unit serialises (first version of this kernel: 64 cycles per load instruction, fc2 17.7 us —
+// profiles/r05_mx_kbench_v1_direct_operand_loads_on.json).  So a unit is fetched the way it LIES in memory — 128-byte runs (8 blocks x 16
+// bytes of one row's nibbles, of one column's lo or hi plane), 8 lanes per run — parked in LDS, and read back in operand order.  Row /
+// column strides of 144 / 272 / 40 / 20 bytes keep both directions free of bank conflicts (MI355X_MICROARCH.md, LDS table).
+template <int WT, int CG> struct mx_lds {
+    static constexpr int AQ_ROW = WT == MI355X_TYPE_Q8_0 ? 272 : 144;     // 8 blocks x 32 / 16 bytes + 16
+    static constexpr int OFF_AQ  = 0;
+    static constexpr int OFF_AQH = OFF_AQ + 16 * AQ_ROW;                  // [16 rows][8 x u32 + 8]      (Q5_0)
+    static constexpr int OFF_AD  = OFF_AQH + 16 * 40;                     // [16 rows][8 x f16 + 4]
+    static constexpr int OFF_BQ  = OFF_AD + 16 * 20;                      // [2 planes][16 CG columns][8 x 16 + 16]
+    static constexpr int BQ_PLANE = 16 * CG * 144;
+    static constexpr int OFF_BDX = OFF_BQ + 2 * BQ_PLANE;                 // [16 CG columns][8 x f32 + 8]
+    static constexpr int SIZE    = OFF_BDX + 16 * CG * 40;                // multiple of 16
 };
 
-// LS = leaf stride (64: k_gemv_q's tree, 8: k_vocab's), LW = leaves per wave (8 / 2), NU = blocks per leaf, CG = column groups of 16,
-// RTP = row tiles per workgroup (2: the 32 rows of one Q8_0 block of the RESULT, whose planes are written as well)
-template <int WT, int LS, int LW, int NU, int CG, int RTP, bool NSEG1>
-__global__ void __launch_bounds__(RTP * (LS == 8 ? 4 : 8) * 64 > 512 ? 1024 : 512) k_gemv_mx(const MXArgs a) {
-    constexpr int NP = LW / 2;                     // pairs per wave and unit
+// one unit's bytes between the global loads and the LDS stores
+template <int WT, int CG> struct mx_unit {
+    u32x4 aq[WT == MI355X_TYPE_Q8_0 ? 4 : 2]; uint2 aqh; uint32_t ad;
+    u32x4 bq[4 * CG]; uint2 bdx[CG];
+};
+
+// LS = leaf stride (64: k_gemv_q's tree, 8: k_vocab's), NU = units per wave (a unit = the 8 neighbouring leaves' blocks u), CG = column
+// groups of 16, RTP = row tiles per workgroup (LS 64, RTP 2: the 32 rows of one Q8_0 block of the RESULT, whose planes are written as well)
+template <int WT, int LS, int NU, int CG, int RTP, bool NSEG1>
+__global__ void __launch_bounds__(RTP * (LS == 8 ? 1 : 8) * 64 > 512 ? 1024 : 512) k_gemv_mx(const MXArgs a) {
+    typedef mx_lds<WT, CG> L;
+    constexpr bool Q8 = WT == MI355X_TYPE_Q8_0, Q5 = WT == MI355X_TYPE_Q5_0;
+    constexpr int NAQ = Q8 ? 4 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t lut[16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int nwt = a.nwt;
-    const int wave_all = tid >> 6;
-    const int tsel = RTP == 1 ? 0 : __builtin_amdgcn_readfirstlane(wave_all / nwt);
-    const int wave = RTP == 1 ? __builtin_amdgcn_readfirstlane(wave_all) : __builtin_amdgcn_readfirstlane(wave_all - tsel * nwt);
-    const int i = lane & 15, kg = lane >> 4, blkoff = kg >> 1, half = kg & 1;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tsel = RTP == 1 ? 0 : wave_all / nwt;
+    const int wave = RTP == 1 ? wave_all : wave_all - tsel * nwt;
+    const int i = lane & 15, kg = lane >> 4;
     const int K = a.K, nb = K >> 5, T = a.T, ntot = a.ntot;
     const int tile = blockIdx.x * RTP + tsel;
-    const int row0_raw = tile * MX_ROWS;
-    const bool tile_ok = row0_raw < ntot;
-    const int row0 = tile_ok ? row0_raw : 0;
+    const int row0 = tile * MX_ROWS < ntot ? tile * MX_ROWS : 0;
     int s = 0;
     if constexpr (!NSEG1) {
         if (a.nseg > 1 && row0 >= a.row_start[1]) s = 1;
         if (a.nseg > 2 && row0 >= a.row_start[2]) s = 2;
     }
-    const MXSeg & sgr = NSEG1 ? a.seg[0] : a.seg[s];
-    const int rseg = row0 - (NSEG1 ? 0 : a.row_start[s]);          // first row of the tile inside its segment (segments are multiples of 16 rows)
+    const MXSeg & sgr = NSEG1 ? a.seg[0] : a.seg[s];                     // (RTP > 1 only with one segment: the workgroup's tiles share it)
+    const int seg0 = NSEG1 ? 0 : a.row_start[s];
+    const int rseg = row0 - seg0;                                         // first row of the tile inside its segment (segments but the last are multiples of 16 rows)
     const char * wbase = (const char *) sgr.w;
     const int64_t nbt = sgr.nbt;
+    const int Nseg = sgr.N;
+    char * R = smem + (size_t) wave_all * L::SIZE;                        // this wave's staging area
 
     if (tid < 16) lut[tid] = ((tid & 1) ? 0xF0u : 0u) | ((tid & 2) ? 0xF000u : 0u) | ((tid & 4) ? 0xF00000u : 0u) | ((tid & 8) ? 0xF0000000u : 0u);
 
-    // ---- per-lane base addresses -------------------------------------------------------------------------------------------------
-    // A: weight row rseg + i, first block of the wave's leaves (+ blkoff: this lane's block of a pair)
-    const int b0 = LW * wave;                                              // first leaf = first block (unit 0) of the wave
-    const int arow = rseg + i < sgr.N ? rseg + i : sgr.N - 1;             // (the last tile of a matrix whose rows are not a multiple of 16: clamped, never stored)
-    const int64_t ibrow = (int64_t) arow * nb;
-    constexpr int QB = WT == MI355X_TYPE_Q8_0 ? 32 : 16;
-    const char * aq_p  = wbase + (ibrow + b0 + blkoff) * QB + (WT == MI355X_TYPE_Q8_0 ? half * 16 : 0);
-    const char * aqh_p = wbase + nbt * 16 + (ibrow + b0 + blkoff) * 4;                                   // Q5_0 only
-    const char * ad_p  = wbase + nbt * (WT == MI355X_TYPE_Q8_0 ? 32 : (WT == MI355X_TYPE_Q5_0 ? 20 : 16)) + (ibrow + b0) * 2;      // both scales of a pair: one dword
-    // B: column i + 16 c of the planes (columns >= T read column T - 1 again; never stored)
+    // ---- the epilogue's operands of this thread's first outputs: requested now, used after the products (two dependent memory round trips
+    //      — column pointer, then residual — that would otherwise follow the last barrier) -----------------------------------------------
+    typedef const MXArgs __attribute__((address_space(4))) * kargs_t;
+    const kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
+    const int nthreads = blockDim.x;
+    constexpr int NOUT = RTP * MX_ROWS * 16 * CG;                         // outputs of the workgroup: [tile][column][row]
+    constexpr int EPI = 2;
+    struct epi_t { int row, t, tl; float bias, res; void * dcol; float * mcol; bool ok; };
+    auto epi_prep = [&](int o) {
+        epi_t e;
+        e.tl = RTP == 1 ? 0 : o / (MX_ROWS * 16 * CG);
+        const int q = RTP == 1 ? o : o - e.tl * (MX_ROWS * 16 * CG);
+        const int r = q & 15;
+        e.t = q >> 4;
+        const int grow = (blockIdx.x * RTP + e.tl) * MX_ROWS + r;          // row over all segments
+        e.ok = o < NOUT && e.t < T && grow < ntot;
+        e.row = e.ok ? grow - seg0 : 0;
+        const int tc = e.ok ? e.t : 0;
+        e.dcol = ka->cols.dst[NSEG1 ? 0 : s][tc];
+        const float * rcol = ka->cols.res[NSEG1 ? 0 : s][tc];
+        e.mcol = LS == 8 ? (float *) ka->cols.mirror[tc] : nullptr;
+        e.bias = sgr.bias ? sgr.bias[e.row] : 0.0f;
+        e.res  = rcol ? rcol[e.row] : 0.0f;
+        // (has-residual is a property of the segment: every column has one or none — checked by the launcher)
+        return e;
+    };
+    epi_t ep[EPI];
+    #pragma unroll
+    for (int k = 0; k < EPI; k++) ep[k] = epi_prep(tid + k * nthreads);
+    const bool has_res = ka->cols.res[NSEG1 ? 0 : s][0] != nullptr;
+
+    // ---- per-lane addresses of the coalesced loads (unit 0; a later unit adds its block offset) --------------------------------------
+    const int b0 = 8 * wave;                                               // first block of the wave's unit 0
+    auto rowg = [&](int r) { const int x = rseg + r; return (int64_t) (x < Nseg ? x : Nseg - 1) * nb; };      // (the last tile of a matrix whose rows are not a multiple of 16: clamped, never stored)
+    const int pc8 = lane & 7, pc16 = lane & 15, p2 = lane & 3;             // piece of a run: block (16-byte nibble runs), 16-byte piece (Q8_0), pair
+    const char * aq_g[NAQ];
+    #pragma unroll
+    for (int k = 0; k < NAQ; k++) aq_g[k] = Q8 ? wbase + (rowg(4*k + (lane >> 4)) + b0) * 32 : wbase + (rowg(8*k + (lane >> 3)) + b0) * 16;
+    const char * aqh_g = wbase + nbt * 16 + (rowg(lane >> 2) + b0) * 4;
+    const char * ad_g  = wbase + nbt * (Q8 ? 32 : (Q5 ? 20 : 16)) + (rowg(lane >> 2) + b0) * 2;
     const size_t istride = dg_img_stride(WT, K);
-    const char * bq_p[CG]; const char * bdx_p[CG];
+    auto col_img = [&](int col, int & ti, int & Ti) {
+        const int tc = col < T ? col : T - 1;                              // (columns >= T read column T - 1 again; never stored)
+        const int gi = tc >> 3; ti = tc & 7; Ti = T - 8*gi < 8 ? T - 8*gi : 8;
+        return (const char *) a.planes + (size_t) gi * istride;
+    };
+    const char * bq_g[4 * CG]; const char * bdx_g[CG];
+    #pragma unroll
+    for (int k = 0; k < 4 * CG; k++) {
+        const int run = 8*k + (lane >> 3), col = run >> 1, plane = run & 1;
+        int ti, Ti; const char * img = col_img(col, ti, Ti);
+        bq_g[k] = img + (size_t) plane * Ti * nb * 16 + ((size_t) ti * nb + b0) * 16;
+    }
     #pragma unroll
     for (int c = 0; c < CG; c++) {
-        const int t = i + 16*c, tc = t < T ? t : T - 1;
-        const int gi = tc >> 3, ti = tc & 7, Ti = T - 8*gi < 8 ? T - 8*gi : 8;
-        const char * img = (const char *) a.planes + (size_t) gi * istride;
-        bq_p[c]  = img + (size_t) half * Ti * nb * 16 + ((size_t) ti * nb + b0 + blkoff) * 16;
-        bdx_p[c] = img + (size_t) 2 * Ti * nb * 16 + ((size_t) ti * nb + b0) * 4;
+        int ti, Ti; const char * img = col_img(16*c + (lane >> 2), ti, Ti);
+        bdx_g[c] = img + (size_t) 2 * Ti * nb * 16 + ((size_t) ti * nb + b0) * 4;
     }
+    // LDS addresses: stores (run order) and loads (operand order: lane = 16 kg + i, K-group kg = block (kg >> 1) of the pair, half kg & 1)
+    char * aq_s[NAQ];
+    #pragma unroll
+    for (int k = 0; k < NAQ; k++) aq_s[k] = Q8 ? R + L::OFF_AQ + (4*k + (lane >> 4)) * L::AQ_ROW + pc16 * 16 : R + L::OFF_AQ + (8*k + (lane >> 3)) * L::AQ_ROW + pc8 * 16;
+    char * aqh_s = R + L::OFF_AQH + (lane >> 2) * 40 + p2 * 8;
+    char * ad_s  = R + L::OFF_AD + (lane >> 2) * 20 + p2 * 4;
+    char * bq_s[4 * CG];
+    #pragma unroll
+    for (int k = 0; k < 4 * CG; k++) { const int run = 8*k + (lane >> 3); bq_s[k] = R + L::OFF_BQ + (run & 1) * L::BQ_PLANE + (run >> 1) * 144 + pc8 * 16; }
+    char * bdx_s = R + L::OFF_BDX + (lane >> 2) * 40 + p2 * 8;
+    const char * aq_l  = Q8 ? R + L::OFF_AQ + i * L::AQ_ROW + ((kg >> 1) * 2 + (kg & 1)) * 16 : R + L::OFF_AQ + i * L::AQ_ROW + (kg >> 1) * 16;
+    const char * aqh_l = R + L::OFF_AQH + i * 40 + (kg >> 1) * 4;
+    const char * ad_l  = R + L::OFF_AD + i * 20;
+    const char * bq_l  = R + L::OFF_BQ + (kg & 1) * L::BQ_PLANE + i * 144 + (kg >> 1) * 16;
+    const char * bdx_l = R + L::OFF_BDX + i * 40;
+
+    // blocks of unit u that exist (wave-uniform): 8, or fewer at the end of a short row (K = 384: 12 blocks), or none
+    auto unit_blocks = [&](int u) { const int left = nb - (b0 + LS*u); return left < 0 ? 0 : (left < 8 ? left : 8); };
+    mx_unit<WT, CG> G;
+    auto load_unit = [&](int u) {
+        const int nv = unit_blocks(u);                                     // > 0 (caller)
+        const int64_t ub = LS * u;
+        // pieces beyond the row's end read its last block / pair again (never used)
+        const int c8 = pc8 < nv ? pc8 : nv - 1, c16 = pc16 < 2*nv ? pc16 : 2*nv - 1, c2 = 2*p2 < nv ? p2 : (nv >> 1) - 1;
+        #pragma unroll
+        for (int k = 0; k < NAQ; k++) G.aq[k] = __builtin_nontemporal_load((const u32x4 *) (aq_g[k] + (Q8 ? ub * 32 + c16 * 16 : (ub + c8) * 16)));
+        if constexpr (Q5) G.aqh = *(const uint2 *) (aqh_g + (ub + 2*c2) * 4); else G.aqh = make_uint2(0, 0);
+        G.ad = *(const uint32_t *) (ad_g + (ub + 2*c2) * 2);
+        #pragma unroll
+        for (int k = 0; k < 4 * CG; k++) G.bq[k] = *(const u32x4 *) (bq_g[k] + (ub + c8) * 16);
+        #pragma unroll
+        for (int c = 0; c < CG; c++) G.bdx[c] = *(const uint2 *) (bdx_g[c] + (ub + 2*c2) * 4);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_unit = [&]() {
+        #pragma unroll
+        for (int k = 0; k < NAQ; k++) *(u32x4 *) aq_s[k] = G.aq[k];
+        if constexpr (Q5) *(uint2 *) aqh_s = G.aqh;
+        *(uint32_t *) ad_s = G.ad;
+        #pragma unroll
+        for (int k = 0; k < 4 * CG; k++) *(u32x4 *) bq_s[k] = G.bq[k];
+        #pragma unroll
+        for (int c = 0; c < CG; c++) *(uint2 *) (bdx_s + c * 16 * 40) = G.bdx[c];
+        // the wave reads what its own lanes wrote: LDS operations of one wave complete in order; nothing may be moved across this point
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
 
     // ---- constants ------------------------------------------------------------------------------------------------------------------
     int mg; asm volatile("v_mov_b32 %0, 0x4b400000" : "=v"(mg));          // C operand of the integer MFMAs: D read as a float = 12582912 + sum
@@ -107,49 +216,33 @@ __global__ void __launch_bounds__(RTP * (LS == 8 ? 4 : 8) * 64 > 512 ? 1024 : 51
     const f32x4_t zf = { 0.0f, 0.0f, 0.0f, 0.0f };
     const uint32_t m_lo = kg < 2 ? 0xFFFFFFFFu : 0u, m_hi = ~m_lo;        // block b lives in K-groups 0, 1 (lanes 0..31), block b + 1 in 2, 3
     const uint32_t m_s  = kg == 0 ? 0xFFFFFFFFu : 0u;                     // rank-1 scale MFMA: K-slot 0 = element 0 of lanes 0..15
-    const int nsh = (WT == MI355X_TYPE_Q8_0) ? 0 : 4 * half;               // this lane's nibble of every byte
-    const int hsh = 16 * half;                                             // ... and its 16 high bits (Q5_0)
+    const int nsh = Q8 ? 0 : 4 * (kg & 1);                                 // this lane's nibble of every byte
+    const int hsh = 16 * (kg & 1);                                         // ... and its 16 high bits (Q5_0)
     typedef int i32x2_t __attribute__((ext_vector_type(2)));
 
-    // ---- loads of unit u: every pair of the wave (clamped: a pair beyond the row reads the row's last pair again and is not used) ----
-    mx_pair<WT, CG> pr[2][NP];
-    auto load_unit = [&](int u, mx_pair<WT, CG> (&st)[NP]) {
-        #pragma unroll
-        for (int j = 0; j < NP; j++) {
-            int rel = 2*j + LS*u;                                          // block offset from b0
-            if (b0 + rel >= nb) rel = nb - 2 - b0;                         // (wave-uniform; nb is even)
-            mx_pair<WT, CG> & p = st[j];
-            p.aq = __builtin_nontemporal_load((const u32x4 *) (aq_p + (int64_t) rel * QB));
-            if constexpr (WT == MI355X_TYPE_Q5_0) p.aqh = *(const uint32_t *) (aqh_p + (int64_t) rel * 4); else p.aqh = 0;
-            p.add = *(const uint32_t *) (ad_p + (int64_t) rel * 2);
-            #pragma unroll
-            for (int c = 0; c < CG; c++) {
-                p.bq[c]  = *(const u32x4 *) (bq_p[c] + (int64_t) rel * 16);
-                p.bdx[c] = *(const float2 *) (bdx_p[c] + (int64_t) rel * 4);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    load_unit(0, pr[0]);
-    if constexpr (NU > 1) load_unit(1, pr[1]);
-    if constexpr (WT == MI355X_TYPE_Q5_0) __syncthreads();                 // the unpack table is complete
+    load_unit(0);                                                          // (every wave of the launch has a unit 0)
+    if constexpr (Q5) __syncthreads();                                     // the unpack table is complete
+    store_unit();
+    if (NU > 1 && unit_blocks(1) > 0) load_unit(1);
 
-    // ---- units -> leaves: accA / accB = the chains of the pair's two leaves (k_gemv_q: one lane's acc over its units) -------------------
-    f32x4_t accA[NP][CG], accB[NP][CG];
+    // ---- units -> leaves: accA / accB = the chains of a pair's two leaves (k_gemv_q: one lane's acc over its units) ---------------------
+    f32x4_t accA[4][CG], accB[4][CG];
     #pragma unroll
-    for (int j = 0; j < NP; j++)
+    for (int j = 0; j < 4; j++)
         #pragma unroll
         for (int c = 0; c < CG; c++) { accA[j][c] = zf; accB[j][c] = zf; }
     #pragma unroll
     for (int u = 0; u < NU; u++) {
+        const int nv = unit_blocks(u);
+        if (nv <= 0) break;
         #pragma unroll
-        for (int j = 0; j < NP; j++) {
-            if (b0 + 2*j + LS*u >= nb) continue;                           // (wave-uniform) the row has no such blocks: the leaf's chain ends
-            const mx_pair<WT, CG> & p = pr[u & 1][j];
+        for (int j = 0; j < 4; j++) {
+            if (2*j >= nv) continue;                                       // (wave-uniform) the row has no such blocks: the leaf's chain ends
             // A: this lane's 16 signed bytes
-            uint32_t w[4] = { p.aq[0], p.aq[1], p.aq[2], p.aq[3] };
-            if constexpr (WT == MI355X_TYPE_Q5_0) {
-                const uint32_t inv = (~p.aqh) >> hsh;                      // bit k set: element k of this half is negative (x - 16 = 0xF0 | nib)
+            const u32x4 q = *(const u32x4 *) (aq_l + j * (Q8 ? 64 : 32));
+            uint32_t w[4] = { q[0], q[1], q[2], q[3] };
+            if constexpr (Q5) {
+                const uint32_t inv = (~*(const uint32_t *) (aqh_l + j * 8)) >> hsh;      // bit k set: element k of this half is negative (x - 16 = 0xF0 | nib)
                 #pragma unroll
                 for (int e = 0; e < 4; e++) w[e] = ((w[e] >> nsh) & 0x0F0F0F0Fu) | lut[(inv >> (4*e)) & 0xFu];
             } else if constexpr (WT == MI355X_TYPE_Q4_0) {
@@ -159,14 +252,16 @@ __global__ void __launch_bounds__(RTP * (LS == 8 ? 4 : 8) * 64 > 512 ? 1024 : 51
             const i32x4_t a_lo = { (int) (w[0] & m_lo), (int) (w[1] & m_lo), (int) (w[2] & m_lo), (int) (w[3] & m_lo) };
             const i32x4_t a_hi = { (int) (w[0] & m_hi), (int) (w[1] & m_hi), (int) (w[2] & m_hi), (int) (w[3] & m_hi) };
             // scale operands: the pair's two f16 weight scales, K-slot 0 only
-            const uint32_t dd = p.add & m_s;
+            const uint32_t dd = *(const uint32_t *) (ad_l + j * 4) & m_s;
             const i32x2_t sa0 = { (int) (dd & 0xFFFFu), 0 }, sa1 = { (int) (dd >> 16), 0 };
             #pragma unroll
             for (int c = 0; c < CG; c++) {
-                const i32x4_t bq = { (int) p.bq[c][0], (int) p.bq[c][1], (int) p.bq[c][2], (int) p.bq[c][3] };
+                const u32x4 bqv = *(const u32x4 *) (bq_l + c * 16 * 144 + j * 32);
+                const float2 bdx = *(const float2 *) (bdx_l + c * 16 * 40 + j * 8);
+                const i32x4_t bq = { (int) bqv[0], (int) bqv[1], (int) bqv[2], (int) bqv[3] };
                 const i32x4_t S0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, bq, cmagic, 0, 0, 0);
                 const i32x4_t S1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, bq, cmagic, 0, 0, 0);
-                const i32x2_t sb0 = { (int) (uint32_t) f2h(p.bdx[c].x), 0 }, sb1 = { (int) (uint32_t) f2h(p.bdx[c].y), 0 };      // exact: a Q8_0 scale is an f16 value
+                const i32x2_t sb0 = { (int) (uint32_t) f2h(bdx.x), 0 }, sb1 = { (int) (uint32_t) f2h(bdx.y), 0 };      // exact: a Q8_0 scale is an f16 value
                 const f32x4_t SC0 = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4_t, sa0), __builtin_bit_cast(half4_t, sb0), zf, 0, 0, 0);
                 const f32x4_t SC1 = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4_t, sa1), __builtin_bit_cast(half4_t, sb1), zf, 0, 0, 0);
                 const f32x4_t F0 = __builtin_bit_cast(f32x4_t, S0), F1 = __builtin_bit_cast(f32x4_t, S1);
@@ -177,63 +272,47 @@ __global__ void __launch_bounds__(RTP * (LS == 8 ? 4 : 8) * 64 > 512 ? 1024 : 51
                 }
             }
         }
-        if (u + 2 < NU) load_unit(u + 2, pr[u & 1]);                       // the stage just used is refilled two units ahead
+        if (u + 1 < NU && unit_blocks(u + 1) > 0) {
+            store_unit();                                                  // (behind this unit's LDS reads: in order)
+            if (u + 2 < NU && unit_blocks(u + 2) > 0) load_unit(u + 2);
+        }
     }
-    f32x4_t l1[NP][CG];
-    #pragma unroll
-    for (int j = 0; j < NP; j++)
-        #pragma unroll
-        for (int c = 0; c < CG; c++) l1[j][c] = accA[j][c] + accB[j][c];   // butterfly step lane ^ 1
-    // butterfly steps lane ^ 2, lane ^ 4 inside the wave's leaves.  A leaf without blocks is +0 and x + 0 == x for every x these sums can
+    // butterfly steps lane ^ 1 (the pair), ^ 2, ^ 4 (the wave's pairs).  A leaf without blocks is +0 and x + 0 == x for every x these sums can
     // take (a sum of values that are not -0 is never -0), so adding the empty leaves as k_gemv_q does changes no bit.
     f32x4_t part[CG];
     #pragma unroll
-    for (int c = 0; c < CG; c++) {
-        if constexpr (NP == 4)      part[c] = (l1[0][c] + l1[1][c]) + (l1[2][c] + l1[3][c]);
-        else if constexpr (NP == 2) part[c] = l1[0][c] + l1[1][c];
-        else                        part[c] = l1[0][c];
-    }
-    // ---- partial tiles -> LDS: [tile of the workgroup][wave][column][MX_PSTRIDE], this lane's rows 4 kg .. 4 kg + 3 of column i + 16 c ----
-    float * pt = (float *) smem;
-    #pragma unroll
     for (int c = 0; c < CG; c++)
-        *(f32x4_t *) (pt + ((size_t) (tsel * nwt + wave) * (16*CG) + (i + 16*c)) * MX_PSTRIDE + 4*kg) = part[c];
+        part[c] = ((accA[0][c] + accB[0][c]) + (accA[1][c] + accB[1][c])) + ((accA[2][c] + accB[2][c]) + (accA[3][c] + accB[3][c]));
+    // ---- partial tiles -> LDS, at the head of the wave's own staging area: [column][MX_PSTRIDE], this lane's rows 4 kg .. 4 kg + 3 of column i + 16 c ----
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+    for (int c = 0; c < CG; c++) *(f32x4_t *) ((float *) R + (i + 16*c) * MX_PSTRIDE + 4*kg) = part[c];
     __syncthreads();
 
     // ---- combine over the waves (butterfly steps lane ^ 8, ^ 16, ^ 32), epilogue, stores ----------------------------------------------
-    typedef const MXArgs __attribute__((address_space(4))) * kargs_t;
-    const kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
-    const int nthreads = blockDim.x;
-    float * otile = pt + (size_t) RTP * nwt * (16*CG) * MX_PSTRIDE;       // [column][32] result tile of a planes-out workgroup
-    for (int o = tid; o < RTP * MX_ROWS * 16 * CG; o += nthreads) {
-        const int tl = RTP == 1 ? 0 : o / (MX_ROWS * 16 * CG), e = RTP == 1 ? o : o - tl * (MX_ROWS * 16 * CG);
-        const int r = e & 15, t = e >> 4;
-        const int trow0 = (blockIdx.x * RTP + tl) * MX_ROWS;
-        if (t >= T || trow0 + r >= ntot) continue;
+    float * otile = (float *) (smem + 16 * 2 * MX_PSTRIDE * 4);           // [column][32] result tile of a planes-out workgroup: behind wave 0's partial tile
+    auto finish = [&](const epi_t & e) {
+        if (!e.ok) return;
+        const int r = e.row & 15;                                          // (segments start at multiples of 16 rows)
         float P[8];
         #pragma unroll
-        for (int w8 = 0; w8 < 8; w8++) P[w8] = w8 < nwt ? pt[((size_t) (tl * nwt + w8) * (16*CG) + t) * MX_PSTRIDE + r] : 0.0f;
+        for (int w8 = 0; w8 < 8; w8++) P[w8] = w8 < nwt ? ((const float *) (smem + (size_t) (e.tl * nwt + w8) * L::SIZE))[e.t * MX_PSTRIDE + r] : 0.0f;
         float v = ((P[0] + P[1]) + (P[2] + P[3])) + ((P[4] + P[5]) + (P[6] + P[7]));
-        int s2 = 0;
-        if constexpr (!NSEG1) {
-            if (a.nseg > 1 && trow0 >= a.row_start[1]) s2 = 1;
-            if (a.nseg > 2 && trow0 >= a.row_start[2]) s2 = 2;
+        if (sgr.bias)      v = v + e.bias;
+        if (sgr.has_scale) v = v * sgr.scale;
+        if (sgr.gelu)      v = gelu_lut(v, a.gelu_tab);
+        if (has_res)       v = v + e.res;
+        if (!(RTP == 2 && LS == 64 && a.planes_only)) {
+            if (sgr.dst_f16) ((uint16_t *) e.dcol)[e.row] = f2h(v); else ((float *) e.dcol)[e.row] = v;
         }
-        const MXSeg & sg = NSEG1 ? a.seg[0] : a.seg[s2];
-        const int row = trow0 - (NSEG1 ? 0 : a.row_start[s2]) + r;
-        void * dcol = ka->cols.dst[NSEG1 ? 0 : s2][t];
-        const float * rcol = ka->cols.res[NSEG1 ? 0 : s2][t];
-        if (sg.bias)      v = v + sg.bias[row];
-        if (sg.has_scale) v = v * sg.scale;
-        if (sg.gelu)      v = gelu_lut(v, a.gelu_tab);
-        if (rcol)         v = v + rcol[row];
-        if (!(RTP == 2 && a.planes_only)) {
-            if (sg.dst_f16) ((uint16_t *) dcol)[row] = f2h(v); else ((float *) dcol)[row] = v;
-        }
-        if constexpr (LS == 8) { float * mcol = (float *) ka->cols.mirror[t]; if (mcol) mcol[row] = v; }
-        if constexpr (RTP == 2) otile[t*32 + tl*MX_ROWS + r] = v;
-    }
-    if constexpr (RTP == 2) {
+        if constexpr (LS == 8) { if (e.mcol) e.mcol[e.row] = v; }
+        if constexpr (RTP == 2 && LS == 64) otile[e.t*32 + e.tl*MX_ROWS + r] = v;
+    };
+    #pragma unroll
+    for (int k = 0; k < EPI; k++) finish(ep[k]);
+    for (int k = EPI; k * nthreads < NOUT; k++) finish(epi_prep(tid + k * nthreads));      // (narrow workgroups of small models only)
+    if constexpr (RTP == 2 && LS == 64) {
         // the workgroup's 32 rows are one Q8_0 block of the result for every column: quantize -> planes of K' = ntot (k_gemv_q POUT)
         __syncthreads();
         if (a.planes_out && tid < 16*CG*8 && (tid >> 3) < T) {
@@ -250,31 +329,37 @@ __global__ void __launch_bounds__(RTP * (LS == 8 ? 4 : 8) * 64 > 512 ? 1024 : 51
     }
 }
 
-template <int WT, int LS, int LW, int NU, int CG, int RTP, bool NSEG1>
+template <int WT, int LS, int NU, int CG, int RTP, bool NSEG1>
 static int mx_emit(mi355x_ctx * ctx, const MXArgs & k, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
-    return emit(ctx, LS == 8 ? "vocab_mx" : "gemv_mx", k_gemv_mx<WT, LS, LW, NU, CG, RTP, NSEG1>, grid, block, lds, k, bytes, flops);
+    static std::atomic<bool> attr_set[64];
+    const int dev = ctx->device & 63;
+    if (lds > 64 * 1024 && !attr_set[dev].load()) {
+        if (hipFuncSetAttribute((const void *) k_gemv_mx<WT, LS, NU, CG, RTP, NSEG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
+        attr_set[dev].store(true);
+    }
+    return emit(ctx, LS == 8 ? "vocab_mx" : "gemv_mx", k_gemv_mx<WT, LS, NU, CG, RTP, NSEG1>, grid, block, lds, k, bytes, flops);
 }
 
 template <int WT, int CG>
 static int mx_launch(mi355x_ctx * ctx, const MXArgs & k, bool vocab, int nu, bool pout, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     if (vocab) {
         switch (nu) {
-            case 2: return mx_emit<WT, 8, 2, 2, CG, 2, true>(ctx, k, grid, block, lds, bytes, flops);
-            case 3: return mx_emit<WT, 8, 2, 3, CG, 2, true>(ctx, k, grid, block, lds, bytes, flops);
-            case 4: return mx_emit<WT, 8, 2, 4, CG, 2, true>(ctx, k, grid, block, lds, bytes, flops);
-            case 5: return mx_emit<WT, 8, 2, 5, CG, 2, true>(ctx, k, grid, block, lds, bytes, flops);
+            case 2: return mx_emit<WT, 8, 2, CG, MX_VOCAB_TILES, true>(ctx, k, grid, block, lds, bytes, flops);
+            case 3: return mx_emit<WT, 8, 3, CG, MX_VOCAB_TILES, true>(ctx, k, grid, block, lds, bytes, flops);
+            case 4: return mx_emit<WT, 8, 4, CG, MX_VOCAB_TILES, true>(ctx, k, grid, block, lds, bytes, flops);
+            case 5: return mx_emit<WT, 8, 5, CG, MX_VOCAB_TILES, true>(ctx, k, grid, block, lds, bytes, flops);
         }
         return MI355X_E_UNSUPPORTED;
     }
     const bool nseg1 = k.nseg == 1;
     if (pout) {
         if (nu != 1 || !nseg1) return MI355X_E_UNSUPPORTED;
-        return mx_emit<WT, 64, 8, 1, CG, 2, true>(ctx, k, grid, block, lds, bytes, flops);
+        return mx_emit<WT, 64, 1, CG, 2, true>(ctx, k, grid, block, lds, bytes, flops);
     }
     switch (nu) {
-        case 1: return nseg1 ? mx_emit<WT, 64, 8, 1, CG, 1, true>(ctx, k, grid, block, lds, bytes, flops) : mx_emit<WT, 64, 8, 1, CG, 1, false>(ctx, k, grid, block, lds, bytes, flops);
-        case 2: return nseg1 ? mx_emit<WT, 64, 8, 2, CG, 1, true>(ctx, k, grid, block, lds, bytes, flops) : MI355X_E_UNSUPPORTED;
-        case 3: return nseg1 ? mx_emit<WT, 64, 8, 3, CG, 1, true>(ctx, k, grid, block, lds, bytes, flops) : MI355X_E_UNSUPPORTED;
+        case 1: return nseg1 ? mx_emit<WT, 64, 1, CG, 1, true>(ctx, k, grid, block, lds, bytes, flops) : mx_emit<WT, 64, 1, CG, 1, false>(ctx, k, grid, block, lds, bytes, flops);
+        case 2: return nseg1 ? mx_emit<WT, 64, 2, CG, 1, true>(ctx, k, grid, block, lds, bytes, flops) : MI355X_E_UNSUPPORTED;
+        case 3: return nseg1 ? mx_emit<WT, 64, 3, CG, 1, true>(ctx, k, grid, block, lds, bytes, flops) : MI355X_E_UNSUPPORTED;
     }
     return MI355X_E_UNSUPPORTED;
 }
@@ -331,7 +416,7 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         if (g.ep.bias || g.ep.has_scale || g.ep.gelu || g.ep.residual || g.dst_type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
         mirror = d->cols && d->cols->mirror[0];
         for (int t = 0; t < T; t++) { k.cols.mirror[t] = mirror ? d->cols->mirror[t] : nullptr; if (mirror && !k.cols.mirror[t]) return MI355X_E_UNSUPPORTED; }
-        nu = K / 256; nwt = 4; rtp = 2;
+        nu = K / 256; nwt = 1; rtp = MX_VOCAB_TILES;
     } else {
         nu = (nb + 63) / 64;
         if (nu > 3) return MI355X_E_UNSUPPORTED;
@@ -346,7 +431,10 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const int ntiles = (ntot + MX_ROWS - 1) / MX_ROWS;              // (a single segment may end inside its last tile: the vocabulary's 51864 / 51865 / 51866 rows)
     const dim3 grid((ntiles + rtp - 1) / rtp), block(64 * nwt * rtp);
     if (pout && (int) block.x < 16 * cg * 8) return MI355X_E_UNSUPPORTED;   // the planes-out pass needs 8 threads per column
-    const uint32_t lds = (uint32_t) ((size_t) rtp * nwt * (16*cg) * MX_PSTRIDE * 4 + (rtp == 2 ? 32 * 16 * cg * 4 : 0));
+    const size_t per_wave = wt == MI355X_TYPE_Q8_0 ? (cg == 2 ? mx_lds<MI355X_TYPE_Q8_0, 2>::SIZE : mx_lds<MI355X_TYPE_Q8_0, 1>::SIZE)
+                                                     : (cg == 2 ? mx_lds<MI355X_TYPE_Q5_0, 2>::SIZE : mx_lds<MI355X_TYPE_Q5_0, 1>::SIZE);
+    const uint32_t lds = (uint32_t) ((size_t) rtp * nwt * per_wave);
+    if (lds > 160 * 1024 - 256) return MI355X_E_UNSUPPORTED;
     const double bytes = wbytes + (double) dg_planes_bytes(wt, K, T) + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;
     int rc;
