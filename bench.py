@@ -9,7 +9,15 @@ the MI355X ggml backend plugin loaded through ggml's own plugin loader.  GGML_MI
 into an abort, so a number printed here was computed by the HIP kernels.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--arch large-v3] [--qtype q5_0]
-  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+  N > 1, one process:   python bench.py --gpus N          N whisper_contexts (device r for context r) in THIS process through the native
+                                                           harness (include/mi355x_host.h): replicas r > 0 skip the model file's payloads and
+                                                           get their weights by the plugin's peer copy from device 0, checksums compared
+  N > 1, one process per GPU (the driver's form):
+          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+                                                           rendezvous / barriers / MAX over ranks on gloo (CPU); the weights travel by the
+                                                           plugin's own RCCL broadcast (system librccl).  ONE HIP runtime in every mode: torch
+                                                           never touches a GPU here.
+  Fewer visible MI355X than --gpus (or than the ranks): the run FAILS with a message, it never shrinks silently.
 
 One JSON line on stdout (rank 0).  `value` = wall ms per chunk aggregated over all streams (T_max / (K*N)); per-stream
 latency is `ms_per_step`.  Weights are synthetic (seeded random, real architecture, reference quantizer); mel is seeded
@@ -91,15 +99,15 @@ def broadcast_weights(p, dist, torch, device: int, rank: int, world: int):
     from whisper_cpp_amd.dist_timing import all_ranks_ok, share_bytes
     uid = (C.c_ubyte * 128)()
     got_id = rank != 0 or p.ggml_backend_mi355x_rccl_unique_id(uid) == 0
-    if not all_ranks_ok(dist, torch, got_id, "cuda"):
+    if not all_ranks_ok(dist, torch, got_id, "cpu"):
         raise RuntimeError("ggml_backend_mi355x_rccl_unique_id failed on rank 0 (librccl.so not loadable?)")
-    uid = (C.c_ubyte * 128)(*share_bytes(dist, torch, bytes(uid) if rank == 0 else None, 128, "cuda"))   # over the harness's own process group
+    uid = (C.c_ubyte * 128)(*share_bytes(dist, torch, bytes(uid) if rank == 0 else None, 128, "cpu"))   # over the harness's own process group
     stats = (C.c_double * 4)()
     p.ggml_backend_mi355x_broadcast_weights_rccl.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
     t0 = time.perf_counter()
     rc = p.ggml_backend_mi355x_broadcast_weights_rccl(device, rank, world, uid, stats)
     wall = time.perf_counter() - t0
-    if not all_ranks_ok(dist, torch, rc == 0 and stats[3] == 1.0, "cuda"):
+    if not all_ranks_ok(dist, torch, rc == 0 and stats[3] == 1.0, "cpu"):
         raise RuntimeError(f"weight broadcast failed or could not be verified on some rank (this rank: rc={rc}, verified={stats[3]})")
     return {"bytes": int(stats[0]), "buffers": int(stats[2]), "seconds": round(stats[1], 4), "GBps": round(stats[0] / max(stats[1], 1e-9) / 1e9, 2),
             "verified": True, "transport": "RCCL ncclBroadcast issued by the plugin (ggml_backend_mi355x_broadcast_weights_rccl), checksums compared across ranks",
@@ -118,6 +126,98 @@ def algorithmic_figures(arch: str, qtype: str):
     enc_flop = 2.0 * n_actx * n_al * 12 * n_as * n_as + 4.0 * n_actx * n_ctx_pad * n_as * n_al \
         + 2.0 * (2 * n_actx) * n_as * 3 * n_mels + 2.0 * n_actx * n_as * 3 * n_as + 2.0 * n_actx * n_tl * 2 * n_ts * n_ts
     return {"decode_bytes_per_token": dec_w * bpw + kv_cross, "encode_flop": enc_flop, "decode_weight_bytes": dec_w * bpw, "decode_kv_bytes_per_stream": kv_cross}
+
+
+DTYPE = "int8 dot (decode mat-vecs) / int8 MFMA (quantized products with > 8 columns) / f16 MFMA (attention, conv), f32 accumulate"
+
+
+def contract_line(a, n_gpus: int, streams_per_gpu: int, ms_per_step: float, agg_ms: float, chunks_per_s: float, data="synthetic"):
+    """the fields the driver's contract names, in one place (every mode prints the same line shape)"""
+    return {"metric": "whisper-bench encoder+decoder ms per 30s chunk", "value": round(agg_ms, 4), "unit": "ms/chunk",
+            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": False,
+            "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": data,
+            "config": {"workload": f"{a.arch} {a.qtype.upper()}: 1 x whisper_encode + {a.n_decode} x whisper_decode(1 token), {streams_per_gpu} stream{'s' if streams_per_gpu > 1 else ''} per GPU",
+                       "streams": n_gpus * streams_per_gpu, "flash_attn": True, "weights": "seeded random, reference quantizer", "mel": "seeded uniform(-1,1)"},
+            "chunks_per_s": round(chunks_per_s, 4)}
+
+
+def run_in_process(a, cpu_selftest: bool, hip_runtime: str):
+    """--gpus N without torchrun: N whisper_contexts (device r for context r) x --streams states each in THIS process, one host thread per state,
+    all started together; wall = the slowest thread (the MAX over GPUs the contract asks for).  Contexts r > 0 open the model file through the
+    payload-skipping loader and receive every weight byte by the plugin's device-to-device copy from device 0; every destination buffer's
+    checksum must equal device 0's or the run fails (include/mi355x_host.h).  Reference: one context per device
+    (include/whisper.h:119, src/whisper.cpp:1297-1311), one state per thread (src/whisper.cpp:7813-7941)."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    from synth_model import make_model
+    from whisper_cpp_amd import host_api
+    model = make_model(a.arch, a.qtype)
+    r = host_api.run(model, use_gpu=not cpu_selftest, n_devices=a.gpus, streams=a.streams, n_decode=a.n_decode, steps=a.steps, warmup=a.warmup,
+                     skip_payloads=not cpu_selftest)
+    if r["rc"] != 0:
+        raise SystemExit(f"bench.py: mi355x_host_run failed: rc={r['rc']} {r['error']}")
+    if r["n_devices"] != a.gpus:
+        raise SystemExit(f"bench.py: the harness ran on {r['n_devices']} devices, {a.gpus} were asked for")
+    if not cpu_selftest and r["bcast_verified"] != 1:
+        raise SystemExit("bench.py: the weight distribution to the replicas could not be verified: refusing to benchmark replicas with unknown weights")
+    n_streams = a.gpus * a.streams
+    ms_per_step = r["ms_per_chunk_per_stream"]
+    out = contract_line(a, a.gpus, a.streams, ms_per_step, ms_per_step / n_streams, r["chunks_per_s"])
+    figs = algorithmic_figures(a.arch, a.qtype)
+    bound_ms = figs["encode_flop"] / (MFMA_F16_PEAK_TFLOPS * 1e12) * 1e3 + a.n_decode * figs["decode_bytes_per_token"] / (HBM_PEAK_GBS * 1e9) * 1e3
+    out.update({
+        "launch": f"one process, {a.gpus} contexts x {a.streams} states, one host thread per state (mi355x_host_run)", "hip_runtime": hip_runtime,
+        "weight_broadcast": None if cpu_selftest else {
+            "bytes": int(r["bcast_bytes"]), "buffers": int(r["bcast_buffers"]), "seconds": round(r["bcast_seconds"], 4),
+            "GBps": round(r["bcast_bytes"] / max(r["bcast_seconds"], 1e-9) / 1e9, 2), "verified": int(r["bcast_verified"]),
+            "transport": "peer copy device 0 -> device r issued by the plugin (ggml_backend_mi355x_broadcast_weights_peer), device-side checksums compared",
+            "model_file_bytes_read_by_all_contexts": int(r["payload_bytes_read"]), "model_file_bytes": int(r["file_bytes"])},
+        # per-GPU figure against the same peaks as the N = 1 line (no kernel profile in this mode: the per-kernel roofline is the N = 1 line's)
+        "roofline": {"kernel": "whole chunk (per GPU)", "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                     "chunk_frac": round(bound_ms / ms_per_step, 4) if ms_per_step > 0 else None},
+        "backend": "reference CPU backend: harness self-test, not a measurement" if cpu_selftest else "MI355X plugin, GGML_MI355X_STRICT=1",
+    })
+    print(json.dumps(out))
+
+
+def run_ranks_selftest(a, dist, torch, rank: int, world: int):
+    """BENCH_BACKEND=cpu under torchrun (tests/test_host.py): the rank protocol of the GPU path — gloo rendezvous, barriers, MAX over ranks, one JSON
+    line from rank 0 with n_gpus = WORLD_SIZE — on the reference CPU backend.  Not a measurement."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    from synth_model import make_model
+    from whisper_cpp_amd import host_api
+    from whisper_cpp_amd.dist_timing import aggregate, timed_region
+    if rank == 0:
+        make_model(a.arch, a.qtype)
+    dist.barrier()
+    model = make_model(a.arch, a.qtype)
+    rd = C.c_int64(0)
+    L = host_api.lib()
+    ctx = L.mi355x_host_open(str(model).encode(), 0, 0, 1, 0, C.byref(rd))
+    if not ctx:
+        raise SystemExit("mi355x_host_open failed")
+    L.mi355x_host_chunk.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    import numpy as np
+    w = C.CDLL(str(ROOT / "whisper.cpp_amd" / "host" / "_whisper" / "libwhisper.so"))
+    w.whisper_model_n_mels.argtypes = [C.c_void_p]
+    w.whisper_set_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    n_mels = w.whisper_model_n_mels(ctx)
+    mel = (np.random.default_rng(42 + rank).random((n_mels, 3000), dtype=np.float32) * 2 - 1)
+    w.whisper_set_mel(ctx, mel.ctypes.data_as(C.c_void_p), 3000, n_mels)
+
+    def chunk():
+        if L.mi355x_host_chunk(ctx, a.n_decode, 2) != 0:
+            raise RuntimeError("mi355x_host_chunk failed")
+    for _ in range(a.warmup):
+        chunk()
+    el = timed_region(chunk, a.steps, dist, None, "cpu")
+    if rank == 0:
+        ms, agg, cps = aggregate(el, a.steps, world)
+        out = contract_line(a, world, 1, ms, agg, cps)
+        out["backend"] = "reference CPU backend: harness self-test, not a measurement"
+        out["launch"] = f"{world} processes (torchrun), gloo rendezvous"
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def main():
@@ -154,9 +254,9 @@ def main():
     # image's /opt/rocm libamdhip64.so.7 (ROCm 7.2); loaded side by side both runtimes initialise the device and every decode step of the
     # plugin gets slower (measured on the same box: 362 vs 348 ms/chunk; the stock whisper-bench process, which has only the system runtime,
     # 339).  Bringing the system runtime into the global symbol scope BEFORE torch is imported makes torch's HIP calls resolve to it as well
-    # (what LD_PRELOAD does).  Single-process runs only: under torchrun the wheel's RCCL stays with the runtime it was built against.
+    # (what LD_PRELOAD does).
     # BENCH_SYSTEM_HIP=0 switches this off, =1 forces it.
-    sys_hip = os.environ.get("BENCH_SYSTEM_HIP", "1" if not under_torchrun else "0")
+    sys_hip = os.environ.get("BENCH_SYSTEM_HIP", "1")      # (under torchrun too since r05: the process group is gloo, torch's RCCL is never used)
     hip_runtime = "pytorch wheel's libamdhip64 next to the system one"
     if sys_hip == "1":
         for cand in ("/opt/rocm/lib/libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
@@ -169,22 +269,47 @@ def main():
                 break
 
     import numpy as np
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False")
-    torch.cuda.set_device(local_rank)
+    import __graft_entry__ as graft
+    graft.load_package()
+    cpu_selftest = os.environ.get("BENCH_BACKEND", "gpu") == "cpu"          # harness self-test on the reference CPU backend (tests/test_host.py): NOT a measurement
+    n_visible = 0
+    if not cpu_selftest:
+        from whisper_cpp_amd import kernels_api as _ka
+        n_visible = int(_ka.lib().mi355x_device_count())
+        if n_visible < 1:
+            raise SystemExit("bench.py needs an MI355X: no gfx950 device is visible (there is no CPU fallback)")
+    if under_torchrun and a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE is {world}: launch one rank per GPU")
+    if not cpu_selftest and (local_rank >= n_visible or (not under_torchrun and a.gpus > n_visible)):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} (local rank {local_rank}) but only {n_visible} MI355X visible: refusing to run on fewer GPUs than asked for")
+    if a.gpus > 1 and not under_torchrun:
+        return run_in_process(a, cpu_selftest, hip_runtime)
+
+    import torch          # CPU tensors of the gloo process group only: no torch.cuda call in this file
     dist = None
     if under_torchrun:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
+        if cpu_selftest:
+            return run_ranks_selftest(a, dist, torch, rank, world)
+    elif cpu_selftest:
+        raise SystemExit("bench.py: BENCH_BACKEND=cpu is the multi-GPU harness self-test: use --gpus N > 1 or torchrun")
+
+    hip = None
+    if not cpu_selftest:
+        hip = C.CDLL("/opt/rocm/lib/libamdhip64.so.7" if os.path.exists("/opt/rocm/lib/libamdhip64.so.7") else "/opt/rocm/lib/libamdhip64.so")
+
+    def device_sync():
+        if hip is not None:
+            hip.hipSetDevice(local_rank)
+            if hip.hipDeviceSynchronize() != 0:
+                raise RuntimeError("hipDeviceSynchronize failed")
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    import __graft_entry__ as graft
-    graft.load_package()
     sys.path.insert(0, str(ROOT / "scripts"))
     from synth_model import make_model          # tooling: writes the synthetic model file with the reference application's own quantizer
 
@@ -282,9 +407,9 @@ def main():
     host0 = (C.c_double * 13)()
     p.ggml_backend_mi355x_host_times(host0)
     # barrier + synchronize on both sides, exactly K steps, MAX over ranks.  Every whisper_encode / whisper_decode
-    # returns only after the backend's stream is drained (ggml_backend_sched_synchronize), torch.cuda.synchronize()
-    # additionally drains the device.
-    elapsed_s = timed_region(chunk, a.steps, dist, torch.cuda.synchronize, "cuda")
+    # returns only after the backend's stream is drained (ggml_backend_sched_synchronize); hipDeviceSynchronize (system runtime, the
+    # plugin's own) additionally drains the device.
+    elapsed_s = timed_region(chunk, a.steps, dist, device_sync, "cpu")
     tm = w.whisper_get_timings(ctx).contents
     encode_ms, decode_ms = float(tm.encode_ms), float(tm.decode_ms)
     host1 = (C.c_double * 13)()
@@ -320,7 +445,8 @@ def main():
                 legs.append((f"own_chains_{a.multi_stream}_streams", 0, a.multi_stream))
             legs.append((f"batched_{a.multi_stream}_streams", 1, a.multi_stream))
             if a.multi_stream == 8:
-                legs.append(("batched_16_streams", 1, 16))        # chains of 10 + 6 columns (images of 8) per step (16 streams >= 16 chunks/s)
+                legs.append(("batched_16_streams", 1, 16))        # chains of 10 + 6 columns per step: from 9 columns on the mat-vecs run on the matrix cores (decode_mx.hip)
+                legs.append(("batched_32_streams", 1, 32))        # chains of 20 + 12 columns
             for label, batching, ns in legs:
                 r = host_api.run(model, use_gpu=True, n_devices=1, streams=ns, n_decode=a.n_decode, steps=2, warmup=1, batching=batching)
                 if r["rc"] != 0:
@@ -348,13 +474,8 @@ def main():
     if rank == 0:
         figs = algorithmic_figures(a.arch, a.qtype)
         ms_per_step, agg_ms, chunks_per_s = aggregate(elapsed_s, a.steps, world * a.streams)
-        out = {
-            "metric": "whisper-bench encoder+decoder ms per 30s chunk", "value": round(agg_ms, 4), "unit": "ms/chunk",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": False,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int8 dot (decode mat-vecs) / int8 MFMA (quantized products with > 8 columns) / f16 MFMA (attention, conv), f32 accumulate", "data": "synthetic",
-            "config": {"workload": f"{a.arch} {a.qtype.upper()}: 1 x whisper_encode + {a.n_decode} x whisper_decode(1 token), {a.streams} stream{'s' if a.streams > 1 else ''} per GPU",
-                       "streams": world * a.streams, "flash_attn": True, "weights": "seeded random, reference quantizer", "mel": "seeded uniform(-1,1)"},
-            "chunks_per_s": round(chunks_per_s, 4),
+        out = contract_line(a, world, a.streams, ms_per_step, agg_ms, chunks_per_s)
+        out.update({
             "encode_ms": round(encode_ms, 3), "decode_ms_per_token": round(decode_ms, 4),
             "batchd_ms_per_token": round(batchd_ms, 4), "prompt_ms_per_token": round(prompt_ms, 4),
             "weight_broadcast": bcast, "multi_stream": multi_stream,
@@ -363,7 +484,8 @@ def main():
                         "host_ms_in_timed_region": {"graph_compute": round(host_ms[3], 2),
                                             "set_tensor": round(host_ms[4], 2), "get_tensor": round(host_ms[5], 2), "cpy_tensor": round(host_ms[6], 2), "synchronize": round(host_ms[7], 2),
                                             "calls": [int(host_ms[8 + i]) for i in range(4)], "gpu_span": round(host_ms[12], 2)}},
-        }
+            "launch": f"{world} process{'es (torchrun), gloo rendezvous, one rank per GPU' if under_torchrun else ''}",
+        })
         if prof:
             # the dominant kernel = the kernel TEMPLATE with the most GPU time (its instantiations are one kernel built for different
             # shapes: the decode mat-vec's five share of ~70 % is what bounds the chunk), no tie-break; achieved = the family's summed

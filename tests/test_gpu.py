@@ -1149,3 +1149,16 @@ def test_language_detection_through_the_plugin(plugin_env, arch, qtype):
     assert d["n_lang"] == 100 and abs(d["sum_gpu"] - 1.0) < 1e-4
     assert d["max_abs_prob_diff"] < 2e-2, d
     assert d["id_cpu"] == d["id_gpu"] or (d["p_top_cpu"] - d["p_second_cpu"]) < 2 * d["max_abs_prob_diff"], d
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` with N above the visible MI355X count fails loudly instead of benchmarking fewer GPUs than asked for
+    (VERDICT r04 next #2); tests/test_host.py covers the N-context and torchrun forms on the CPU backend"""
+    import __graft_entry__ as graft
+    graft.load_package()
+    from whisper_cpp_amd import kernels_api
+    n = int(kernels_api.lib().mi355x_device_count())
+    assert n >= 1
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n + 1), "--arch", "micro"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and f"only {n} MI355X visible" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert "{" not in r.stdout

@@ -409,6 +409,49 @@ def test_native_harness_refuses_gpu_mode_without_the_plugin(tmp_path):
     assert h.lib().mi355x_host_run(C.byref(cfg), C.byref(res)) != 0 and b"plugin" in res.error
 
 
+def _bench(args, env_extra=None, torchrun=0, port=29533):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(env_extra or {}))
+    cmd = [sys.executable]
+    if torchrun:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(torchrun), "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    cmd += [str(ROOT / "bench.py")] + args
+    return subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+
+
+def _bench_line(r):
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-1500:])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_runs_that_many_contexts_in_one_process():
+    """`python bench.py --gpus 2` (no torchrun) = 2 whisper_contexts in one process through the native harness and prints n_gpus: 2 (VERDICT r04
+    missing #2: the flag was parsed and never used).  Run on the reference CPU backend (BENCH_BACKEND=cpu: the harness self-test)."""
+    _host_api()
+    d = _bench(["--gpus", "2", "--arch", "micro", "--steps", "1", "--warmup", "0", "--n-decode", "4"], {"BENCH_BACKEND": "cpu"})
+    d = _bench_line(d)
+    assert d["n_gpus"] == 2 and d["config"]["streams"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
+    assert d["value"] > 0 and abs(d["ms_per_step"] - 2 * d["value"]) < 1e-3 * d["ms_per_step"]      # value = whole-job aggregate over both replicas
+    assert "self-test" in d["backend"] and d["weight_broadcast"] is None
+
+
+def test_bench_under_torchrun_prints_world_size_as_n_gpus():
+    """the driver's N > 1 form — torchrun, one rank per GPU — on gloo with world size 2 and the reference CPU backend: the rank protocol
+    (rendezvous, barriers, MAX over ranks, ONE line from rank 0) yields n_gpus = WORLD_SIZE; a --gpus that contradicts WORLD_SIZE is refused"""
+    _host_api()
+    d = _bench_line(_bench(["--gpus", "2", "--arch", "micro", "--steps", "1", "--warmup", "0", "--n-decode", "4"], {"BENCH_BACKEND": "cpu"}, torchrun=2))
+    assert d["n_gpus"] == 2 and d["config"]["streams"] == 2 and "torchrun" in d["launch"]
+    r = _bench(["--gpus", "4", "--arch", "micro", "--steps", "1", "--warmup", "0", "--n-decode", "4"], {"BENCH_BACKEND": "cpu"}, torchrun=2, port=29535)
+    assert r.returncode != 0 and "WORLD_SIZE is 2" in (r.stderr + r.stdout)
+
+
+def test_bench_never_shrinks_to_fewer_gpus_silently():
+    """no MI355X here: bench.py must say so and exit non-zero (there is no CPU fallback); on a one-GPU box `--gpus 2` fails the same way
+    (tests/test_gpu.py::test_bench_refuses_more_gpus_than_the_box_has)"""
+    r = _bench(["--gpus", "2", "--arch", "micro"])
+    assert r.returncode != 0 and "MI355X" in r.stderr and "{" not in r.stdout
+
+
 def _latest(pattern):
     files = sorted((ROOT / "profiles").glob(pattern))
     assert files, f"profiles/{pattern} is missing"
