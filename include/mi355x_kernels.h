@@ -239,10 +239,6 @@ typedef struct mi355x_gemv_cols {
      * Honoured with or without x_planes; dst / res above only with x_planes.  mi355x_last_launch_mirrored tells whether the launch that
      * mi355x_gemv_fused just issued wrote them (a kernel family without the option ignores them). */
     void *        mirror[MI355X_MAX_COLS];
-    /* optional activation source of the x_planes path WITHOUT planes: has_norm = 1, x == x_planes == NULL and x[t] = column t's F32
-     * vector (K <= 2048) — LayerNorm, affine and the rounding to the vec_dot_type run in the mat-vec's own prologue (the arithmetic of
-     * mi355x_act_prepare, one dependent launch less).  MI355X_E_UNSUPPORTED: prepare planes and come back with x_planes. */
-    const float * x[MI355X_MAX_COLS];
 } mi355x_gemv_cols;
 MI355X_API int mi355x_last_launch_mirrored(mi355x_ctx * ctx);
 

@@ -210,8 +210,10 @@ def test_no_kernel_spills_to_scratch():
     assert not spilled, spilled[:10]
     by = {k["demangled"]: k for k in ks}
     for name in ("k_gemv_row<6, 1, 1, 0, true, 1>", "k_gemv_row<6, 1, 1, 1, true, 1>", "k_gemv_row<6, 1, 1, 1, false, 1>", "k_gemv_row<6, 1, 1, 2, true, 1>",
-                 "k_gemv_q<6, 8, 1, true, 1, false, false, false>", "k_gemv_q<6, 8, 3, true, 1, false, false, false>", "k_gemv_q<6, 8, 1, true, 1, false, true, false>",
-                 "k_gemv_q<6, 8, 1, false, 1, false, true, false>", "k_gemv_q<6, 8, 1, true, 4, true, true, false>"):
+                 "k_gemv_q<6, 8, 1, true, 1, false, false>", "k_gemv_q<6, 8, 3, true, 1, false, false>", "k_gemv_q<6, 8, 1, false, 1, false, false>",
+                 "k_gemv_q<6, 8, 1, true, 4, true, false>",
+                 # the matrix-core mat-vecs of wide cross-state batches (decode_mx.hip): two 5-wave workgroups per CU for the 1280-feature products
+                 "k_gemv_mx<6, 64, 1, 1, 1, true>", "k_gemv_mx<6, 64, 1, 1, 1, false>", "k_gemv_mx<6, 64, 1, 2, 1, true>", "k_gemv_mx<6, 64, 1, 2, 2, true>"):
         assert by[name]["vgpr_count"] <= 128, (name, by[name])
     assert by["k_gemm_f16_ring<64, 4, 128>"]["agpr_count"] == 32 and by["k_gemm_f16_ring<128, 2, 128>"]["agpr_count"] == 64      # accumulators live in AGPRs
 
@@ -250,8 +252,7 @@ def test_ring_gemm_loop_never_drains_the_dma_queue(tmp_path):
 @pytest.mark.parametrize("mangled,min_loads", [("_Z10k_gemv_rowILi6ELi1ELi1ELi1ELb1ELi1EEv6DGArgs", 8),      # LN + mat-vec
                                                ("_Z10k_gemv_rowILi6ELi1ELi1ELi2ELb1ELi1EEv6DGArgs", 27),     # attention combine + mat-vec
                                                ("_Z10k_gemv_rowILi6ELi1ELi1ELi1ELb0ELi1EEv6DGArgs", 8),      # LN + Q/K/V
-                                               ("_Z8k_gemv_qILi6ELi8ELi1ELb1ELi1ELb0ELb0ELb0EEv6QGArgs", 10),        # mat-vec over pre-quantized planes (T <= 8)
-                                               ("_Z8k_gemv_qILi6ELi8ELi1ELb0ELi1ELb0ELb1ELb0EEv6QGArgs", 12)])       # LN of 8 columns + Q/K/V in the plane kernel
+                                               ("_Z8k_gemv_qILi6ELi8ELi1ELb1ELi1ELb0ELb0EEv6QGArgs", 10)])        # mat-vec over pre-quantized planes (T <= 8)
 def test_decode_matvec_issues_all_loads_in_one_burst(mangled, min_loads):
     """ISA of the built decode kernels: every global load of the kernel body is issued before the FIRST vmcnt wait, and that
     wait is a counted one that leaves the weight stream in flight.  This is the property that took the projection inside

@@ -483,6 +483,7 @@ struct mi_backend_ctx {
     void *       act = nullptr; size_t act_size = 0;
     void *       act_alt = nullptr; size_t act_alt_size = 0;     // second scratch: a GEMM reading `act` writes the next GEMM's prepared activations here
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
+    const void * elided_src = nullptr;     // F32 result a producer did NOT store because its only reader takes the prepared activations (this graph): reading it is an error
     mi_io_marks io;                                             // uploads this stream already waits behind
     mi_qstate   qs;                                             // planes a producer's epilogue left for the next mat-vec (T >= 3 pipeline)
     // cross-state batches (mi_batch_group)
@@ -749,13 +750,21 @@ static bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, 
     if (!((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && w->nb[0] == 2 && w->nb[1] % 16 == 0))) return false;
     const int mode = mode_for(w->type);
     if ((mode == 1 && K % 32) || (mode == 2 && K % 256)) return false;
-    const int rmode = rows_mode_for(w, K);
+    int rmode = rows_mode_for(w, K);
+    if (rmode && ((uintptr_t) w->data % 16)) rmode = 0;                   // (mi355x_gemm_q8act's own precondition: never promise rows it would refuse)
     mode_out = rmode ? rmode : mode;
     return true;
 }
 
 static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgraph * g = nullptr) {
     const ggml_tensor * mm = c.mm, * w = mm->src[0], * x = mm->src[1];
+    // a producer elided this F32 activation because mm_takes_prepared() promised that its prepared rows would be consumed.  If the
+    // consuming kernel then refuses them (alignment, a shape only its launch code knows), no path that re-reads x->data may run: fail loudly.
+    auto reads_elided = [&]() {
+        if (x->data != b->elided_src || !b->elided_src) return false;
+        GGML_LOG_ERROR("ggml-mi355x: %s: the prepared activations of %s were refused and its F32 form was never stored\n", mm->name, x->name);
+        return true;
+    };
     mi355x_tensor mw = to_mt(w), mx = to_mt(x);
     // destination: the chain's last tensor, seen as [N, T] with the dtype of that tensor
     mi355x_tensor md = to_mt(mm);
@@ -814,6 +823,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                         if (rc == 0) {
                             std::swap(b->act, b->act_alt); std::swap(b->act_size, b->act_alt_size);
                             b->act_src = c.last->data; b->act_K = M; b->act_T = T; b->act_mode = 3; b->act_nb1 = M*4;
+                            if (only) b->elided_src = c.last->data;
                             return 0;
                         }
                         if (rc != MI355X_E_UNSUPPORTED) return rc;
@@ -823,6 +833,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                 if (rc != MI355X_E_UNSUPPORTED) return rc;
             }
         }
+        if (reads_elided()) return (int) hipErrorInvalidValue;            // everything below reads x->data
         if (!((mode == 1 && K % 32) || (mode == 2 && K % 256))) {
             const void * act; int64_t ld;
             if (x->type == GGML_TYPE_F16 && mode == 0) { act = x->data; ld = (int64_t) x->nb[1] / 2; }
@@ -857,6 +868,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                     if (rc == 0) {       // the next GEMM finds its activations prepared: the scratch buffers trade places
                         std::swap(b->act, b->act_alt); std::swap(b->act_size, b->act_alt_size);
                         b->act_src = c.last->data; b->act_K = M; b->act_T = T; b->act_mode = 1; b->act_nb1 = M*4;
+                        if (prep_only) b->elided_src = c.last->data;
                         return 0;
                     }
                     if (rc != MI355X_E_UNSUPPORTED) return rc;
@@ -1303,10 +1315,10 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
     }
     end_out = ch[n - 1].end; rc_out = 0;
     if (!k) return true;
-    // k_act_prepare -> planes -> mat-vec (two launches), or with GGML_MI355X_LN_FUSED=1 the LayerNorm in the mat-vec's own prologue (one
-    // launch).  The one launch is SLOWER (the normalisation of T columns repeated in 256-768 workgroups is VALU time: LN + Q/K/V 15.7 us
-    // against 4.5 + 7.2; profiles/r03_plane_ln_and_one_launch_cross_attention_ab.txt), so it is off by default.
-    static const bool ln_fused = getenv("GGML_MI355X_LN_FUSED") && atoi(getenv("GGML_MI355X_LN_FUSED")) != 0;
+    // k_act_prepare -> planes -> mat-vec: two launches.  The LayerNorm in the mat-vec's own prologue (one launch) lost every time it was built: a
+    // workgroup then normalises and quantizes ALL T columns (k_act_prepare spreads them over T workgroups) — k_gemv_q form r03: LN + Q/K/V 15.7 us
+    // against 4.5 + 7.2; matrix-core form r05: 16 / 32 streams 10.6 / 7.8 chunks/s against 14.6 / 20.7, beam step 0.552 against 0.487 ms per token
+    // (profiles/r05_ln_fused_ab.txt).  Both forms are deleted.
     mi355x_act_desc a; memset(&a, 0, sizeof(a));
     a.K = (int) K; a.T = cs.T; a.wtype = (int32_t) w0->type; a.has_norm = 1; memcpy(&a.eps, ln.norm->op_params, sizeof(float)); a.ln_w = ln.w; a.ln_b = ln.b;
     for (int c = 0; c < cs.T; c++) a.xcol[c] = (const float *) cs_col(cs, c, i, 0);
@@ -1321,15 +1333,12 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
     auto use_planes = [&]() -> int {
         const int r = mi355x_act_prepare(k, &a, p0);
         if (r) return r;
-        d.has_norm = 0; d.ln_w = d.ln_b = nullptr; d.x_planes = p0; memset(cols.x, 0, sizeof(cols.x));
+        d.x_planes = p0;
         return 0;
     };
-    if (ln_fused) { d.has_norm = 1; d.eps = a.eps; d.ln_w = ln.w; d.ln_b = ln.b; for (int c = 0; c < cs.T; c++) cols.x[c] = a.xcol[c]; }
-    else {
-        rc = use_planes();
-        if (rc == MI355X_E_UNSUPPORTED) return false;
-        if (rc) { rc_out = rc; return true; }
-    }
+    rc = use_planes();
+    if (rc == MI355X_E_UNSUPPORTED) return false;
+    if (rc) { rc_out = rc; return true; }
     bool mirror = n == 1 && cs.owner[0] && mirror_wanted(g, ch[0], cs.S > 1 ? 1 : cs.T);
     if (mirror) {
         const size_t rowb = (size_t) ch[0].last->ne[0] * 4;
@@ -1341,12 +1350,6 @@ static bool q_ln_gemv(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, int 
         if (!mirror) memset(cols.mirror, 0, sizeof(cols.mirror));
     }
     rc = mi355x_gemv_fused(k, &d);
-    if (rc == MI355X_E_UNSUPPORTED && d.has_norm) {          // the LayerNorm form was not taken (e.g. the vocabulary projection): planes
-        rc = use_planes();
-        if (rc == MI355X_E_UNSUPPORTED) return false;
-        if (rc) { rc_out = rc; return true; }
-        rc = mi355x_gemv_fused(k, &d);
-    }
     if (rc == 0 && mirror && mi355x_last_launch_mirrored(k)) {
         const size_t rowb = (size_t) ch[0].last->ne[0] * 4;
         if (cs.S > 1) for (int c = 0; c < cs.T; c++) { mi_backend_ctx * ob = cs.owner[c]; ob->mirror_src = cs_tensor(cs, c, ch[0].end, -1)->data; ob->mirror_bytes = rowb; ob->mirror_state.store(1); }
@@ -1659,7 +1662,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
     return mi355x_flush(b->k);            // launches the kernel library held back for grouping (gemm_mfma.hip) leave with their range
 }
 static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
-    b->act_src = nullptr; b->qs = mi_qstate();
+    b->act_src = nullptr; b->elided_src = nullptr; b->qs = mi_qstate();
     return mi_emit_range(b, g, 0, g->n_nodes);
 }
 
@@ -1825,10 +1828,15 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
             // every state is checked ONCE per graph shape — node for node against the chain's first graph — before it may be a column,
             // not only the states that happened to be in the first batch of that shape
             bool fresh = grp.sig_nodes != sn || grp.sig_w != sw;
+            // a state already verified for this shape (an unverified state in column 0 used to be compared with itself only)
+            int vref = -1;
+            for (int c = 0; c < n && vref < 0; c++) if (mem[c]->b->sig_nodes == sn && mem[c]->b->sig_w == sw) vref = c;
+            if (vref < 0) fresh = true;                                      // nobody here has been checked: the dry walk below vouches for column 0
             for (int c = 0; c < n && ok; c++) {
                 mi_backend_ctx * bc = mem[c]->b;
-                if (bc->sig_nodes == sn && bc->sig_w == sw && !fresh) continue;
-                if (c > 0 || !fresh) ok = mi_graphs_congruent(g0, cs.g[c]);
+                if (!fresh && bc->sig_nodes == sn && bc->sig_w == sw) continue;          // verified earlier, and so is the graph it is compared with (transitively)
+                const int ref = fresh ? 0 : vref;                           // fresh: everybody against column 0 (walked below); else against a verified member
+                if (c != ref) ok = mi_graphs_congruent(cs.g[ref], cs.g[c]);
             }
             if (ok && fresh) ok = mi_walk_batch(nullptr, cs) == 0;
             if (ok) { grp.sig_nodes = sn; grp.sig_w = sw; for (int c = 0; c < n; c++) { mem[c]->b->sig_nodes = sn; mem[c]->b->sig_w = sw; } }
@@ -1858,12 +1866,18 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
     mi_io_order_stream(b0->device, ln.io, bs);                // every member's graph inputs leave with one scatter launch at the head of the chain
     const int rc = mi_walk_batch(ln.k, cs);
     if (rc != 0) {
-        // a kernel rejected the chain half-way (a shape or alignment only its launch code knows): what was launched has written nothing a
-        // repeat would not write again (activations, this position's KV rows), so every member runs its step again on its own chain
-        // once the partial chain has drained, and this graph shape stops batching
-        GGML_LOG_WARN("ggml-mi355x: cross-state batch rejected mid-chain (rc=%d %s): %d states repeat the step on their own chains\n", rc, mi355x_last_error(), n);
         (void) mi355x_ctx_synchronize(ln.k);
         grp.n_fallback++;
+        if (rc != MI355X_E_UNSUPPORTED && rc != (int) hipErrorInvalidValue) {
+            // a device fault, not a rejection: repeating the step n times on the states' own chains would hit the same fault n times
+            GGML_LOG_ERROR("ggml-mi355x: cross-state batch failed mid-chain (rc=%d %s): %d states report failure\n", rc, mi355x_last_error(), n);
+            for (int c = 0; c < n; c++) mem[c]->status = GGML_STATUS_FAILED;
+            return false;
+        }
+        // a kernel rejected the chain half-way (a shape or alignment only its launch code knows): what was launched has written nothing a
+        // repeat would not write again (activations, this position's KV rows), so every member runs its step again on its own chain
+        // once the partial chain has drained, and this graph shape stops batching for these states
+        GGML_LOG_WARN("ggml-mi355x: cross-state batch rejected mid-chain (rc=%d %s): %d states repeat the step on their own chains\n", rc, mi355x_last_error(), n);
         { std::lock_guard<std::mutex> sl(grp.sig_m); grp.sig_nodes = 0; grp.sig_w = nullptr; }
         for (int c = 0; c < n; c++) {
             mem[c]->b->no_batch_nodes = mem[c]->g->n_nodes; mem[c]->b->sig_nodes = 0;

@@ -171,6 +171,7 @@ void * mi355x_scratch_alloc(mi355x_ctx * ctx, size_t bytes) {
         size_t want = ctx->scratch_used + bytes;
         size_t nsz = ctx->scratch_size ? ctx->scratch_size : ((size_t) 64 << 20);
         while (nsz < want) nsz *= 2;
+        (void) mi355x_flush_pending(ctx);                // a held-back GEMM reads rows in the arena that is about to be retired: it leaves first
         (void) hipStreamSynchronize(ctx->stream);
         void * nptr = nullptr;
         if (hipMalloc(&nptr, nsz) != hipSuccess) { mi355x_set_error("scratch alloc of %zu bytes failed", nsz); return nullptr; }

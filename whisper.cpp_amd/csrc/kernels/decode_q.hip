@@ -213,7 +213,6 @@ struct QGArgs {
     QSeg seg[3];
     const uint16_t * gelu_tab;
     void * planes_out; int planes_only; int pad;
-    const float * ln_w; const float * ln_b; float eps; int pad2;          // LN form: planes built in the prologue from cols.x
     mi355x_gemv_cols cols;
 };
 
@@ -252,14 +251,11 @@ __device__ __forceinline__ void wblk_dot_q4k_rt(const wblk<MI355X_TYPE_Q4_K> & r
 // TMAX: columns the kernel is built for (run-time T <= TMAX).  NU: lane-units per row and lane (1: K <= 2048, 3: K <= 6144; Q4_K
 // units are 64 elements: 1: K <= 4096, 2: K <= 8192).  R rows per wave.  POUT: 8 waves x 4 rows = the 32 rows of one Q8_0
 // block of the RESULT per workgroup, whose planes are written as well (single segment).
-// LN: no planes come in; the prologue is k_act_prepare MODE 1 for all T columns at once (LayerNorm + affine of cols.x[t], then the
-// quantizer), statement for statement, written to the LDS image instead of HBM — one dependent launch less per LayerNorm.  The
-// weights are requested first and stay in flight under it.  K <= 2048 (NU == 1).
 // MG: more than one image (T > 8).  MG = false is the single-image kernel: no image loop, no prefetch registers.
-template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT, bool LN, bool MG>
+template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT, bool MG>
 __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QGArgs a) {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
-    constexpr int CP = LN ? 1 : (TMAX * (Q4K ? NU*4096*9/8 + 256 : NU*64*40) / 16 + 255) / 256;       // uint4 copy slots per thread (>= 256 threads)
+    constexpr int CP = (TMAX * (Q4K ? NU*4096*9/8 + 256 : NU*64*40) / 16 + 255) / 256;       // uint4 copy slots per thread (>= 256 threads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;
@@ -311,22 +307,10 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
     auto img_n16 = [&](int Ti) { return (int) (((Q4K ? (size_t) Ti * ((size_t) K + nsb*4 + (K >> 5)*4) : (size_t) Ti * nb * 40) + 15) >> 4); };
     int n16 = img_n16(T);
     u32x4 cp[CP];
-    float4 xr[LN ? TMAX : 1], lw, lb;
-    const int K4 = K >> 2;
-    if constexpr (LN) {
-        const int e4c = tid < K4 ? tid : K4 - 1;
-        #pragma unroll
-        for (int tt = 0; tt < TMAX; tt++) {
-            const float * xp = ka->cols.x[tt];                 // (columns >= T repeat column T - 1: launcher)
-            xr[tt] = *(const float4 *) ((const char *) xp + (size_t) e4c*16);
-        }
-        lw = *(const float4 *) (a.ln_w + e4c*4); lb = *(const float4 *) (a.ln_b + e4c*4);
-    } else {
-        #pragma unroll
-        for (int i = 0; i < CP; i++) {
-            const int idx = tid + i*nthreads;
-            cp[i] = ((const u32x4 *) a.planes)[idx < n16 ? idx : n16 - 1];
-        }
+    #pragma unroll
+    for (int i = 0; i < CP; i++) {
+        const int idx = tid + i*nthreads;
+        cp[i] = ((const u32x4 *) a.planes)[idx < n16 ? idx : n16 - 1];
     }
     __builtin_amdgcn_sched_barrier(0);
     const float * bptr = sg.bias ? sg.bias + row + rlane : (const float *) a.gelu_tab;
@@ -355,67 +339,15 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
         // ---- plane image -> LDS ----
         // (unconditional stores: surplus slots land in one dummy word behind the image.  A predicated store in this loop makes the
         //  compiler turn the predicate into a loop exit, keep the loop rolled and park cp[] in scratch memory.)
-        if constexpr (LN) {
-            __shared__ float red[2][TMAX][16];
-            uint32_t * plo, * phi; float * pdx; int * psx;
-            planes_of<Q4K>(smem, K, T, plo, phi, pdx, psx);
-            if (gi > 0) {
-                const int e4c = tid < K4 ? tid : K4 - 1;
-                #pragma unroll
-                for (int tt = 0; tt < TMAX; tt++) {
-                    const float * xp = ka->cols.x[gi * MI355X_IMG_COLS + tt];
-                    xr[tt] = *(const float4 *) ((const char *) xp + (size_t) e4c*16);
-                }
-            }
-            #pragma unroll
-            for (int tt = 0; tt < TMAX; tt++) {
-                float p = 0.0f;
-                if (tid < K4) p += (xr[tt].x + xr[tt].y) + (xr[tt].z + xr[tt].w);
-                p = wave_sum(p);
-                if (lane == 0) red[0][tt][wave] = p;
-            }
-            __syncthreads();
-            float mean[TMAX];
-            #pragma unroll
-            for (int tt = 0; tt < TMAX; tt++) {
-                float rs = 0.0f;
-                #pragma unroll
-                for (int w = 0; w < 8; w++) { const float pw = red[0][tt][w]; rs += w < nwaves ? pw : 0.0f; }
-                mean[tt] = rs / K;
-                float p = 0.0f;
-                if (tid < K4) {
-                    const float d0 = xr[tt].x - mean[tt], d1 = xr[tt].y - mean[tt], d2 = xr[tt].z - mean[tt], d3 = xr[tt].w - mean[tt];
-                    p += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
-                }
-                p = wave_sum(p);
-                if (lane == 0) red[1][tt][wave] = p;
-            }
-            __syncthreads();
-            #pragma unroll
-            for (int tt = 0; tt < TMAX; tt++) {
-                float rs = 0.0f;
-                #pragma unroll
-                for (int w = 0; w < 8; w++) { const float pw = red[1][tt][w]; rs += w < nwaves ? pw : 0.0f; }
-                const float rstd = 1.0f / sqrtf(rs / K + a.eps);
-                if (tt < T && tid < K4) {
-                    float o[4] = { (xr[tt].x - mean[tt]) * rstd, (xr[tt].y - mean[tt]) * rstd, (xr[tt].z - mean[tt]) * rstd, (xr[tt].w - mean[tt]) * rstd };
-                    o[0] = o[0]*lw.x; o[1] = o[1]*lw.y; o[2] = o[2]*lw.z; o[3] = o[3]*lw.w;
-                    o[0] = o[0]+lb.x; o[1] = o[1]+lb.y; o[2] = o[2]+lb.z; o[3] = o[3]+lb.w;
-                    if constexpr (Q4K) dg_q8_K_store(o, tid*4, tt, K, T, plo, pdx, psx);
-                    else               dg_q8_0_store(o, tid*4, tt, K >> 5, plo, phi, pdx, psx);
-                }
-            }
-        } else {
-            #pragma unroll
-            for (int i = 0; i < CP; i++) {
-                const int idx = tid + i*nthreads;
-                ((u32x4 *) smem)[idx < n16 ? idx : n16] = cp[i];
-            }
+        #pragma unroll
+        for (int i = 0; i < CP; i++) {
+            const int idx = tid + i*nthreads;
+            ((u32x4 *) smem)[idx < n16 ? idx : n16] = cp[i];
         }
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);          // nothing that needs the WEIGHTS may move above the barrier: they are still in flight while the planes settle
         const int Tn = Tall - (gi + 1) * MI355X_IMG_COLS < MI355X_IMG_COLS ? Tall - (gi + 1) * MI355X_IMG_COLS : MI355X_IMG_COLS;      // columns of the next image
-        if constexpr (!LN && MG) {
+        if constexpr (MG) {
             if (gi + 1 < G) {           // the next image: in flight under this image's dots
                 n16 = img_n16(Tn);
                 const u32x4 * nxt = (const u32x4 *) ((const char *) a.planes + (size_t) (gi + 1) * istride);
@@ -535,51 +467,38 @@ __global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QG
 }
 
 template <int WT, int TMAX, int NU, bool MG>
-static int launch_gemv_q_v(mi355x_ctx * ctx, const QGArgs & k, bool nseg1, bool pout, bool ln, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
+static int launch_gemv_q_v(mi355x_ctx * ctx, const QGArgs & k, bool nseg1, bool pout, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv_q";
-    if constexpr (NU == 1) {
-        if (ln) {
-            if constexpr (WT != MI355X_TYPE_Q4_K) {
-                if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, true, MG>, grid, block, lds, k, bytes, flops);
-            }
-            if (pout) return MI355X_E_UNSUPPORTED;
-            if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, true, MG>, grid, block, lds, k, bytes, flops);
-            return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, true, MG>, grid, block, lds, k, bytes, flops);
-        }
-    }
-    if (ln) return MI355X_E_UNSUPPORTED;
     if constexpr (NU == 1 && WT != MI355X_TYPE_Q4_K) {
-        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, false, MG>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
-        if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, false, MG>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
+        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, MG>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
+        if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, MG>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
     }
     if (pout) return MI355X_E_UNSUPPORTED;
-    if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, false, MG>, grid, block, lds, k, bytes, flops);
-    if constexpr (NU == 1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, false, MG>, grid, block, lds, k, bytes, flops);
+    if (nseg1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 1, false, MG>, grid, block, lds, k, bytes, flops);
+    if constexpr (NU == 1) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, false, 1, false, MG>, grid, block, lds, k, bytes, flops);
     return MI355X_E_UNSUPPORTED;
 }
 template <int WT>
-static int launch_gemv_q(mi355x_ctx * ctx, const QGArgs & k, int nu, bool nseg1, bool pout, bool ln, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
+static int launch_gemv_q(mi355x_ctx * ctx, const QGArgs & k, int nu, bool nseg1, bool pout, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     constexpr int NUBIG = WT == MI355X_TYPE_Q4_K ? 2 : 3;
     if (k.T <= 4) {
-        if (nu == 1) return launch_gemv_q_v<WT, 4, 1, false>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
-        if (pout || ln) return MI355X_E_UNSUPPORTED;
-        return launch_gemv_q_v<WT, 4, NUBIG, false>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
+        if (nu == 1) return launch_gemv_q_v<WT, 4, 1, false>(ctx, k, nseg1, pout, grid, block, lds, bytes, flops);
+        if (pout) return MI355X_E_UNSUPPORTED;
+        return launch_gemv_q_v<WT, 4, NUBIG, false>(ctx, k, nseg1, false, grid, block, lds, bytes, flops);
     }
     if (k.T <= MI355X_IMG_COLS) {
-        if (nu == 1) return launch_gemv_q_v<WT, 8, 1, false>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
-        if (pout || ln) return MI355X_E_UNSUPPORTED;
-        return launch_gemv_q_v<WT, 8, NUBIG, false>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
+        if (nu == 1) return launch_gemv_q_v<WT, 8, 1, false>(ctx, k, nseg1, pout, grid, block, lds, bytes, flops);
+        if (pout) return MI355X_E_UNSUPPORTED;
+        return launch_gemv_q_v<WT, 8, NUBIG, false>(ctx, k, nseg1, false, grid, block, lds, bytes, flops);
     }
-    if (nu == 1) return launch_gemv_q_v<WT, 8, 1, true>(ctx, k, nseg1, pout, ln, grid, block, lds, bytes, flops);
-    if (pout || ln) return MI355X_E_UNSUPPORTED;
-    return launch_gemv_q_v<WT, 8, NUBIG, true>(ctx, k, nseg1, false, false, grid, block, lds, bytes, flops);
+    if (nu == 1) return launch_gemv_q_v<WT, 8, 1, true>(ctx, k, nseg1, pout, grid, block, lds, bytes, flops);
+    if (pout) return MI355X_E_UNSUPPORTED;
+    return launch_gemv_q_v<WT, 8, NUBIG, true>(ctx, k, nseg1, false, grid, block, lds, bytes, flops);
 }
 
 // mat-vec over pre-quantized activation planes; MI355X_E_UNSUPPORTED: the caller tries k_gemv8 (which copies the same image)
 int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
-    // activations: prepared planes, or (LN form) per-column F32 vectors normalised and quantized in the prologue
-    const bool ln = !d->x_planes && d->has_norm && d->cols && d->cols->x[0];
-    if ((!d->x_planes && !ln) || d->x || d->attn_part_o || (d->has_norm && !ln)) return MI355X_E_UNSUPPORTED;
+    if (!d->x_planes || d->x || d->attn_part_o || d->has_norm) return MI355X_E_UNSUPPORTED;
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > MI355X_MAX_COLS || ((uintptr_t) d->x_planes % 16)) return MI355X_E_UNSUPPORTED;
     const int wt = d->seg[0].wtype, K = d->K, T = d->T;
     if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;
@@ -590,12 +509,6 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (units > 64 * nu) return MI355X_E_UNSUPPORTED;
     QGArgs k; memset(&k, 0, sizeof(k));
     k.planes = d->x_planes; k.K = K; k.T = T; k.nseg = d->nseg; k.gelu_tab = ctx->gelu_tab;
-    if (ln) {
-        if (K > 2048 || nu != 1 || !d->ln_w || !d->ln_b || ((uintptr_t) d->ln_w % 16) || ((uintptr_t) d->ln_b % 16)) return MI355X_E_UNSUPPORTED;
-        for (int t = 0; t < T; t++) if (!d->cols->x[t] || ((uintptr_t) d->cols->x[t] % 16)) return MI355X_E_UNSUPPORTED;
-        for (int t = 0; t < MI355X_MAX_COLS; t++) k.cols.x[t] = d->cols->x[t < T ? t : T - 1];
-        k.ln_w = d->ln_w; k.ln_b = d->ln_b; k.eps = d->eps;
-    }
     int ntot = 0; double wbytes = 0;
     for (int s = 0; s < d->nseg; s++) {
         const mi355x_gemv_seg & g = d->seg[s];
@@ -632,16 +545,16 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (lds > 64 * 1024) return MI355X_E_UNSUPPORTED;
     // the 32 rows of a planes-out workgroup: 8 waves x 4 rows or 16 waves x 2 rows (GGML_MI355X_POUT_ROWS; more waves = more loads in flight per CU)
     static const int pout_rows = getenv("GGML_MI355X_POUT_ROWS") && atoi(getenv("GGML_MI355X_POUT_ROWS")) == 2 ? 2 : 4;
-    const int prows = ln ? 4 : pout_rows;                 // (the LayerNorm form keeps T float4 per thread: 8 waves x 4 rows only)
+    const int prows = pout_rows;
     const int waves = pout ? 32 / prows : gemv_row_waves(K), rpb = pout ? 32 : waves;
     const dim3 grid((ntot + rpb - 1) / rpb), block(64 * waves);
-    const double bytes = wbytes + (ln ? (double) T*K*4 : (double) dg_planes_bytes(wt, K, T)) + (double) ntot*T*4;
+    const double bytes = wbytes + (double) dg_planes_bytes(wt, K, T) + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;
     switch (wt) {
-        case MI355X_TYPE_Q4_0: return launch_gemv_q<MI355X_TYPE_Q4_0>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q5_0: return launch_gemv_q<MI355X_TYPE_Q5_0>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q8_0: return launch_gemv_q<MI355X_TYPE_Q8_0>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
-        case MI355X_TYPE_Q4_K: return launch_gemv_q<MI355X_TYPE_Q4_K>(ctx, k, nu, d->nseg == 1, pout, ln, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q4_0: return launch_gemv_q<MI355X_TYPE_Q4_0>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q5_0: return launch_gemv_q<MI355X_TYPE_Q5_0>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q8_0: return launch_gemv_q<MI355X_TYPE_Q8_0>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
+        case MI355X_TYPE_Q4_K: return launch_gemv_q<MI355X_TYPE_Q4_K>(ctx, k, nu, d->nseg == 1, pout, grid, block, (uint32_t) lds, bytes, flops);
     }
     return MI355X_E_UNSUPPORTED;
 }

@@ -359,7 +359,7 @@ extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     ctx->last_mirrored = 0;
     if (d->nseg < 1 || d->nseg > 3 || d->T < 1 || d->T > MI355X_MAX_COLS) return MI355X_E_UNSUPPORTED;
     // more than 8 columns: the plane kernels only (images of 8 columns, decode_q.hip)
-    if (d->T > MI355X_IMG_COLS && !d->x_planes && !(!d->x && d->has_norm && d->cols && d->cols->x[0])) return MI355X_E_UNSUPPORTED;
+    if (d->T > MI355X_IMG_COLS && !d->x_planes) return MI355X_E_UNSUPPORTED;
     for (int s = 0; s < d->nseg; s++) if (d->seg[s].ep.bias_per_col) return MI355X_E_UNSUPPORTED;      // (MFMA path only)
     if (d->x_planes) {   // wide cross-state batches: the matrix-core form (decode_mx.hip), same summation trees as the kernels below
         const int rc = mi355x_gemv_mx(ctx, d);
@@ -386,7 +386,7 @@ extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
             if (d->cols) {
                 memset(&cols, 0, sizeof(cols));
                 for (int s = 0; s < d->nseg; s++) for (int t = 0; t < sub.T; t++) { cols.dst[s][t] = d->cols->dst[s][c0 + t]; cols.res[s][t] = d->cols->res[s][c0 + t]; }
-                for (int t = 0; t < sub.T; t++) { cols.mirror[t] = d->cols->mirror[c0 + t]; cols.x[t] = d->cols->x[c0 + t]; }
+                for (int t = 0; t < sub.T; t++) { cols.mirror[t] = d->cols->mirror[c0 + t]; }
                 sub.cols = &cols;
             } else {
                 for (int s = 0; s < d->nseg; s++) {
@@ -405,7 +405,6 @@ extern "C" int mi355x_gemv_fused(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         ctx->last_mirrored = mirrored ? 1 : 0;
         return 0;
     }
-    if (!d->x && d->has_norm && d->cols && d->cols->x[0]) return mi355x_gemv_q(ctx, d);      // the plane kernel's LayerNorm form (no planes in HBM)
     {   // the lean decode kernels (decode.hip) take every quantized shape of the whisper graphs; what is left for k_gemv below:
         // F16 weights (f16 models), LDS-heavy shapes (K*T too large for the 64 KB planes)
         const int rc = mi355x_gemv8(ctx, d);

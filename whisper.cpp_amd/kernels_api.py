@@ -62,7 +62,7 @@ IMG_COLS = 8
 
 
 class GemvCols(C.Structure):          # mi355x_gemv_cols: [segment][column] destinations / residuals
-    _fields_ = [("dst", (C.c_void_p * MAX_COLS) * 3), ("res", (C.c_void_p * MAX_COLS) * 3), ("mirror", C.c_void_p * MAX_COLS), ("x", C.c_void_p * MAX_COLS)]
+    _fields_ = [("dst", (C.c_void_p * MAX_COLS) * 3), ("res", (C.c_void_p * MAX_COLS) * 3), ("mirror", C.c_void_p * MAX_COLS)]
 
 
 class ActDesc(C.Structure):
