@@ -41,6 +41,8 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # MI355X_MICROARCH.md: 6.29 TB/s measured (float4 copy, 79 % of spec) — reported beside the spec peak
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak
+MFMA_I8_PEAK_TOPS = 5000.0     # dense int8 MFMA peak (2 x bf16: 2 x K per instruction); measured micro-benchmark ceiling 4404 TOPS (32x32x32), 3944 (16x16x64) — MI355X_MICROARCH.md
+MFMA_I8_MEASURED_TOPS = 4404.0
 
 
 class ContextParams(C.Structure):       # struct whisper_context_params, include/whisper.h:116-129
@@ -123,9 +125,14 @@ def algorithmic_figures(arch: str, qtype: str):
     dec_w = n_tl * (4 + 4 + 8) * n_ts * n_ts + n_vocab * n_ts            # self-attn 4n^2, cross-attn q/k(v precomputed)/o ... + mlp 8n^2 + logits
     dec_w = n_tl * (4 * n_ts * n_ts + 2 * n_ts * n_ts + 8 * n_ts * n_ts) + n_vocab * n_ts
     kv_cross = n_tl * 2 * n_ctx_pad * n_ts * 2
-    enc_flop = 2.0 * n_actx * n_al * 12 * n_as * n_as + 4.0 * n_actx * n_ctx_pad * n_as * n_al \
-        + 2.0 * (2 * n_actx) * n_as * 3 * n_mels + 2.0 * n_actx * n_as * 3 * n_as + 2.0 * n_actx * n_tl * 2 * n_ts * n_ts
-    return {"decode_bytes_per_token": dec_w * bpw + kv_cross, "encode_flop": enc_flop, "decode_weight_bytes": dec_w * bpw, "decode_kv_bytes_per_stream": kv_cross}
+    gemm_flop = 2.0 * n_actx * n_al * 12 * n_as * n_as + 2.0 * n_actx * n_tl * 2 * n_ts * n_ts          # encoder layers' products + cross-K/V: quantized weights -> int8 MFMA
+    f16_flop = 4.0 * n_actx * n_ctx_pad * n_as * n_al + 2.0 * (2 * n_actx) * n_as * 3 * n_mels + 2.0 * n_actx * n_as * 3 * n_as      # attention + the two convolutions: f16 MFMA
+    enc_flop = gemm_flop + f16_flop
+    int8 = qtype != "f16"
+    # roofline time of one encode: every part at the dense peak of the matrix-core type it runs on
+    enc_bound_ms = (gemm_flop / ((MFMA_I8_PEAK_TOPS if int8 else MFMA_F16_PEAK_TFLOPS) * 1e12) + f16_flop / (MFMA_F16_PEAK_TFLOPS * 1e12)) * 1e3
+    return {"decode_bytes_per_token": dec_w * bpw + kv_cross, "encode_flop": enc_flop, "decode_weight_bytes": dec_w * bpw, "decode_kv_bytes_per_stream": kv_cross,
+            "encode_flop_int8": gemm_flop if int8 else 0.0, "encode_flop_f16": f16_flop if int8 else enc_flop, "encode_bound_ms": enc_bound_ms}
 
 
 DTYPE = "int8 dot (decode mat-vecs) / int8 MFMA (quantized products with > 8 columns) / f16 MFMA (attention, conv), f32 accumulate"
@@ -163,7 +170,7 @@ def run_in_process(a, cpu_selftest: bool, hip_runtime: str):
     ms_per_step = r["ms_per_chunk_per_stream"]
     out = contract_line(a, a.gpus, a.streams, ms_per_step, ms_per_step / n_streams, r["chunks_per_s"])
     figs = algorithmic_figures(a.arch, a.qtype)
-    bound_ms = figs["encode_flop"] / (MFMA_F16_PEAK_TFLOPS * 1e12) * 1e3 + a.n_decode * figs["decode_bytes_per_token"] / (HBM_PEAK_GBS * 1e9) * 1e3
+    bound_ms = figs["encode_bound_ms"] + a.n_decode * figs["decode_bytes_per_token"] / (HBM_PEAK_GBS * 1e9) * 1e3
     out.update({
         "launch": f"one process, {a.gpus} contexts x {a.streams} states, one host thread per state (mi355x_host_run)", "hip_runtime": hip_runtime,
         "weight_broadcast": None if cpu_selftest else {
@@ -500,37 +507,55 @@ def main():
             dom = max(fam.values(), key=lambda f: f["total_ms"])
             big = max(dom["members"], key=lambda r: r["total_ms"])
             avg_ms = dom["total_ms"] / max(dom["calls"], 1)
-            if "gemm" in dom["name"] or "fattn_mfma" in dom["name"] or "mmq" in dom["name"]:
+            is_i8 = "mmq" in dom["name"]
+            if "gemm" in dom["name"] or "fattn_mfma" in dom["name"] or is_i8:
                 ach = dom["algo_flops"] / (dom["total_ms"] * 1e-3) / 1e12
-                out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 3), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None}
+                peak = MFMA_I8_PEAK_TOPS if is_i8 else MFMA_F16_PEAK_TFLOPS          # an int8 kernel is scored against the int8 ceiling
+                out["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TOP/s" if is_i8 else "TFLOP/s",
+                                   "frac": round(ach / peak, 4), "traffic": None}
+                if is_i8:
+                    out["roofline"]["measured_ceiling"] = MFMA_I8_MEASURED_TOPS
             else:
                 ach = dom["algo_bytes"] / (dom["total_ms"] * 1e-3) / 1e9
                 out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                                    "measured_copy_ceiling": HBM_COPY_CEILING_GBS, "frac_of_copy_ceiling": round(ach / HBM_COPY_CEILING_GBS, 4)}
-            # HBM traffic per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
-            # MI355X_MICROARCH.md prescribes; profiles/pmc_traffic.json says how it was collected); null if not measured
+            # HBM traffic from the committed PMC passes of THIS configuration (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md
+            # prescribes; profiles/pmc_traffic.json says how it was collected).  Like `achieved`, `traffic` is the FAMILY's figure per launch: the
+            # launch-weighted mean over its instantiations of the counter bytes, next to `algorithmic_per_launch`, the same mean of the algorithmic
+            # bytes — and every instantiation is listed with its own pair (same kernel, same launch), so that traffic / algorithmic means something.
+            pmc = {}
             try:
-                pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["kernels"]
-                key = big["name"].split("(")[0].strip()
-                if key in pmc:
-                    out["roofline"]["traffic"] = pmc[key]["hbm_bytes_per_launch"]
+                pj = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())
+                pmc = pj.get("configs", {}).get(f"{a.arch} {a.qtype}", {}).get("kernels", {})
             except Exception:  # noqa: BLE001
                 pass
+            hbm = out["roofline"]["bound"] == "hbm"
+            inst = []
+            for r in sorted(dom["members"], key=lambda r: -r["total_ms"]):
+                key = r["name"].split("(")[0].strip()
+                e = {"name": r["name"], "launches": r["calls"], "avg_launch_us": round(r["total_ms"] * 1e3 / max(r["calls"], 1), 3),
+                     "algorithmic_per_launch": (r["algo_bytes"] if hbm else r["algo_flops"]) / max(r["calls"], 1),
+                     "traffic": pmc[key]["hbm_bytes_per_launch"] if key in pmc else None}
+                if hbm:
+                    e["GBps"] = round(r["algo_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 1) if r["total_ms"] > 0 else None
+                    e["traffic_over_algorithmic"] = round(e["traffic"] / e["algorithmic_per_launch"], 3) if e["traffic"] and e["algorithmic_per_launch"] else None
+                inst.append(e)
+            if inst and all(e["traffic"] is not None for e in inst):
+                out["roofline"]["traffic"] = round(sum(e["traffic"] * e["launches"] for e in inst) / max(dom["calls"], 1))
             out["roofline"].update({"launches": dom["calls"], "avg_launch_us": round(avg_ms * 1e3, 3), "share_of_gpu_time": round(dom["total_ms"] / total, 4),
-                                    "algorithmic_per_launch": (dom["algo_bytes"] if out["roofline"]["bound"] == "hbm" else dom["algo_flops"]) / max(dom["calls"], 1),
-                                    "instantiations": len(dom["members"]),
-                                    "largest_instantiation": {"name": big["name"], "launches": big["calls"], "avg_launch_us": round(big["total_ms"] * 1e3 / max(big["calls"], 1), 3),
-                                                              "GBps": round(big["algo_bytes"] / (big["total_ms"] * 1e-3) / 1e9, 1) if big["total_ms"] > 0 else None}})
+                                    "algorithmic_per_launch": (dom["algo_bytes"] if hbm else dom["algo_flops"]) / max(dom["calls"], 1),
+                                    "instantiations": inst})
             # the whole step against the same peaks: algorithmic bytes per token / measured ms per token / HBM peak, encoder FLOP / measured ms / MFMA peak
             dec_b = figs["decode_bytes_per_token"]
             if decode_ms > 0:
                 out["roofline"]["step_frac"] = round(dec_b / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if encode_ms > 0:
-                out["roofline"]["encode_frac"] = round(figs["encode_flop"] / (encode_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
+                # encoder: roofline time (int8 products at the int8 peak, attention / conv at the f16 peak) / measured time
+                out["roofline"]["encode_frac"] = round(figs["encode_bound_ms"] / encode_ms, 4)
+                out["roofline"]["encode_frac_if_all_f16_peak"] = round(figs["encode_flop"] / (encode_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4)
             # roofline time of the chunk (encoder at the MFMA peak + n_decode tokens at the HBM peak) / measured time
-            bound_ms = figs["encode_flop"] / (MFMA_F16_PEAK_TFLOPS * 1e12) * 1e3 + a.n_decode * dec_b / (HBM_PEAK_GBS * 1e9) * 1e3
+            bound_ms = figs["encode_bound_ms"] + a.n_decode * dec_b / (HBM_PEAK_GBS * 1e9) * 1e3
             out["roofline"]["chunk_frac"] = round(bound_ms / agg_ms, 4) if agg_ms > 0 else None
             out["kernel_time_ms_per_chunk"] = {r["name"]: round(r["total_ms"], 3) for r in sorted(prof, key=lambda r: -r["total_ms"])}
             # every kernel with >= 2 % of the GPU time: launches, mean duration, achieved algorithmic GB/s and TFLOP/s

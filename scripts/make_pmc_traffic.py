@@ -29,6 +29,13 @@ for name, (n, tot) in sorted(rd.items(), key=lambda kv: -kv[1][1]):
     wn, wt = wr.get(name, [0, 0.0])
     w = wt / wn * 1024 if wn else 0.0
     kern[name] = {"launches_sampled": n, "hbm_read_bytes_per_launch": round(r), "hbm_write_bytes_per_launch": round(w), "hbm_bytes_per_launch": round(r + w)}
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --arch large-v3 --qtype q5_0 --steps 1 --warmup 0 "
-                            "--n-decode 8`; bytes = counter * 1024, FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64 B, MI355X_MICROARCH.md HBM "
-                            "section); WRITE_SIZE uncalibrated", "round": rnd, "kernels": kern}, indent=1))
+# optional: argv[3] = "<arch> <qtype>" of the pass, argv[4] = an existing pmc_traffic.json to merge into (configs are keyed by "<arch> <qtype>")
+cfg = sys.argv[3] if len(sys.argv) > 3 else "large-v3 q5_0"
+doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --arch A --qtype Q --steps 1 --warmup 0 --n-decode 8`, one entry per "
+                 "configuration; bytes = counter * 1024, FETCH_SIZE doubled (gfx950: 128-byte requests tallied at 64 B, MI355X_MICROARCH.md HBM section); "
+                 "WRITE_SIZE uncalibrated", "round": rnd, "configs": {}}
+if len(sys.argv) > 4 and os.path.exists(sys.argv[4]):
+    old = json.load(open(sys.argv[4]))
+    doc["configs"] = old.get("configs", {})
+doc["configs"][cfg] = {"round": rnd, "kernels": kern}
+print(json.dumps(doc, indent=1))

@@ -179,7 +179,7 @@ def test_pmc_traffic_json_applies_the_gfx950_corrections(tmp_path):
             w.writerow(["__amd_rocclr_copyBuffer", ctr, 5.0])
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "make_pmc_traffic.py"), str(tmp_path), "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
-    k = json.loads(r.stdout)["kernels"]
+    k = json.loads(r.stdout)["configs"]["large-v3 q5_0"]["kernels"]      # (one entry per benchmarked configuration since r05)
     assert list(k) == ["void k_x<1>"]                                # runtime copy kernels are not ours
     assert k["void k_x<1>"] == {"launches_sampled": 2, "hbm_read_bytes_per_launch": 200 * 1024 * 2, "hbm_write_bytes_per_launch": 20 * 1024,
                                "hbm_bytes_per_launch": 200 * 1024 * 2 + 20 * 1024}
@@ -187,7 +187,9 @@ def test_pmc_traffic_json_applies_the_gfx950_corrections(tmp_path):
 
 def test_committed_pmc_traffic_covers_the_benchmarked_kernels():
     """bench.py looks the dominant kernel up in profiles/pmc_traffic.json by its demangled name without the argument list"""
-    k = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["kernels"]
+    cfgs = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text())["configs"]
+    assert "large-v3 q5_0" in cfgs                                   # the headline; BASELINE.json's configs[2] (large-v3 Q4_K) is added by the round's closing run
+    k = cfgs["large-v3 q5_0"]["kernels"]
     for name in ("void k_fattn_dec<1>", "void k_gemv_row<6, 1, 1, 2, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 1>", "void k_gemv_row<6, 1, 1, 1, true, 4>",
                  "void k_vocab<6, 1, 5, 1>", "void k_gemv_q<6, 8, 1, true, 1, false, false, false>"):
         assert name in k and k[name]["hbm_bytes_per_launch"] > 0, name

@@ -803,6 +803,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             const int rr = mi_act_reserve(b, (size_t) T * K * 2);          // (rows need 1.25 bytes per element: the f16 size covers them)
             if (rr != 0) return rr;
             if (!(b->act_src == x->data && b->act_K == K && b->act_T == T && b->act_mode == rmode && b->act_nb1 == (int64_t) x->nb[1])) {
+                if (reads_elided()) return (int) hipErrorInvalidValue;
                 const int rc = mi355x_prep_act(b->k, x->data, (int64_t) x->nb[1], x->type == GGML_TYPE_F16, b->act, (int) K, T, rmode);
                 if (rc && rc != MI355X_E_UNSUPPORTED) return rc;
                 if (rc == 0) { b->act_src = x->data; b->act_K = K; b->act_T = T; b->act_mode = rmode; b->act_nb1 = (int64_t) x->nb[1]; }
@@ -833,7 +834,6 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                 if (rc != MI355X_E_UNSUPPORTED) return rc;
             }
         }
-        if (reads_elided()) return (int) hipErrorInvalidValue;            // everything below reads x->data
         if (!((mode == 1 && K % 32) || (mode == 2 && K % 256))) {
             const void * act; int64_t ld;
             if (x->type == GGML_TYPE_F16 && mode == 0) { act = x->data; ld = (int64_t) x->nb[1] / 2; }
@@ -841,6 +841,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                 const int rr = mi_act_reserve(b, (size_t) T * K * 2);
                 if (rr != 0) return rr;
                 if (!(b->act_src == x->data && b->act_K == K && b->act_T == T && b->act_mode == mode && b->act_nb1 == (int64_t) x->nb[1])) {
+                    if (reads_elided()) return (int) hipErrorInvalidValue;        // (the prepared form on hand is not this path's: x->data would be read)
                     const int rc = mi355x_prep_act(b->k, x->data, (int64_t) x->nb[1], x->type == GGML_TYPE_F16, b->act, (int) K, T, mode);
                     if (rc) return rc;
                     b->act_src = x->data; b->act_K = K; b->act_T = T; b->act_mode = mode; b->act_nb1 = (int64_t) x->nb[1];
@@ -890,6 +891,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             if (rc != MI355X_E_UNSUPPORTED) return rc;
         }
     }
+    if (reads_elided()) return (int) hipErrorInvalidValue;                // the generic kernel reads x->data
     return mi355x_mul_mat(b->k, &mw, &mx, &md, has_ep ? &c.ep : nullptr);
 }
 
