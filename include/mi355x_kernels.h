@@ -387,6 +387,17 @@ MI355X_API int mi355x_concat(mi355x_ctx * ctx, const mi355x_tensor * a, const mi
  * computed on the host; exposed so that tests can compare it with the reference's table without a GPU */
 MI355X_API void mi355x_gelu_table_host(uint16_t * out65536);
 
+/* TEST hook: kernel-shape variants that a test compares with the default inside one process (tests/test_gpu_mmq.py, tests/test_gpu_encoder.py).
+ * Production never calls it; unset options take the built-in default.  set = 0 returns an option to its default. */
+enum mi355x_test_opt {
+    MI355X_OPT_MMQ_GROUP = 0,      /* 0: the int8 tile GEMM's products leave as single launches instead of grouped ones */
+    MI355X_OPT_MMQ_SCALE_MFMA,     /* 0: scale products dw * dx on the VALU instead of the rank-1 f16 MFMA */
+    MI355X_OPT_MMQ_TILE,           /* 12864: 128 x 64 tiles instead of 64 x 128 */
+    MI355X_OPT_FATTN_NG,           /* 1..4: key groups per workgroup of the MFMA attention kernel instead of the n_kv-dependent choice */
+    MI355X_OPT_COUNT
+};
+MI355X_API void mi355x_test_option(int opt, int value, int set);
+
 /* debug: with GGML_MI355X_KTIME=1 the decode mat-vec stamps s_memtime at its phase boundaries (workgroup 0, wave 0);
  * copies the 16 stamps of the last launch to the host.  MI355X_E_UNSUPPORTED when the mode is off. */
 MI355X_API int mi355x_debug_read_stamps(mi355x_ctx * ctx, unsigned long long * out16);

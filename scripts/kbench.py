@@ -4,9 +4,7 @@ large-v3 layer, each launched `--iters` times back to back on the library's stre
 `rocprofv3 --kernel-trace -f csv` (scripts/summarize_trace.py then reports per-(kernel, grid) durations); it also prints
 the hipEvent-bracketed per-launch averages measured by the library's own profiler.
 
-  python scripts/kbench.py [--qtype q5_0] [--iters 50] [--T 1]
-Tuning knobs are environment variables read by the library (GGML_MI355X_GEMV_WPB, GGML_MI355X_GEMV_XFIRST,
-GGML_MI355X_GEMV_V1, GGML_MI355X_FATTN_V1)."""
+  python scripts/kbench.py [--qtype q5_0] [--iters 50] [--T 1]"""
 import argparse
 import ctypes as C
 import json

@@ -2,7 +2,7 @@
 """Concurrent streams on ONE MI355X through the native harness (include/mi355x_host.h): chunks/s per stream count, with the plugin's
 cross-state batching off and / or on.
    usage: scripts/stream_scaling.py [--arch large-v3] [--qtype q5_0] [--streams 1,2,4,8] [--batching 0,1] [--n-decode 256] [--steps 2]
-   env:   GPU_MAX_HW_QUEUES (8), GGML_MI355X_XCD_STREAMS=1 (one XCD-masked HIP stream per state)"""
+   env:   GPU_MAX_HW_QUEUES (8), GGML_MI355X_BATCH_COLS (fixed chain width), GGML_MI355X_MX_MIN_T (0: mat-vecs of wide chains off the matrix cores)"""
 import argparse
 import json
 import os
@@ -36,4 +36,4 @@ for batching in [int(x) for x in a.batching.split(",")]:
                      "batch_stats": r["batch_stats"], "rc": r["rc"], "error": r["error"]})
         print(json.dumps(rows[-1]), flush=True)
 print(json.dumps({"arch": a.arch, "qtype": a.qtype, "n_decode": a.n_decode, "hw_queues": os.environ["GPU_MAX_HW_QUEUES"],
-                  "xcd_streams": os.environ.get("GGML_MI355X_XCD_STREAMS", "0"), "xcd_mask_layout": os.environ.get("GGML_MI355X_XCD_MASK_LAYOUT", "0"), "rows": rows}))
+                  "batch_cols": os.environ.get("GGML_MI355X_BATCH_COLS", "default"), "mx_min_t": os.environ.get("GGML_MI355X_MX_MIN_T", "default"), "rows": rows}))

@@ -34,26 +34,6 @@ def gpu():
     ctx.close()
 
 
-class env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        for k, v in self.kv.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = str(v)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def dev(torch, a):
     t = torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
     torch.cuda.synchronize()
@@ -181,10 +161,15 @@ def test_mmq_tile_shapes_and_scale_forms_are_bit_identical(gpu, oracle, t, K, N,
     x = rng.standard_normal((T, K)).astype(np.float32)
     _, planar = quantize(oracle, ka, tid, wf)
     got = {}
-    for name, kv in {"default": {}, "128x64": dict(GGML_MI355X_MMQ_TILE=12864), "valu-scales": dict(GGML_MI355X_MMQ_SCALE_MFMA=0),
-                     "single launches": dict(GGML_MI355X_MMQ_GROUP=0)}.items():
-        with env(**kv):
+    # (kernel library test options, include/mi355x_kernels.h: 0 MMQ_GROUP, 1 MMQ_SCALE_MFMA, 2 MMQ_TILE)
+    for name, (which, value) in {"default": (None, 0), "128x64": (2, 12864), "valu-scales": (1, 0), "single launches": (0, 0)}.items():
+        if which is not None:
+            ka.lib().mi355x_test_option(which, value, 1)
+        try:
             got[name], _ = run_mmq(gpu, tid, planar, x, K, N, T)
+        finally:
+            if which is not None:
+                ka.lib().mi355x_test_option(which, 0, 0)
     for name in got:
         assert np.array_equal(got["default"].view(np.uint32), got[name].view(np.uint32)), name
 
@@ -209,7 +194,8 @@ def test_grouped_mmq_launch_is_bit_identical_to_single_launches(gpu, oracle, t):
     for grouped in (1, 0):
         ys = [torch.full((T, N), 5.0, dtype=torch.float16 if i == 1 else torch.float32, device="cuda:0") for i in range(3)]
         torch.cuda.synchronize()
-        with env(GGML_MI355X_MMQ_GROUP=grouped):
+        ka.lib().mi355x_test_option(0, grouped, 1)            # MI355X_OPT_MMQ_GROUP
+        try:
             ctx.prof(True); ctx.prof_reset()
             for i in range(3):
                 ep = ka.Epilogue(bias=biases[i].data_ptr())
@@ -217,6 +203,8 @@ def test_grouped_mmq_launch_is_bit_identical_to_single_launches(gpu, oracle, t):
                 ctx.check(ka.lib().mi355x_gemm_q8act(ctx.h, C.byref(tw), r_d.data_ptr(), T, ys[i].data_ptr(), N * (2 if i == 1 else 4), ka.F16 if i == 1 else ka.F32, C.byref(ep)), "gemm_q8act")
             ctx.sync()
             rows = ctx.prof_report(); ctx.prof(False)
+        finally:
+            ka.lib().mi355x_test_option(0, 0, 0)
         launches = sum(r["calls"] for r in rows if "mmq" in r["name"])
         assert launches == (1 if grouped else 3), rows
         out[grouped] = [y.cpu().numpy() for y in ys]

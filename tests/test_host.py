@@ -207,7 +207,7 @@ def test_no_kernel_spills_to_scratch():
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "kernel_resources.py"), "--json"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     ks = json.loads(r.stdout)
-    assert len(ks) > 300
+    assert len(ks) > 250
     spilled = [k["demangled"] for k in ks if k.get("private_segment_fixed_size", 0) > 0]
     assert not spilled, spilled[:10]
     by = {k["demangled"]: k for k in ks}
@@ -231,8 +231,9 @@ def test_ring_gemm_loop_never_drains_the_dma_queue(tmp_path):
                         f"-I{src.parent}", str(src), "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     text = out.read_text()
+    # (the shapes the product launches since the r05 clean-up: 64 x 4 stages and 128 x 2 for single products, 64 x 2 for grouped ones)
     for fn, counted in (("_Z15k_gemm_f16_ringILi64ELi4ELi128EEv8GemmArgs", "vmcnt(12)"), ("_Z15k_gemm_f16_ringILi128ELi2ELi128EEv8GemmArgs", None),
-                        ("_Z21k_gemm_f16_ring_groupILi64ELi4ELi128EEv13GemmGroupArgs", "vmcnt(12)"), ("_Z21k_gemm_f16_ring_groupILi128ELi2ELi128EEv13GemmGroupArgs", None)):
+                        ("_Z21k_gemm_f16_ring_groupILi64ELi2ELi128EEv13GemmGroupArgs", None)):
         body = text[text.index(fn + ":"):]
         body = body[:body.index("s_endpgm")]
         assert body.count("global_load_lds_dwordx4") >= 12, fn

@@ -155,16 +155,14 @@ static mi_io_ctx * mi_io(int device) {          // caller holds no lock; device 
     std::lock_guard<std::mutex> lk(io.mtx);
     if (!io.tried) {
         io.tried = true;
-        static const bool enabled = env_flag("GGML_MI355X_ASYNC_IO", true);
         io.cap = (size_t) 4 << 20;
-        if (enabled && hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking) == hipSuccess &&
+        if (hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&io.ev, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&io.ev_flush, hipEventDisableTiming) == hipSuccess &&
             hipHostMalloc((void **) &io.pinned, io.cap, hipHostMallocDefault) == hipSuccess) {
             io.ok = true;
             void * dp = nullptr;
-            static const bool defer = env_flag("GGML_MI355X_DEFER_IO", true);
-            if (defer && hipHostGetDevicePointer(&dp, io.pinned, 0) == hipSuccess) io.pinned_dev = (char *) dp;
+            if (hipHostGetDevicePointer(&dp, io.pinned, 0) == hipSuccess) io.pinned_dev = (char *) dp;
             else (void) hipGetLastError();
         }
     }
@@ -218,10 +216,6 @@ static bool mi_io_upload(int device, void * dst, const void * src, size_t size) 
         return true;
     }
     if (hipMemcpyAsync(dst, io->pinned + io->off, size, hipMemcpyHostToDevice, io->stream) != hipSuccess) return false;
-    // first upload since the last compute: wake the chip now, while the host still has its per-step work ahead
-    // (measured: no effect on the ~30 us stall before the first chip-wide dispatch of a step; off unless GGML_MI355X_WAKE=n)
-    static const int wake = getenv("GGML_MI355X_WAKE") ? atoi(getenv("GGML_MI355X_WAKE")) : 0;
-    if (wake > 0 && io->seq.load() == io->wake_seq) (void) mi355x_wake((void *) io->stream, wake);
     io->off += need;
     (void) hipEventRecord(io->ev, io->stream);
     io->seq++; io->copy_seq++;
@@ -322,16 +316,6 @@ static void mi_buffer_get_tensor(ggml_backend_buffer_t buffer, const ggml_tensor
     io_timer tm(1);
     mi_buffer_ctx * ctx = (mi_buffer_ctx *) buffer->context;
     if (!is_quant_type(tensor->type) && mi_mirror_read(ctx->device, (const char *) tensor->data + offset, data, size)) {          // logits: already in host memory
-        static const bool check = env_flag("GGML_MI355X_MIRROR_CHECK", false);       // debugging aid: the mirror against the device copy it shadows
-        if (check) {
-            std::vector<char> devc(size);
-            (void) hipSetDevice(ctx->device);
-            (void) hipDeviceSynchronize();
-            (void) hipMemcpy(devc.data(), (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost);
-            size_t bad = 0, first = 0;
-            for (size_t i = 0; i + 4 <= size; i += 4) if (memcmp(devc.data() + i, (const char *) data + i, 4) != 0) { if (!bad) first = i / 4; bad++; }
-            if (bad) GGML_LOG_ERROR("ggml-mi355x: MIRROR_CHECK: %zu of %zu words of '%s' (offset %zu) differ between the host mirror and the device, first at %zu\n", bad, size / 4, tensor->name, offset, first);
-        }
         return;
     }
     (void) hipSetDevice(ctx->device);
@@ -702,7 +686,7 @@ static int rows_mode_for(const ggml_tensor * w, int64_t K) {
 
 // f16 copy of a quantized weight for the MFMA path (nullptr: not eligible / over budget -> the GEMM dequantizes in its loop)
 static const void * mi_shadow_get(mi_backend_ctx * b, const ggml_tensor * w, const mi355x_tensor & mw) {
-    static const size_t cap_mb = getenv("GGML_MI355X_F16_SHADOW_MB") ? (size_t) atoll(getenv("GGML_MI355X_F16_SHADOW_MB")) : 16384;
+    constexpr size_t cap_mb = 16384;               // f16 copies of quantized weights (GGML_MI355X_MMQ=0 only): at most 16 GB of the 288
     if (cap_mb == 0) return nullptr;
     ggml_backend_buffer_t buf = w->view_src ? w->view_src->buffer : w->buffer;
     if (!buf || !mi_buffer_is_ours(buf) || buf->usage != GGML_BACKEND_BUFFER_USAGE_WEIGHTS) return nullptr;
@@ -811,10 +795,9 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             }
             if (b->act_src == x->data && b->act_mode == rmode) {
                 // fc1 + GELU -> fc2: the epilogue writes the next product's rows (second scratch), and the F32 result only if somebody reads it
-                static const bool prep_out_on = env_flag("GGML_MI355X_GEMM_PREP_OUT", true);
                 const int64_t M = mm->ne[0];
                 int rc = MI355X_E_UNSUPPORTED;
-                if (g && b->fuse && prep_out_on && c.last->type == GGML_TYPE_F32 && M % 128 == 0 && M <= 8192 &&
+                if (g && b->fuse && c.last->type == GGML_TYPE_F32 && M % 128 == 0 && M <= 8192 &&
                     c.last->nb[0] == 4 && (int64_t) c.last->nb[1] == M*4 && c.last->ne[1] == T && c.last->ne[2] == 1 && c.last->ne[3] == 1) {
                     const int j = next_real(g, c.end);
                     int mode2 = -1;
@@ -851,10 +834,9 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             // Is the result itself the activation matrix of the next node's MFMA GEMM (fc1 + GELU -> fc2)?  Then the epilogue writes
             // that GEMM's prepared f16 activations (second scratch; this product still reads the first), and when nothing else reads
             // the F32 result it is not stored at all: one launch, a 30 MB write and a 30 MB read less per encoder layer of large-v3.
-            static const bool prep_out_on = env_flag("GGML_MI355X_GEMM_PREP_OUT", true);
             void * prep_out = nullptr; bool prep_only = false;
             const int64_t M = mm->ne[0];
-            if (g && b->fuse && prep_out_on && act == b->act && c.last->type == GGML_TYPE_F32 && M % 32 == 0 && M <= 8192 &&
+            if (g && b->fuse && act == b->act && c.last->type == GGML_TYPE_F32 && M % 32 == 0 && M <= 8192 &&
                 c.last->nb[0] == 4 && (int64_t) c.last->nb[1] == M*4 && c.last->ne[1] == T && c.last->ne[2] == 1 && c.last->ne[3] == 1) {
                 const int j = next_real(g, c.end);
                 int mode2 = -1;
@@ -877,7 +859,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                 return mi355x_gemm_f16act(b->k, &wt, act, ld, T, md.data, md.nb[1], md.type, has_ep ? &c.ep : nullptr);
             };
             // wide activations: run the GEMM on the weight's f16 copy (same values, no dequantization in the loop)
-            static const int shadow_min_t = getenv("GGML_MI355X_F16_SHADOW_MIN_T") ? atoi(getenv("GGML_MI355X_F16_SHADOW_MIN_T")) : 128;
+            constexpr int shadow_min_t = 128;
             if (mode != 0 && T >= shadow_min_t) {
                 if (const void * f16 = mi_shadow_get(b, w, mw)) {
                     mi355x_tensor ms = mw;
@@ -927,7 +909,7 @@ static int run_ln_chain(mi_backend_ctx * b, const ln_chain & c, const ggml_cgrap
     mi355x_tensor mx = to_mt(c.norm->src[0]), md = to_mt(c.last);
     // encoder / prompt: the next node is an MFMA GEMM on this LayerNorm's result -> write its prepared f16 activations in the same
     // pass (one launch and one read of the 7.7 MB result less per LayerNorm; bit-identical to mi355x_prep_act on the result)
-    static const bool fuse_prep = env_flag("GGML_MI355X_LN_PREP", true);
+    constexpr bool fuse_prep = true;
     int mode = 0;
     const int j = g ? next_real(g, c.end) : 0;
     if (g && b->fuse && fuse_prep && j < g->n_nodes && mm_takes_prepared(b, g->nodes[j], c.last, mode)) {
@@ -1403,13 +1385,12 @@ static bool q_attn_proj(mi355x_ctx * k, const mi_colset & cs, mi_qstate & qs, in
         }
         max_kv = std::max(max_kv, (int) st[c].n_kv);
     }
-    // ONE launch from q / K / V to the projection's activation planes for self-attention (<= 512 keys).  GGML_MI355X_ATTN_PLANES_MAX_KV=1536
-    // sends cross-attention's 1500 keys the same way (three rounds in one 16-wave workgroup per (head, column)): no gain — 13.5 us against
-    // 6.5 + 6.7 for partial records + combine, 8 streams 9.53 against 9.75 chunks/s (same profile file) — so the default stays 512.
-    static const bool self_planes = env_flag("GGML_MI355X_SELF_ATTN_PLANES", true);
-    static const int planes_max_kv = getenv("GGML_MI355X_ATTN_PLANES_MAX_KV") ? atoi(getenv("GGML_MI355X_ATTN_PLANES_MAX_KV")) : 512;
+    // ONE launch from q / K / V to the projection's activation planes for self-attention (<= 512 keys).  Cross-attention's 1500 keys the same
+    // way (three rounds in one 16-wave workgroup per (head, column)) lost twice — r03: 13.5 us against 6.5 + 6.7 for partial records + combine;
+    // r05 with the matrix-core mat-vecs: 16 / 32 streams 14.8 / 18.5 chunks/s against 15.7 / 21.9 (profiles/r05_stream_scaling.txt)
+    constexpr int planes_max_kv = 512;
     bool have_planes = false;
-    if (self_planes && max_kv <= planes_max_kv && w->type != GGML_TYPE_Q4_K && (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2))) {
+    if (max_kv <= planes_max_kv && w->type != GGML_TYPE_Q4_K && (!m || (m->type == GGML_TYPE_F16 && m->nb[0] == 2))) {
         rc = mi355x_flash_attn_planes(k, cs.T, st, &mq, &mk, &mv, scale, p0);
         if (rc == 0) have_planes = true;
         else if (rc != MI355X_E_UNSUPPORTED) { rc_out = rc; return true; }
@@ -1569,7 +1550,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         int rc = MI355X_E_UNSUPPORTED;
         // decoder steps with planes_min_t .. 8 columns (beam search): the pre-quantized-activation pipeline (stages above); whatever it
         // does not take falls through to the fused / generic paths below
-        static const int planes_min_t = getenv("GGML_MI355X_PLANES_MIN_T") ? atoi(getenv("GGML_MI355X_PLANES_MIN_T")) : 3;
+        constexpr int planes_min_t = 3;
         if (b->fuse && !b->exact && (n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_NORM || n->op == GGML_OP_FLASH_ATTN_EXT)) {
             const int64_t Tn = n->op == GGML_OP_FLASH_ATTN_EXT ? n->src[0]->ne[1] : (n->op == GGML_OP_MUL_MAT ? n->src[1]->ne[1] : ggml_nrows(n->src[0]));
             if (Tn >= planes_min_t && Tn <= MI355X_IMG_COLS) {
@@ -1629,7 +1610,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
         } else if (n->op == GGML_OP_FLASH_ATTN_EXT && b->fuse && n->src[0]->ne[1] > 8) {
             // encoder / prompt attention whose result (through a reshape) is the activation matrix of the output projection: the
             // attention kernel leaves that GEMM's prepared f16 activations as well (one launch and one pass over the result less)
-            static const bool on = env_flag("GGML_MI355X_FATTN_PREP_OUT", true);
+            constexpr bool on = true;
             const int j = next_real(g, i);
             const int64_t T = n->src[0]->ne[1], NS = n->ne[0] * n->ne[1];
             int mode = -1;
@@ -1718,7 +1699,7 @@ static ggml_status mi_compute_own(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     b->own_dirty = true;
     mi_io_order_stream(b->device, b->io, cs);
     // GPU span bookkeeping (two event records per call)
-    static const bool span_on = env_flag("GGML_MI355X_SPAN", true);
+    constexpr bool span_on = true;
     int span_idx = -1;
     if (span_on && !b->prof) {
         if (b->span_ev.empty()) {
@@ -1776,7 +1757,7 @@ static bool mi_batching_on() {
 // measured large-v3 Q5_0: 2 / 4 states 3.35 / 5.96 chunks/s merged against 4.1 / 7.5 on their own streams, 8 states 9.75 against 2.8
 // (profiles/r03_stream_scaling_*).  ggml_backend_mi355x_set_batching(n >= 2) / GGML_MI355X_BATCH=n sets the threshold to n.
 static int mi_batch_min_states() {
-    static const int env_min = getenv("GGML_MI355X_BATCH_MIN_STREAMS") ? std::max(2, atoi(getenv("GGML_MI355X_BATCH_MIN_STREAMS"))) : 5;
+    constexpr int env_min = 5;
     const int v = g_batching.load();
     return v >= 2 ? v : env_min;
 }
@@ -1897,7 +1878,9 @@ static bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi
 }
 
 static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
-    static const double window_ms = getenv("GGML_MI355X_BATCH_WINDOW_US") ? atof(getenv("GGML_MI355X_BATCH_WINDOW_US")) * 1e-3 : 3.0;
+    // (the window must stay above a chain step: 1 ms / 0.4 ms collapse to 2.4 / 2.0 chunks/s at 16 streams — states are dropped while they are simply on
+    //  their way through the host part of a step; profiles/r05_stream_scaling.txt)
+    constexpr double window_ms = 3.0;
     // columns per merged chain.  GGML_MI355X_BATCH_COLS=n (2..32) fixes it; by default 60 % of the decoding states (at least 4) ride one chain and
     // the rest a second one next to it (MI_BATCH_LANES streams): two chains of unequal width fill each other's launch gaps.  Measured on large-v3
     // Q5_0 (profiles/r04_stream_scaling.txt, r04_chain_split_sweep.txt): 16 states as 10 + 6: 14.2 chunks/s, 12 + 4: 13.9, 8 + 8: 11.5-12.5, one
@@ -1909,9 +1892,7 @@ static ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
     std::unique_lock<std::mutex> lk(grp.m);
     if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
-    // (A-B switches of that rule: GGML_MI355X_BATCH_SPLIT_PCT = the share of the decoding states a chain may carry, _SPLIT_MIN = its floor)
-    static const int split_pct = getenv("GGML_MI355X_BATCH_SPLIT_PCT") ? std::max(10, std::min(100, atoi(getenv("GGML_MI355X_BATCH_SPLIT_PCT")))) : 60;
-    static const int split_min = getenv("GGML_MI355X_BATCH_SPLIT_MIN") ? std::max(1, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_SPLIT_MIN")))) : 4;
+    constexpr int split_pct = 60, split_min = 4;
     auto cols_cap = [&]() {
         if (env_cols) return env_cols;
         return std::min(MI355X_MAX_COLS, std::max(split_min, (split_pct * (int) grp.members.size() + 99) / 100));

@@ -46,7 +46,6 @@ struct mi355x_ctx {
     std::vector<pending>                 ev_pending;
     std::map<std::string, prof_acc>      prof_rows;
     int                                  n_cu = 256;
-    int                                  cu_mask_xcd = -1;       // >= 0: the stream is confined to this XCD (GGML_MI355X_XCD_STREAMS)
     void *                               dbg_stamps = nullptr;   // 16 x u64 (device), GGML_MI355X_KTIME=1 only
     // launches held back so that independent neighbours can go out as ONE grouped launch (gemm_mfma.hip: the Q / K / V projections
     // of an encoder layer, the cross-attention K / V projections of consecutive layers).  Anything else that is emitted, and every
@@ -58,6 +57,7 @@ struct mi355x_ctx {
 };
 static inline int mi355x_flush_pending(mi355x_ctx * ctx) { return (ctx->pending_n > 0 && !ctx->in_flush && ctx->pending_flush) ? ctx->pending_flush(ctx) : 0; }
 void * mi355x_debug_stamps(mi355x_ctx * ctx);
+int    mi355x_opt(int opt, int def);          // value of a test option (mi355x_test_option), `def` when unset
 
 void   mi355x_set_error(const char * fmt, ...);
 #define HIP_CHECK_RET(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { mi355x_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return (int) e_; } } while (0)

@@ -60,22 +60,8 @@ extern "C" mi355x_ctx * mi355x_ctx_create(int device) {
     ctx->device = device;
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) ctx->n_cu = p.multiProcessorCount;
-    // GGML_MI355X_XCD_STREAMS=1 (experiment): the n-th context of a device gets a stream whose CU mask is ONE XCD
-    // (n mod 8), so that up to eight concurrent decode streams each own an XCD (own L2, no interleaving of their dependent launch
-    // chains on shared CUs).  Mask layout: GGML_MI355X_XCD_MASK_LAYOUT=0 bit (8k + x) = k-th CU of XCD x (default, what the
-    // driver's symmetric mapping implies), 1 = bits [32x, 32x + 32); scripts/probes/cumask_probe.hip measures which one is right.
-    static const int xcd_streams = getenv("GGML_MI355X_XCD_STREAMS") ? atoi(getenv("GGML_MI355X_XCD_STREAMS")) : 0;
-    bool have_stream = false;
-    if (xcd_streams > 0) {
-        static std::atomic<int> next_xcd[64];
-        static const int layout = getenv("GGML_MI355X_XCD_MASK_LAYOUT") ? atoi(getenv("GGML_MI355X_XCD_MASK_LAYOUT")) : 0;
-        const int x = next_xcd[device & 63].fetch_add(1) % 8, per = ctx->n_cu / 8, nwords = (ctx->n_cu + 31) / 32;
-        uint32_t mask[16] = { 0 };
-        for (int i = 0; i < per && nwords <= 16; i++) { const int bit = layout == 0 ? x + 8 * i : x * per + i; mask[bit >> 5] |= 1u << (bit & 31); }
-        if (hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t) nwords, mask) == hipSuccess) { have_stream = true; ctx->cu_mask_xcd = x; }
-        else (void) hipGetLastError();
-    }
-    if (!have_stream && hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    // (one XCD-masked stream per state — hipExtStreamCreateWithCUMask — was measured in round 3 and lost: HISTORY.md)
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
     std::vector<uint16_t> tab(65536);
     mi355x_gelu_table_host(tab.data());
     if (hipMalloc((void **) &ctx->gelu_tab, 65536*2) != hipSuccess ||
@@ -136,6 +122,15 @@ static void prof_drain(mi355x_ctx * ctx) {
     ctx->ev_pending.clear();
 }
 
+// ---- test options (mi355x_kernels.h: mi355x_test_option): kernel-shape variants a test compares with the default inside one process ----
+static std::atomic<int> g_test_opt[MI355X_OPT_COUNT];
+static std::atomic<bool> g_test_opt_set[MI355X_OPT_COUNT];
+extern "C" void mi355x_test_option(int opt, int value, int set) {
+    if (opt < 0 || opt >= MI355X_OPT_COUNT) return;
+    g_test_opt[opt].store(value); g_test_opt_set[opt].store(set != 0);
+}
+int mi355x_opt(int opt, int def) { return g_test_opt_set[opt].load(std::memory_order_relaxed) ? g_test_opt[opt].load(std::memory_order_relaxed) : def; }
+
 extern "C" int mi355x_flush(mi355x_ctx * ctx) { return mi355x_flush_pending(ctx); }
 extern "C" int mi355x_last_launch_mirrored(mi355x_ctx * ctx) { const int r = ctx->last_mirrored; ctx->last_mirrored = 0; return r; }
 
@@ -143,18 +138,6 @@ extern "C" int mi355x_last_launch_mirrored(mi355x_ctx * ctx) { const int r = ctx
 extern "C" int mi355x_ctx_synchronize(mi355x_ctx * ctx) {
     (void) hipSetDevice(ctx->device);
     { const int rc = mi355x_flush_pending(ctx); if (rc) return rc; }
-    // optional (GGML_MI355X_SYNC_SPIN_US=n): poll the stream for up to n microseconds before the blocking wait.  Measured on
-    // the decode loop: no gain over hipStreamSynchronize (which already spins), so it is off by default.
-    static const int spin_us = getenv("GGML_MI355X_SYNC_SPIN_US") ? atoi(getenv("GGML_MI355X_SYNC_SPIN_US")) : 0;
-    if (spin_us > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            const hipError_t q = hipStreamQuery(ctx->stream);
-            if (q == hipSuccess) { if (ctx->prof) prof_drain(ctx); return 0; }
-            if (q != hipErrorNotReady) break;
-            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
-        }
-    }
     HIP_OK(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) prof_drain(ctx);
     return 0;

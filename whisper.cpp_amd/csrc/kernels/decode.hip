@@ -399,8 +399,6 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
 
     // ---- the load burst -------------------------------------------------------------------------------------------
     float4 xr[T][XS];
-    constexpr int XW = 8;                                                // MODE 3: float4 slots per lane covering K <= 2048
-    float4 xw[MODE == 3 ? T : 1][MODE == 3 ? XW : 1];
     constexpr bool PBURST = MODE == 2 && T <= 2;                         // record bursts cost 72 registers per column
     float2 pml[PBURST ? MAXP : 1];
     float4 pov[PBURST ? MAXP : 1];
@@ -416,18 +414,6 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
             pml[p] = *(const float2 *) (a.part_ml + (base + pc)*2);
             pov[p] = *(const float4 *) (a.part_o + (base + pc)*64 + pd);
         }
-    } else if constexpr (MODE == 3) {
-        // wave-local LayerNorm: every wave holds the whole vector (slot i = elements [64i, 64i+64) float4s), so the
-        // statistics need no LDS round trip and no workgroup barrier
-        #pragma unroll
-        for (int t = 0; t < T; t++) {
-            const char * xp = (const char *) a.x + (int64_t) t*a.x_nb1;
-            #pragma unroll
-            for (int i = 0; i < XW; i++) {
-                const int e4 = lane + 64*i;
-                xw[t][i] = *(const float4 *) (xp + (size_t) (e4 < K4 ? e4 : K4 - 1)*16);
-            }
-        }
     } else {
         #pragma unroll
         for (int t = 0; t < T; t++) {
@@ -440,8 +426,8 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);          // pin the issue order: the scheduler otherwise sinks / reorders these loads
-    float4 lw[(MODE == 1 || MODE == 3) ? XS : 1], lb[(MODE == 1 || MODE == 3) ? XS : 1];
-    if constexpr (MODE == 1 || MODE == 3) {
+    float4 lw[MODE == 1 ? XS : 1], lb[MODE == 1 ? XS : 1];
+    if constexpr (MODE == 1) {
         #pragma unroll
         for (int i = 0; i < XS; i++) {
             const int e4 = tid + i*nthreads, e4c = e4 < K4 ? e4 : K4 - 1;
@@ -569,40 +555,7 @@ __global__ void __launch_bounds__(512) k_gemv_row(const DGArgs a) {
             }
         }
     }
-    if constexpr (MODE == 3) {
-        // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine; statistics per wave (identical in every wave: same order)
-        #pragma unroll
-        for (int t = 0; t < T; t++) {
-            float p = 0.0f;
-            #pragma unroll
-            for (int i = 0; i < XW; i++) if (lane + 64*i < K4) p += (xw[t][i].x + xw[t][i].y) + (xw[t][i].z + xw[t][i].w);
-            const float mean = wave_sum(p) / K;
-            float q = 0.0f;
-            #pragma unroll
-            for (int i = 0; i < XW; i++) {
-                if (lane + 64*i < K4) {
-                    const float d0 = xw[t][i].x - mean, d1 = xw[t][i].y - mean, d2 = xw[t][i].z - mean, d3 = xw[t][i].w - mean;
-                    q += (d0*d0 + d1*d1) + (d2*d2 + d3*d3);
-                }
-            }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / K + a.eps);
-            // this wave quantizes slot `wave` (element tid): value select, no dynamic register indexing
-            float4 sel = xw[t][0];
-            #pragma unroll
-            for (int i = 1; i < XW; i++) {
-                const bool m = wave == i;
-                sel.x = m ? xw[t][i].x : sel.x; sel.y = m ? xw[t][i].y : sel.y; sel.z = m ? xw[t][i].z : sel.z; sel.w = m ? xw[t][i].w : sel.w;
-            }
-            if (tid < K4) {
-                const float4 w = lw[0], b = lb[0];
-                float o[4] = { (sel.x - mean) * rstd, (sel.y - mean) * rstd, (sel.z - mean) * rstd, (sel.w - mean) * rstd };
-                o[0] = o[0]*w.x; o[1] = o[1]*w.y; o[2] = o[2]*w.z; o[3] = o[3]*w.w;
-                o[0] = o[0]+b.x; o[1] = o[1]+b.y; o[2] = o[2]+b.z; o[3] = o[3]+b.w;
-                act_store(o, tid*4, t);
-            }
-        }
-        DG_STAMP(2);
-    } else if constexpr (MODE == 1) {
+    if constexpr (MODE == 1) {
         // ggml_norm (ggml-cpu/ops.cpp:3698-3765) + affine, two passes over the registers
         float mean[T], rstd[T];
         #pragma unroll
@@ -777,36 +730,25 @@ static int launch_gemv_row_m(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 gri
         return MI355X_E_UNSUPPORTED;
     }
     const dim3 block(64 * gemv_row_waves(k.K));
-    if constexpr (MODE == 3) {              // wave-local LayerNorm: whole vector in every wave's registers, T <= 2
-        if (T == 1) return emit(ctx, name, k_gemv_row<WT, 1, 1, 3, NSEG1>, grid, block, lds, k, bytes, flops);
-        if (T == 2) return emit(ctx, name, k_gemv_row<WT, 2, 1, 3, NSEG1>, grid, block, lds, k, bytes, flops);
-        return MI355X_E_UNSUPPORTED;
-    } else {
-        switch (T) {
-            case 1: return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            case 2: return emit(ctx, name, k_gemv_row<WT, 2, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            case 5: return emit(ctx, name, k_gemv_row<WT, 5, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            case 6: return emit(ctx, name, k_gemv_row<WT, 6, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            case 7: return emit(ctx, name, k_gemv_row<WT, 7, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            case 8: return emit(ctx, name, k_gemv_row<WT, 8, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
-            default: return MI355X_E_UNSUPPORTED;
-        }
+    switch (T) {
+        case 1: return emit(ctx, name, k_gemv_row<WT, 1, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        case 2: return emit(ctx, name, k_gemv_row<WT, 2, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        case 3: return emit(ctx, name, k_gemv_row<WT, 3, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        case 4: return emit(ctx, name, k_gemv_row<WT, 4, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        case 5: return emit(ctx, name, k_gemv_row<WT, 5, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        case 6: return emit(ctx, name, k_gemv_row<WT, 6, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        case 7: return emit(ctx, name, k_gemv_row<WT, 7, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        case 8: return emit(ctx, name, k_gemv_row<WT, 8, 1, MODE, NSEG1>, grid, block, lds, k, bytes, flops);
+        default: return MI355X_E_UNSUPPORTED;
     }
 }
 template <int WT>
 static int launch_gemv_row(mi355x_ctx * ctx, const DGArgs & k, int T, dim3 grid, uint32_t lds, double bytes, double flops, int R = 1) {
-    // wave-local LayerNorm (MODE 3) measured no faster than the workgroup version and slower for N >= 3840 (every one of
-    // ~15 waves per CU repeats the statistics): off unless GGML_MI355X_GEMV_WAVE_LN=1
-    static const bool wave_ln = getenv("GGML_MI355X_GEMV_WAVE_LN") && atoi(getenv("GGML_MI355X_GEMV_WAVE_LN"));
     if (k.x == nullptr) {
         if (k.nparts > 12 || k.nseg != 1) return MI355X_E_UNSUPPORTED;   // records of one column are held in registers, 12 at most
         return launch_gemv_row_m<WT, 2, true>(ctx, k, T, grid, lds, bytes, flops, R);
     }
     if (k.has_norm) {
-        if (wave_ln && k.K <= 2048 && T <= 2)
-            return k.nseg == 1 ? launch_gemv_row_m<WT, 3, true>(ctx, k, T, grid, lds, bytes, flops) : launch_gemv_row_m<WT, 3, false>(ctx, k, T, grid, lds, bytes, flops);
         return k.nseg == 1 ? launch_gemv_row_m<WT, 1, true>(ctx, k, T, grid, lds, bytes, flops, R) : launch_gemv_row_m<WT, 1, false>(ctx, k, T, grid, lds, bytes, flops, R);
     }
     if (k.nseg != 1) return MI355X_E_UNSUPPORTED;                        // several segments without LayerNorm: generic kernel
@@ -863,23 +805,18 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     k.ntot = ntot;
     const double bytes0 = wbytes + (double) K*T*4 + (double) ntot*T*4;
     const double flops0 = 2.0 * ntot * K * T;
-    static const int env_lean = getenv("GGML_MI355X_GEMV_LEAN") ? atoi(getenv("GGML_MI355X_GEMV_LEAN")) : 1;
-    if (env_lean && !from_q && !want_mirror && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
+    if (!from_q && !want_mirror && ntot <= 8192 && K <= (T == 1 ? 5120 : 2048)) {
         const int rpw = gemv_row_waves(K);
         // 512-byte reduction header + activation planes (+ one float4 per thread and column when the attention combine
         // of T > 2 columns is staged through LDS)
         const size_t lds_row = 512 + dg_act_bytes(wt, K, T) + ((from_part && T > 2) ? (size_t) T * 64 * rpw * 16 + 16 : 0);
         // rows per wave: 4 once the activation re-reads outweigh the weights (T >= 3), if every segment is a multiple of 4 rows
-        static const int env_r = getenv("GGML_MI355X_GEMV_ROWS") ? atoi(getenv("GGML_MI355X_GEMV_ROWS")) : 4;
         // (measured at T = 5, large-v3: LN+FC1 11.3 -> 10.0 us, LN+QKV 12.5 -> 10.5 us; the 1280-row O-projection with its
         // attention-combine prologue gets SLOWER on 64 workgroups, 12.1 -> 16.4 us, so it keeps one row per wave)
         // Also at T = 1 / 2 for the wide mat-vecs (LN + Q/K/V, LN + fc1): fewer, fatter workgroups stage the activation fewer times
-        // (round-3 A-B, large-v3 Q5_0: 1.391 -> 1.330 ms/token, profiles/r03_ab_gemv_rows_min_t.txt; GGML_MI355X_GEMV_ROWS_MIN_T=3 is round 2)
-        static const int env_r_min_t = getenv("GGML_MI355X_GEMV_ROWS_MIN_T") ? atoi(getenv("GGML_MI355X_GEMV_ROWS_MIN_T")) : 1;
-        int R = (T >= env_r_min_t && K <= 2048 && env_r == 4 && !from_part && ntot / (gemv_row_waves(K) * 4) >= 128) ? 4 : 1;
+        // (round-3 A-B, large-v3 Q5_0: 1.391 -> 1.330 ms/token, profiles/r03_ab_gemv_rows_min_t.txt)
+        int R = (K <= 2048 && !from_part && ntot / (gemv_row_waves(K) * 4) >= 128) ? 4 : 1;
         for (int s = 0; s < d->nseg; s++) if (d->seg[s].N % 4) R = 1;
-        static const bool env_wave_ln = getenv("GGML_MI355X_GEMV_WAVE_LN") && atoi(getenv("GGML_MI355X_GEMV_WAVE_LN"));
-        if (d->has_norm && env_wave_ln) R = 1;
         const int rpb = gemv_row_waves(K) * R;
         const dim3 grid((ntot + rpb - 1) / rpb);
         int rc = MI355X_E_UNSUPPORTED;
@@ -896,29 +833,23 @@ int mi355x_gemv8(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     // geometry: latency-bound regime => as many waves as the matrix allows, up to ~16 per CU: lanes per row LPR such that
     // N * LPR / 64 waves >= 8 per CU (but no more lanes than the row has blocks), 4 waves per workgroup (each workgroup
     // repeats the activation prologue; 256 threads keep it short), several passes per wave only for huge N
-    static const int env_lpr = getenv("GGML_MI355X_GEMV_LPR") ? atoi(getenv("GGML_MI355X_GEMV_LPR")) : 0;
-    static const int env_wpb = getenv("GGML_MI355X_GEMV_WPB") ? atoi(getenv("GGML_MI355X_GEMV_WPB")) : 0;
-    static const int env_xfirst = getenv("GGML_MI355X_GEMV_XFIRST") ? atoi(getenv("GGML_MI355X_GEMV_XFIRST")) : 1;
-    static const int env_wpc = getenv("GGML_MI355X_GEMV_WAVES_PER_CU") ? atoi(getenv("GGML_MI355X_GEMV_WAVES_PER_CU")) : 8;
+    constexpr int env_wpc = 8;
     int lpr = 8;
     while (lpr < 64 && (int64_t) ntot * lpr / 64 < (int64_t) ctx->n_cu * env_wpc) lpr *= 2;
     while (lpr > 8 && lpr / 2 >= K / (wt == MI355X_TYPE_Q4_K ? 64 : 32)) lpr /= 2;
-    if (env_lpr == 8 || env_lpr == 16 || env_lpr == 32 || env_lpr == 64) lpr = env_lpr;
     const int rpw = 64 / lpr;
     const int ngroups = (ntot + rpw - 1) / rpw;
     // row groups per wave: one wave per row group up to 32 waves per CU (the whole matrix requested at once), more only beyond that.
-    // GGML_MI355X_GEMV_PASS_WAVES=n: at most n waves per CU, each walking several row groups with the next group's loads in flight (A-B knob
+    // at most 8 waves per CU, each walking several row groups with the next group's loads in flight (A-B in round 3
     // for the vocabulary projection, 6484 row groups: 32 -> 1 pass, 16 -> 2, 8 -> 4)
     // (measured r03, single stream large-v3 Q5_0: 32 -> 1.3921, 16 -> 1.3888, 8 -> 1.3806 ms/token; profiles/r03_single_stream_mirror_and_logits_passes_ab.txt)
-    static const int env_pw = getenv("GGML_MI355X_GEMV_PASS_WAVES") ? atoi(getenv("GGML_MI355X_GEMV_PASS_WAVES")) : 8;
-    const int pw = env_pw >= 1 && env_pw <= 32 ? env_pw : 32;
+    constexpr int pw = 8;
     int passes = (ngroups + ctx->n_cu*pw - 1) / (ctx->n_cu*pw);
     if (passes < 1) passes = 1; if (passes > 16) passes = 16;
     const int nw = (ngroups + passes - 1) / passes;
-    int wpb = 4;
-    if (env_wpb == 1 || env_wpb == 2 || env_wpb == 4) wpb = env_wpb;
+    constexpr int wpb = 4;
     k.passes = passes;
-    k.xfirst = (!from_part && !from_q && env_xfirst && (int64_t) T * (K/4) <= (int64_t) DG_XR * 64 * wpb) ? 1 : 0;
+    k.xfirst = (!from_part && !from_q && (int64_t) T * (K/4) <= (int64_t) DG_XR * 64 * wpb) ? 1 : 0;
     const int nblocks = (nw + wpb - 1) / wpb;
     const double bytes = wbytes + (double) K*T*4 + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;

@@ -253,7 +253,7 @@ __device__ __forceinline__ void wblk_dot_q4k_rt(const wblk<MI355X_TYPE_Q4_K> & r
 // block of the RESULT per workgroup, whose planes are written as well (single segment).
 // MG: more than one image (T > 8).  MG = false is the single-image kernel: no image loop, no prefetch registers.
 template <int WT, int TMAX, int NU, bool NSEG1, int R, bool POUT, bool MG>
-__global__ void __launch_bounds__(POUT && R == 2 ? 1024 : 512) k_gemv_q(const QGArgs a) {
+__global__ void __launch_bounds__(512) k_gemv_q(const QGArgs a) {
     constexpr bool Q4K = WT == MI355X_TYPE_Q4_K;
     constexpr int CP = (TMAX * (Q4K ? NU*4096*9/8 + 256 : NU*64*40) / 16 + 255) / 256;       // uint4 copy slots per thread (>= 256 threads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -470,7 +470,6 @@ template <int WT, int TMAX, int NU, bool MG>
 static int launch_gemv_q_v(mi355x_ctx * ctx, const QGArgs & k, bool nseg1, bool pout, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     const char * name = "gemv_q";
     if constexpr (NU == 1 && WT != MI355X_TYPE_Q4_K) {
-        if (pout && block.x == 1024) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 2, true, MG>, grid, block, lds, k, bytes, flops);     // 16 waves x 2 rows
         if (pout) return emit(ctx, name, k_gemv_q<WT, TMAX, NU, true, 4, true, MG>, grid, block, lds, k, bytes, flops);                        //  8 waves x 4 rows
     }
     if (pout) return MI355X_E_UNSUPPORTED;
@@ -543,9 +542,8 @@ int mi355x_gemv_q(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const size_t img = (dg_act_bytes(wt, K, T < MI355X_IMG_COLS ? T : MI355X_IMG_COLS) + 15) & ~(size_t) 15;      // one image of <= 8 columns at a time
     const size_t lds = img + 16 + (pout ? (size_t) MI355X_IMG_COLS * 32 * 4 : 0);      // image | dummy word | result tile
     if (lds > 64 * 1024) return MI355X_E_UNSUPPORTED;
-    // the 32 rows of a planes-out workgroup: 8 waves x 4 rows or 16 waves x 2 rows (GGML_MI355X_POUT_ROWS; more waves = more loads in flight per CU)
-    static const int pout_rows = getenv("GGML_MI355X_POUT_ROWS") && atoi(getenv("GGML_MI355X_POUT_ROWS")) == 2 ? 2 : 4;
-    const int prows = pout_rows;
+    // the 32 rows of a planes-out workgroup: 8 waves x 4 rows (16 waves x 2 rows measured no faster)
+    const int prows = 4;
     const int waves = pout ? 32 / prows : gemv_row_waves(K), rpb = pout ? 32 : waves;
     const dim3 grid((ntot + rpb - 1) / rpb), block(64 * waves);
     const double bytes = wbytes + (double) dg_planes_bytes(wt, K, T) + (double) ntot*T*4;
@@ -767,8 +765,7 @@ static int launch_vocab(mi355x_ctx * ctx, const VArgs & k, int U, dim3 grid, uin
 
 // the vocabulary projection: MI355X_E_UNSUPPORTED = not this shape (the caller goes on to k_gemv8)
 int mi355x_vocab(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
-    static const bool on = !getenv("GGML_MI355X_VOCAB_KERNEL") || atoi(getenv("GGML_MI355X_VOCAB_KERNEL")) != 0;
-    if (!on || d->nseg != 1 || d->T < 1 || d->T > MI355X_MAX_COLS || d->attn_part_o) return MI355X_E_UNSUPPORTED;
+    if (d->nseg != 1 || d->T < 1 || d->T > MI355X_MAX_COLS || d->attn_part_o) return MI355X_E_UNSUPPORTED;
     const mi355x_gemv_seg & g = d->seg[0];
     const int wt = g.wtype, K = d->K, T = d->T, N = g.N;
     if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0) return MI355X_E_UNSUPPORTED;
@@ -797,13 +794,8 @@ int mi355x_vocab(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     // 8-wave workgroups, every wave walking 4 row groups with two of them in flight (measured, large-v3 Q5_0, HBM-cold, rocprofv3:
     // 4 groups per wave = 203 workgroups 11.1 us, one workgroup per CU 11.6, 2 groups per wave 12.3, 1 per wave 14.1, 8 per wave 15.2;
     // k_gemv8 17.9; a read-once stream of the same bytes 9.0 — profiles/r03_vocab_kernel.txt).
-    // GGML_MI355X_VOCAB_GROUPS=n: n groups per wave; GGML_MI355X_VOCAB_WGS_PER_CU=m: m workgroups per CU instead.
-    static const int env_gpw = getenv("GGML_MI355X_VOCAB_GROUPS") ? atoi(getenv("GGML_MI355X_VOCAB_GROUPS")) : 4;
-    static const int env_wpc = getenv("GGML_MI355X_VOCAB_WGS_PER_CU") ? atoi(getenv("GGML_MI355X_VOCAB_WGS_PER_CU")) : 0;
     const int ngroups = (N + 7) / 8;
     int nwg = ((ngroups + 3) / 4 + 7) / 8;
-    if (env_gpw >= 1 && env_gpw <= 64) nwg = ((ngroups + env_gpw - 1) / env_gpw + 7) / 8;
-    if (env_wpc >= 1 && env_wpc <= 8) nwg = ctx->n_cu * env_wpc;
     if (nwg > (ngroups + 7) / 8) nwg = (ngroups + 7) / 8;
     const dim3 grid(nwg);
     const double bytes = (double) mi355x_type_row_bytes(wt, K) * N + (double) K*T*4 + (double) N*T*4;

@@ -381,25 +381,21 @@ static int flash_attn_impl(mi355x_ctx * ctx, const mi355x_tensor * q, const mi35
         if (rc != MI355X_E_UNSUPPORTED) return rc;
     }
     const double bytes = kv_bytes * ((T + 127) / 128) + (double) T*H*FA_D*8;
-    // key groups per workgroup (waves per SIMD): 3 from 12 key tiles on, 2 from 4 on (GGML_MI355X_FATTN_NG=1..4 forces one).
+    // key groups per workgroup (waves per SIMD): 3 from 12 key tiles on, 2 from 4 on (test option MI355X_OPT_FATTN_NG = 1..4 forces one).
     // Encoder size, 1500 x 1500 x 20 heads, hipEvent means (profiles/r03b_encoder_kernel_variants.txt): 1 group 40.2 us (r02's kernel: 49),
     // 2 groups 33.6, 3 groups 32.4, 4 groups 33.3
-    const int ng_env = getenv("GGML_MI355X_FATTN_NG") ? atoi(getenv("GGML_MI355X_FATTN_NG")) : 0;
+    const int ng_env = mi355x_opt(MI355X_OPT_FATTN_NG, 0);
     const int ntiles = (n_kv + KT - 1) / KT;
     const bool folded = !mask && scale > 0.0f;                  // the running maximum on raw scores needs a positive scale
     int ng = ng_env >= 1 && ng_env <= 4 ? ng_env : (ntiles >= 12 ? 3 : ntiles >= 4 ? 2 : 1);
     if (ng > ntiles) ng = ntiles;
     if (!folded && ng > 3) ng = 3;                              // the masked form needs 166 VGPRs: three waves per SIMD at most
     const dim3 grid((T + 127) / 128, H);
-    // V through the transposing LDS read (GGML_MI355X_FATTN_TR=0: transposed on the way into LDS, the r02 layout)
-    const bool vtr = !(getenv("GGML_MI355X_FATTN_TR") && !atoi(getenv("GGML_MI355X_FATTN_TR")));
-#define FA_LAUNCH(NG_) (folded ? (vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, true>, grid, dim3(256*NG_), 0, a, bytes, flops) \
-                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, false>, grid, dim3(256*NG_), 0, a, bytes, flops)) \
-                               : (vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, true>,  grid, dim3(256*NG_), 0, a, bytes, flops) \
-                                      : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, false>,  grid, dim3(256*NG_), 0, a, bytes, flops)))
+    // V goes through the transposing LDS read (ds_read_b64_tr_b16); round 2's layout — transposed on the way into LDS — is gone
+#define FA_LAUNCH(NG_) (folded ? emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, false, true>, grid, dim3(256*NG_), 0, a, bytes, flops) \
+                               : emit(ctx, "fattn_mfma", k_fattn_mfma<NG_, true, true>,  grid, dim3(256*NG_), 0, a, bytes, flops))
     switch (ng) {
-        case 4:  return vtr ? emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, true>, grid, dim3(1024), 0, a, bytes, flops)
-                            : emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, false>, grid, dim3(1024), 0, a, bytes, flops);
+        case 4:  return emit(ctx, "fattn_mfma", k_fattn_mfma<4, false, true>, grid, dim3(1024), 0, a, bytes, flops);
         case 3:  return FA_LAUNCH(3);
         case 2:  return FA_LAUNCH(2);
         default: return FA_LAUNCH(1);

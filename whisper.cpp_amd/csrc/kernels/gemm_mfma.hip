@@ -632,8 +632,7 @@ static void ring_tiling(GemmArgs & k, int64_t per) {
     const double a_tile = (double) TM * k.K * 2, b_tile = (double) BN * k.K * 2;
     const double col_major = a_tile * (k.per < k.mt ? k.per : k.mt) + b_tile * ((k.per + k.mt - 1) / k.mt + (k.per % k.mt ? 1 : 0));
     const double row_major = b_tile * (k.per < k.nt ? k.per : k.nt) + a_tile * ((k.per + k.nt - 1) / k.nt + (k.per % k.nt ? 1 : 0));
-    static const int force = getenv("GGML_MI355X_GEMM_XCD_ORDER") ? atoi(getenv("GGML_MI355X_GEMM_XCD_ORDER")) : -1;
-    k.m_major = force >= 0 ? force : (row_major < col_major ? 1 : 0);
+    k.m_major = row_major < col_major ? 1 : 0;
 }
 
 template <typename F>
@@ -723,53 +722,15 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
     if (n == 1) {
         // stages: measured on large-v3 encode — 64-wide tiles (one block per CU): 2 -> 13.0 ms, 3 -> 11.3, 4 -> 10.9, 5/6 no better;
         // 128-wide tiles (FC1, ~2 blocks per CU): 2 stages (64 KB, two blocks co-resident) 10.6-10.8 vs 3 -> 10.9, 4 -> 11.0
-        static const int nst128 = getenv("GGML_MI355X_GEMM_RING_NST128") ? atoi(getenv("GGML_MI355X_GEMM_RING_NST128")) : 2;
-        static const int nst64  = getenv("GGML_MI355X_GEMM_RING_NST64")  ? atoi(getenv("GGML_MI355X_GEMM_RING_NST64"))  : 4;
-        // GGML_MI355X_GEMM_RING_BIG=<BN><stages> (e.g. 642): A-B override of the tile width / depth for products that cover the chip
-        static const int big = getenv("GGML_MI355X_GEMM_RING_BIG") ? atoi(getenv("GGML_MI355X_GEMM_RING_BIG")) : 0;
-        // GGML_MI355X_GEMM_RING_TM256=<BN><stages> (1282, 1283, 642, 643): 256-row tiles (8 waves) for products with at least
-        // GGML_MI355X_GEMM_RING_TM256_MIN (default 200) such tiles
-        // (read at every flush — a few hundred per encode — so that a test can switch them inside one process)
-        const int tm256 = getenv("GGML_MI355X_GEMM_RING_TM256") ? atoi(getenv("GGML_MI355X_GEMM_RING_TM256")) : 0;
-        const int tm256_min = getenv("GGML_MI355X_GEMM_RING_TM256_MIN") ? atoi(getenv("GGML_MI355X_GEMM_RING_TM256_MIN")) : 200;
-        const int64_t mt256 = (k.M + 255) / 256, nt64 = (k.T + 63) / 64;
-        if (tm256 / 10 == 128 && mt256 * nt128 >= tm256_min)
-            rc = tm256 == 1283 ? launch_ring<128, 3, 256>(ctx, k, P.bytes, P.flops) : launch_ring<128, 2, 256>(ctx, k, P.bytes, P.flops);
-        else if (tm256 / 10 == 64 && mt256 * nt64 >= tm256_min)
-            rc = tm256 == 643 ? launch_ring<64, 3, 256>(ctx, k, P.bytes, P.flops) : launch_ring<64, 2, 256>(ctx, k, P.bytes, P.flops);
-        else
-        if (mt * nt128 >= ctx->n_cu && big == 642)      rc = launch_ring<64, 2>(ctx, k, P.bytes, P.flops);
-        else if (mt * nt128 >= ctx->n_cu && big == 643) rc = launch_ring<64, 3>(ctx, k, P.bytes, P.flops);
-        else if (mt * nt128 >= ctx->n_cu && big == 644) rc = launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
-        else
-        if (mt * nt128 >= ctx->n_cu) rc = nst128 == 2 ? launch_ring<128, 2>(ctx, k, P.bytes, P.flops)
-                                        : nst128 == 4 ? launch_ring<128, 4>(ctx, k, P.bytes, P.flops)
-                                                      : launch_ring<128, 3>(ctx, k, P.bytes, P.flops);
-        else                         rc = nst64 == 2 ? launch_ring<64, 2>(ctx, k, P.bytes, P.flops)
-                                        : nst64 == 3 ? launch_ring<64, 3>(ctx, k, P.bytes, P.flops)
-                                        : nst64 == 5 ? launch_ring<64, 5>(ctx, k, P.bytes, P.flops)
-                                        : nst64 == 6 ? launch_ring<64, 6>(ctx, k, P.bytes, P.flops)
-                                                     : launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
+        // (256-row tiles with 8 waves, and other widths / depths for the chip-covering products, were measured in rounds 2 and 3 and lost: HISTORY.md)
+        if (mt * nt128 >= ctx->n_cu) rc = launch_ring<128, 2>(ctx, k, P.bytes, P.flops);
+        else                         rc = launch_ring<64, 4>(ctx, k, P.bytes, P.flops);
     } else {
-        // (GGML_MI355X_GEMM_GROUP_CFG=<BN><stages>, e.g. 643: A-B measurements of the tile width / ring depth of the grouped form)
-        const int cfg = getenv("GGML_MI355X_GEMM_GROUP_CFG") ? atoi(getenv("GGML_MI355X_GEMM_GROUP_CFG")) : 0;
-        switch (cfg) {
-            case 642:  rc = launch_ring_group<64, 2>(ctx, P.k, n, P.bytes, P.flops); break;
-            case 643:  rc = launch_ring_group<64, 3>(ctx, P.k, n, P.bytes, P.flops); break;
-            case 644:  rc = launch_ring_group<64, 4>(ctx, P.k, n, P.bytes, P.flops); break;
-            case 1282: rc = launch_ring_group<128, 2>(ctx, P.k, n, P.bytes, P.flops); break;
-            case 1283: rc = launch_ring_group<128, 3>(ctx, P.k, n, P.bytes, P.flops); break;
-            case 2561282: rc = launch_ring_group<128, 2, 256>(ctx, P.k, n, P.bytes, P.flops); break;   // 256-row tiles, 8 waves
-            case 2561283: rc = launch_ring_group<128, 3, 256>(ctx, P.k, n, P.bytes, P.flops); break;
-            case 256642:  rc = launch_ring_group<64, 2, 256>(ctx, P.k, n, P.bytes, P.flops); break;
-            case 256643:  rc = launch_ring_group<64, 3, 256>(ctx, P.k, n, P.bytes, P.flops); break;
-            default:
-                // measured on large-v3 encode (32 Q/K/V groups + 8 cross-K/V groups of 8, profiles/r02_encoder_ab.txt): 64-wide tiles
-                // with a 2-stage ring (48 KB: three workgroups co-resident per CU, each other's DMA waits hidden) 2.13 ms;
-                // 64 x 3 stages (2 per CU) 2.81; 128 x 2 stages (2 per CU) 2.63; 64 x 4 (1 per CU) 3.51; 128 x 3 (1 per CU) 3.88;
-                // the same products as single launches (64 x 4) 2.9
-                rc = launch_ring_group<64, 2>(ctx, P.k, n, P.bytes, P.flops);
-        }
+        // measured on large-v3 encode (32 Q/K/V groups + 8 cross-K/V groups of 8, profiles/r02_encoder_ab.txt): 64-wide tiles
+        // with a 2-stage ring (48 KB: three workgroups co-resident per CU, each other's DMA waits hidden) 2.13 ms;
+        // 64 x 3 stages (2 per CU) 2.81; 128 x 2 stages (2 per CU) 2.63; 64 x 4 (1 per CU) 3.51; 128 x 3 (1 per CU) 3.88;
+        // the same products as single launches (64 x 4) 2.9
+        rc = launch_ring_group<64, 2>(ctx, P.k, n, P.bytes, P.flops);
     }
     if (rc == MI355X_E_UNSUPPORTED) {
         // the runtime rejected the ring kernel's dynamic LDS size: every member leaves as the register-staged kernel instead (the
@@ -783,10 +744,9 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
 
 // hold a ring GEMM back; it leaves with the next flush (mi355x_flush_pending: any other launch, synchronize, end of the graph range)
 static int hold_ring_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, double flops) {
-    static const bool group_on = !(getenv("GGML_MI355X_GEMM_GROUP") && !atoi(getenv("GGML_MI355X_GEMM_GROUP")));
     PendingGemms * P = (PendingGemms *) ctx->pending_store;
     // (the pending store may hold another kernel family's launches — mmq.hip groups its products the same way: those leave first)
-    if (ctx->pending_n > 0 && (ctx->pending_flush != flush_pending_gemms || !(group_on && gemm_mergeable(*P, ctx->pending_n, k)))) {
+    if (ctx->pending_n > 0 && (ctx->pending_flush != flush_pending_gemms || !gemm_mergeable(*P, ctx->pending_n, k))) {
         const int rc = mi355x_flush_pending(ctx);
         if (rc) return rc;
     }
@@ -803,9 +763,8 @@ static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, doubl
     const int64_t mt = (k.M + BM - 1) / BM;
     const int64_t nt128 = (k.T + 127) / 128, nt64 = (k.T + 63) / 64;
     if constexpr (AT == MI355X_TYPE_F16) {
-        // both operands plain f16: the LDS-DMA ring (GGML_MI355X_GEMM_RING=0 keeps the register-staged kernel)
-        static const bool ring_on = !(getenv("GGML_MI355X_GEMM_RING") && !atoi(getenv("GGML_MI355X_GEMM_RING")));
-        if (ring_on && k.K % BK == 0 && k.K >= 2*BK && (k.a_nb1 % 16) == 0 && ((uintptr_t) k.A % 16) == 0 && (k.ldb % 8) == 0 && nt64 <= 65535) {
+        // both operands plain f16: the LDS-DMA ring
+        if (k.K % BK == 0 && k.K >= 2*BK && (k.a_nb1 % 16) == 0 && ((uintptr_t) k.A % 16) == 0 && (k.ldb % 8) == 0 && nt64 <= 65535) {
             return hold_ring_gemm(ctx, k, bytes, flops);
         }
     }

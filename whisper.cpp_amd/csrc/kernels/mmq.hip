@@ -46,7 +46,6 @@ struct MmqArgs {
     const uint16_t * gelu_tab;
     int8_t * pq; float * pd; int prep_only;                    // epilogue also leaves the Q8_0 rows of the result (K' = M): the next GEMM's B
     int mt, nt, per, m_major;                                  // tile counts and XCD-aware tile order
-    int dbg;                                                   // GGML_MI355X_MMQ_DBG (anatomy of a K-step, scripts/mmq_kbench.py): 1 no MFMA / fold, 2 no global loads after the first step, 4 no LDS stores after the first step
 };
 
 #define MQ_KS 128                      // K elements per step = bytes per tile row
@@ -487,19 +486,16 @@ __device__ __forceinline__ void mmq_tile(const MmqArgs & a, const int tile, char
         if constexpr (!SMF) { if (nb_ >= 0) read_frags(st, nb_); }
     };
 
-    const bool dbg_nocomp = a.dbg & 1, dbg_noload = a.dbg & 2, dbg_nostore = a.dbg & 4;
     for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk && !dbg_noload) load_tile(kt + 1);
+        if (kt + 1 < nk) load_tile(kt + 1);
         const char * st = lds + (kt & 1) * STAGE;
         __builtin_amdgcn_sched_barrier(0);
-        if (!dbg_nocomp) {
-            read_frags(st, 0);
-            block(st, 1);
-            block(st, 2);
-            block(st, 3);
-            block(st, -1);
-        }
-        if (kt + 1 < nk && !dbg_nostore) store_tile(kt + 1, lds + ((kt + 1) & 1) * STAGE);
+        read_frags(st, 0);
+        block(st, 1);
+        block(st, 2);
+        block(st, 3);
+        block(st, -1);
+        if (kt + 1 < nk) store_tile(kt + 1, lds + ((kt + 1) & 1) * STAGE);
         __syncthreads();
     }
     mq_epilogue<MT, NT>(a, acc, m0 + wm*(MT*32), n0 + wn*(NT*32), lane);
@@ -582,19 +578,19 @@ static int launch_mmq(mi355x_ctx * ctx, const MmqArgs * members, int n, double b
 
 // tile shape: 64 x 128 — the A unpack is amortised over the tile's 128 columns, the B tile is a plain copy, and two result sets, the
 // constant C operand and the prefetch registers fit 256 VGPRs beside 2 accumulator tiles per wave (with 4 — a 128 x 128 tile — they
-// spill); GGML_MI355X_MMQ_TILE=12864 selects 128 x 64 for A-B measurements
+// spill); test option MI355X_OPT_MMQ_TILE = 12864 selects 128 x 64 (bit-identical, tests/test_gpu_mmq.py)
 template <int WT, bool SMF>
 static int launch_mmq_shape(mi355x_ctx * ctx, const MmqArgs * members, int n, double bytes, double flops) {
     if constexpr (SMF) {
-        const int force = getenv("GGML_MI355X_MMQ_TILE") ? atoi(getenv("GGML_MI355X_MMQ_TILE")) : 0;
+        const int force = mi355x_opt(MI355X_OPT_MMQ_TILE, 0);
         if (force == 12864) return launch_mmq<WT, 128, 64, true>(ctx, members, n, bytes, flops);
     }
     return launch_mmq<WT, 64, 128, SMF>(ctx, members, n, bytes, flops);
 }
 
 static int launch_mmq_any(mi355x_ctx * ctx, int wt, const MmqArgs * members, int n, double bytes, double flops) {
-    // GGML_MI355X_MMQ_SCALE_MFMA=0: scale products on the VALU from broadcast LDS reads (the Q4_K form) instead of the rank-1 MFMA
-    const bool smf = !(getenv("GGML_MI355X_MMQ_SCALE_MFMA") && !atoi(getenv("GGML_MI355X_MMQ_SCALE_MFMA")));
+    // test option MI355X_OPT_MMQ_SCALE_MFMA = 0: scale products on the VALU from broadcast LDS reads (the Q4_K form) instead of the rank-1 MFMA
+    const bool smf = mi355x_opt(MI355X_OPT_MMQ_SCALE_MFMA, 1) != 0;
     switch (wt) {
         case MI355X_TYPE_Q4_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q4_0, true>(ctx, members, n, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q4_0, false>(ctx, members, n, bytes, flops);
         case MI355X_TYPE_Q5_0: return smf ? launch_mmq_shape<MI355X_TYPE_Q5_0, true>(ctx, members, n, bytes, flops) : launch_mmq_shape<MI355X_TYPE_Q5_0, false>(ctx, members, n, bytes, flops);
@@ -641,7 +637,7 @@ static int flush_pending_mmq(mi355x_ctx * ctx) {
 }
 
 static int hold_mmq(mi355x_ctx * ctx, int wt, const MmqArgs & k, double bytes, double flops) {
-    const bool group_on = !(getenv("GGML_MI355X_MMQ_GROUP") && !atoi(getenv("GGML_MI355X_MMQ_GROUP")));      // (read per call: a test compares both forms in one process)
+    const bool group_on = mi355x_opt(MI355X_OPT_MMQ_GROUP, 1) != 0;      // (test option: single launches, compared with the grouped form in one process)
     if (!group_on) return launch_mmq_any(ctx, wt, &k, 1, bytes, flops);
     PendingMmq * P = (PendingMmq *) ctx->pending_store;
     if (ctx->pending_n > 0 && (ctx->pending_flush != flush_pending_mmq || !mmq_mergeable(*P, ctx->pending_n, wt, k))) {
@@ -676,7 +672,6 @@ static int gemm_q8act_impl(mi355x_ctx * ctx, const mi355x_tensor * A, const void
         const qrows_t P = qrows_of(prep_out, 0, M, T);
         k.pq = P.q; k.pd = P.d; k.prep_only = prep_only;
     }
-    k.dbg = getenv("GGML_MI355X_MMQ_DBG") ? atoi(getenv("GGML_MI355X_MMQ_DBG")) : 0;
     const double flops = 2.0 * M * (double) K * (double) T;
     const double bytes = (double) mi355x_type_row_bytes(wt, K) * M + (double) qrows_bytes(q8k, K, T) + (prep_only ? 0.0 : (double) T*M*(k.dst_f16 ? 2 : 4)) + (prep_out ? (double) qrows_bytes(0, M, T) : 0.0);
     return hold_mmq(ctx, wt, k, bytes, flops);       // leaves with the next flush (any other launch, synchronize, end of the graph range)

@@ -24,7 +24,7 @@ SYMBOLS = [
     "mi355x_repack_from_planar", "mi355x_mul_mat", "mi355x_prep_act", "mi355x_gemm_f16act", "mi355x_dequant_f16", "mi355x_gemv_fused",
     "mi355x_flash_attn_ext", "mi355x_flash_attn_ext_exact", "mi355x_flash_attn_partial", "mi355x_flash_attn_combine", "mi355x_norm", "mi355x_binary", "mi355x_scale", "mi355x_gelu", "mi355x_cpy",
     "mi355x_last_launch_mirrored", "mi355x_act_planes_bytes", "mi355x_act_prepare", "mi355x_act_scratch", "mi355x_flash_attn_partial_multi", "mi355x_flash_attn_planes", "mi355x_decode_head_multi",
-    "mi355x_argmax_top2", "mi355x_act_rows_bytes", "mi355x_gemm_q8act", "mi355x_gemm_q8act_prep", "mi355x_flash_attn_ext_prep_rows", "mi355x_unary", "mi355x_pad_reflect_1d", "mi355x_get_rows", "mi355x_get_rows_add", "mi355x_im2col_1d", "mi355x_soft_max", "mi355x_rope", "mi355x_concat", "mi355x_memset", "mi355x_checksum", "mi355x_log_mel", "mi355x_log_mel_n_len", "mi355x_debug_read_stamps", "mi355x_wake",
+    "mi355x_argmax_top2", "mi355x_act_rows_bytes", "mi355x_gemm_q8act", "mi355x_gemm_q8act_prep", "mi355x_flash_attn_ext_prep_rows", "mi355x_unary", "mi355x_pad_reflect_1d", "mi355x_get_rows", "mi355x_get_rows_add", "mi355x_im2col_1d", "mi355x_soft_max", "mi355x_rope", "mi355x_concat", "mi355x_memset", "mi355x_checksum", "mi355x_log_mel", "mi355x_log_mel_n_len", "mi355x_debug_read_stamps", "mi355x_wake", "mi355x_test_option",
 ]
 
 
