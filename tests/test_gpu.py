@@ -1020,8 +1020,12 @@ def test_bench_smoke():
     assert ms["streams"] == 8 and b8["chunks_per_s"] > 0 and o8["chunks_per_s"] > 0 and o4["chunks_per_s"] > 0, ms
     assert b8["batch_stats"]["chains"] > 0 and b8["mean_columns_per_chain"] > 2 and o8["batch_stats"]["chains"] == 0 and o4["batch_stats"]["chains"] == 0, ms
     # the roofline object is the time-weighted figure of the dominant kernel TEMPLATE, with the whole step / encoder beside it
-    for k in ("frac", "step_frac", "encode_frac", "chunk_frac", "instantiations", "largest_instantiation"):
+    for k in ("frac", "step_frac", "encode_frac", "chunk_frac", "instantiations", "algorithmic_per_launch", "traffic"):
         assert k in d["roofline"], k
+    # every instantiation of the family carries its own (algorithmic bytes, counter bytes) pair per launch
+    inst = d["roofline"]["instantiations"]
+    assert isinstance(inst, list) and inst and all("algorithmic_per_launch" in e and "traffic" in e and e["launches"] > 0 for e in inst)
+    assert "batched_16_streams" in ms and "batched_32_streams" in ms and ms["batched_32_streams"]["chunks_per_s"] > 0
 
 
 def test_bench_under_torchrun_exercises_the_native_weight_distribution():

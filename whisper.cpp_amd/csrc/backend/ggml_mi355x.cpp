@@ -467,7 +467,8 @@ struct mi_backend_ctx {
     void *       act = nullptr; size_t act_size = 0;
     void *       act_alt = nullptr; size_t act_alt_size = 0;     // second scratch: a GEMM reading `act` writes the next GEMM's prepared activations here
     const void * act_src = nullptr; int64_t act_K = 0, act_T = 0, act_nb1 = 0; int act_mode = -1;
-    const void * elided_src = nullptr;     // F32 result a producer did NOT store because its only reader takes the prepared activations (this graph): reading it is an error
+    const void * elided_src = nullptr;     // F32 result a producer did NOT store because its only reader takes the prepared activations (this graph) ...
+    const ggml_tensor * elided_for = nullptr;   // ... that reader: the one node for which reading x->data is an error (the address itself is reused by later tensors)
     mi_io_marks io;                                             // uploads this stream already waits behind
     mi_qstate   qs;                                             // planes a producer's epilogue left for the next mat-vec (T >= 3 pipeline)
     // cross-state batches (mi_batch_group)
@@ -745,7 +746,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
     // a producer elided this F32 activation because mm_takes_prepared() promised that its prepared rows would be consumed.  If the
     // consuming kernel then refuses them (alignment, a shape only its launch code knows), no path that re-reads x->data may run: fail loudly.
     auto reads_elided = [&]() {
-        if (x->data != b->elided_src || !b->elided_src) return false;
+        if (!b->elided_src || mm != b->elided_for || x->data != b->elided_src) return false;
         GGML_LOG_ERROR("ggml-mi355x: %s: the prepared activations of %s were refused and its F32 form was never stored\n", mm->name, x->name);
         return true;
     };
@@ -807,7 +808,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                         if (rc == 0) {
                             std::swap(b->act, b->act_alt); std::swap(b->act_size, b->act_alt_size);
                             b->act_src = c.last->data; b->act_K = M; b->act_T = T; b->act_mode = 3; b->act_nb1 = M*4;
-                            if (only) b->elided_src = c.last->data;
+                            if (only) { b->elided_src = c.last->data; b->elided_for = g->nodes[j]; }
                             return 0;
                         }
                         if (rc != MI355X_E_UNSUPPORTED) return rc;
@@ -834,14 +835,14 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
             // Is the result itself the activation matrix of the next node's MFMA GEMM (fc1 + GELU -> fc2)?  Then the epilogue writes
             // that GEMM's prepared f16 activations (second scratch; this product still reads the first), and when nothing else reads
             // the F32 result it is not stored at all: one launch, a 30 MB write and a 30 MB read less per encoder layer of large-v3.
-            void * prep_out = nullptr; bool prep_only = false;
+            void * prep_out = nullptr; bool prep_only = false; const ggml_tensor * prep_for = nullptr;
             const int64_t M = mm->ne[0];
             if (g && b->fuse && act == b->act && c.last->type == GGML_TYPE_F32 && M % 32 == 0 && M <= 8192 &&
                 c.last->nb[0] == 4 && (int64_t) c.last->nb[1] == M*4 && c.last->ne[1] == T && c.last->ne[2] == 1 && c.last->ne[3] == 1) {
                 const int j = next_real(g, c.end);
                 int mode2 = -1;
                 if (j < g->n_nodes && mm_takes_prepared(b, g->nodes[j], c.last, mode2) && mode2 == 1 && mi_act_reserve(b, (size_t) T * M * 2, true) == 0) {
-                    prep_out = b->act_alt;
+                    prep_out = b->act_alt; prep_for = g->nodes[j];
                     prep_only = can_elide(g, c.last, 1);
                 }
             }
@@ -851,7 +852,7 @@ static int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgrap
                     if (rc == 0) {       // the next GEMM finds its activations prepared: the scratch buffers trade places
                         std::swap(b->act, b->act_alt); std::swap(b->act_size, b->act_alt_size);
                         b->act_src = c.last->data; b->act_K = M; b->act_T = T; b->act_mode = 1; b->act_nb1 = M*4;
-                        if (prep_only) b->elided_src = c.last->data;
+                        if (prep_only) { b->elided_src = c.last->data; b->elided_for = prep_for; }
                         return 0;
                     }
                     if (rc != MI355X_E_UNSUPPORTED) return rc;
@@ -1645,7 +1646,7 @@ static int mi_emit_range(mi_backend_ctx * b, ggml_cgraph * g, int i0, int i_stop
     return mi355x_flush(b->k);            // launches the kernel library held back for grouping (gemm_mfma.hip) leave with their range
 }
 static int mi_emit_graph(mi_backend_ctx * b, ggml_cgraph * g) {
-    b->act_src = nullptr; b->elided_src = nullptr; b->qs = mi_qstate();
+    b->act_src = nullptr; b->elided_src = nullptr; b->elided_for = nullptr; b->qs = mi_qstate();
     return mi_emit_range(b, g, 0, g->n_nodes);
 }
 
