@@ -23,7 +23,7 @@ REF = Path(os.environ.get("WHISPER_REF", "/root/reference"))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 KERNEL_SRCS = ["ctx.hip", "elementwise.hip", "gemv.hip", "decode.hip", "decode_q.hip", "decode_mx.hip", "gemm_mfma.hip", "fattn.hip", "fattn_exact.hip", "mel.hip", "mul_mat.hip", "mmq.hip"]
-BACKEND_SRCS = ["ggml_mi355x.cpp"]
+BACKEND_SRCS = ["ggml_mi355x.cpp", "mi_buffers.cpp", "mi_planner.cpp", "mi_batching.cpp", "mi_distribution.cpp"]      # one internal header: mi_backend.h
 
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
             "-Wall", "-Wno-unused-function", "-Wno-unused-variable", f"-I{ROOT / 'include'}", f"-I{CSRC / 'kernels'}"]
