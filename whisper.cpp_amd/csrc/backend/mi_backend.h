@@ -170,7 +170,8 @@ struct mi_backend_ctx {
     mi_io_marks io;                                             // uploads this stream already waits behind
     mi_qstate   qs;                                             // planes a producer's epilogue left for the next mat-vec (T >= 3 pipeline)
     // cross-state batches (mi_batch_group)
-    bool        in_group = false;                               // counted among the device's decoding states (guarded by the group's mutex)
+    std::atomic<bool> in_group{false};                          // counted among the device's decoding states: written under the group's mutex, READ without it by
+                                                                // mi_batch_leave's fast path (ThreadSanitizer, r05: another thread's window time-out clears it meanwhile)
     bool        in_flight = false;                              // a column of a chain that is being launched right now (group's mutex)
     bool        own_dirty = false;                              // work was launched on the own stream since the group's stream last waited for it
     hipEvent_t  own_ev = nullptr;
@@ -180,7 +181,8 @@ struct mi_backend_ctx {
     // host-visible mirror of the logits: the vocabulary projection stores its result a second time into pinned, device-mapped host memory,
     // so whisper's read-back of the row(s) (ggml_backend_tensor_get, src/whisper.cpp:2957-2963) is a memcpy instead of a device-to-host copy
     char *      mirror_host = nullptr; char * mirror_dev = nullptr;
-    const void * mirror_src = nullptr; size_t mirror_bytes = 0;  // device range [mirror_src, + mirror_bytes) is what the mirror holds
+    std::atomic<const void *> mirror_src{nullptr}; std::atomic<size_t> mirror_bytes{0};   // device range [mirror_src, + mirror_bytes) is what the mirror holds.  Atomic: every
+                                                                // stream's logits read scans ALL backends' ranges while a chain leader publishes another state's (ThreadSanitizer, r05)
     std::atomic<int> mirror_state{0};                           // 0 nothing, 1 launched (not yet synchronized), 2 valid
     // where the last decoder step of this state left its logits (device): ggml_backend_mi355x_argmax_last reduces a row there
     const float * logits_dev = nullptr; int logits_n = 0, logits_rows = 0;

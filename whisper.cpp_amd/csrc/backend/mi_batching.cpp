@@ -188,7 +188,13 @@ ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
             }
         }
         if (!lead) {
+#if defined(__SANITIZE_THREAD__)
+            // (the sanitizer build waits through pthread_cond_timedwait: gcc 11's libtsan has no interceptor for pthread_cond_clockwait, which wait_for uses —
+            //  it would not see the mutex released inside the wait and report a double lock plus a race on everything the mutex guards)
+            grp.cv.wait_until(lk, std::chrono::system_clock::now() + std::chrono::microseconds(200));
+#else
             grp.cv.wait_for(lk, std::chrono::microseconds(200));
+#endif
             continue;
         }
         mi_batch_member * mem[MI355X_MAX_COLS];

@@ -371,15 +371,15 @@ char * mi_mirror_dev(mi_backend_ctx * b) {             // device address of the 
 void mi_mirror_invalidate(int device, const void * p, size_t n) {
     std::shared_lock<std::shared_mutex> lk(g_backends_rw);
     for (auto * b : g_backends)
-        if (b->device == device && b->mirror_state.load() != 0 && (const char *) b->mirror_src < (const char *) p + n && (const char *) p < (const char *) b->mirror_src + b->mirror_bytes) b->mirror_state.store(0);
+        if (b->device == device && b->mirror_state.load() != 0 && (const char *) b->mirror_src.load() < (const char *) p + n && (const char *) p < (const char *) b->mirror_src.load() + b->mirror_bytes.load()) b->mirror_state.store(0);
 }
 // read [src, src + size) from a valid mirror instead of the device; false: no mirror holds it
 bool mi_mirror_read(int device, const void * src, void * dst, size_t size) {
     std::shared_lock<std::shared_mutex> lk(g_backends_rw);          // (shared: several streams copy their rows at the same time)
     for (auto * b : g_backends) {
         if (b->device != device || b->mirror_state.load() != 2) continue;
-        const char * s0 = (const char *) b->mirror_src;
-        if ((const char *) src >= s0 && (const char *) src + size <= s0 + b->mirror_bytes) { memcpy(dst, b->mirror_host + ((const char *) src - s0), size); return true; }
+        const char * s0 = (const char *) b->mirror_src.load();
+        if ((const char *) src >= s0 && (const char *) src + size <= s0 + b->mirror_bytes.load()) { memcpy(dst, b->mirror_host + ((const char *) src - s0), size); return true; }
     }
     return false;
 }
