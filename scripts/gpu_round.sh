@@ -40,7 +40,7 @@ prof)
     ;;
 pmc)
     stage "rocprofv3 --pmc passes (bench.py $ARCH $QT, decode only)"
-    for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"; do
+    for ctr in ${PMC_SETS:-"FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE"}; do
         tag=$(echo "$ctr" | tr ' ' '+')
         rm -rf "$OUT/pmc_$tag"
         ( cd /tmp && timeout 900 rocprofv3 --pmc $ctr --kernel-trace -f csv -d "$OUT/pmc_$tag" -o pmc -- python3 "$ROOT/bench.py" --arch "$ARCH" --qtype "$QT" --steps 1 --warmup 0 --n-decode 8 --no-cpu-baseline --no-profile --multi-stream 0 \
@@ -49,7 +49,9 @@ pmc)
         python3 scripts/summarize_pmc.py "$OUT/pmc_$tag" > "$OUT/pmc_$tag.summary.txt" 2>&1; head -30 "$OUT/pmc_$tag.summary.txt"
     done
     # per-kernel HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes of THIS run (bench.py's roofline.traffic reads profiles/pmc_traffic.json)
-    python3 scripts/make_pmc_traffic.py "$OUT" ${ROUND:-4} > "$OUT/pmc_traffic.json" 2> "$OUT/pmc_traffic.err"; head -c 600 "$OUT/pmc_traffic.json"; echo
+    # (one entry per configuration: merged into the committed file's other configurations)
+    python3 scripts/make_pmc_traffic.py "$OUT" ${ROUND:-5} "$ARCH $QT" "$ROOT/profiles/pmc_traffic.json" > "$OUT/pmc_traffic_${ARCH}_${QT}.json" 2> "$OUT/pmc_traffic.err"; head -c 400 "$OUT/pmc_traffic_${ARCH}_${QT}.json"; echo
+    for t in FETCH_SIZE WRITE_SIZE; do rm -rf "$OUT/pmc_${ARCH}_${QT}_$t"; mv "$OUT/pmc_$t" "$OUT/pmc_${ARCH}_${QT}_$t" 2>/dev/null; done
     for d in "$OUT"/pmc_*/; do find "$d" -name "*.csv" -size +20M -delete; done
     ;;
 kbench)
