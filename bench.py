@@ -474,6 +474,29 @@ def main():
         except Exception as e:  # noqa: BLE001
             multi_stream = {"streams": a.multi_stream, "error": str(e)}
 
+    # SURVEY.md §8 row f4, reported beside the headline (the headline itself keeps BASELINE.json's synthetic mel input): 30 s of synthetic PCM resident
+    # in HBM -> mi355x_log_mel -> whisper_set_mel -> one chunk on that spectrogram.  Reference: whisper_pcm_to_mel on host threads (src/whisper.cpp:3901).
+    front_end = None
+    if rank == 0 and world == 1 and hip is not None:
+        try:
+            from whisper_cpp_amd.front_end import GpuFrontEnd, model_filters
+            from whisper_cpp_amd import kernels_api as ka_
+            t = np.arange(16000 * 30, dtype=np.float64) / 16000.0
+            pcm = (0.3 * np.sin(2 * np.pi * (200 + 80 * np.sin(2 * np.pi * 0.5 * t)) * t) + 0.05 * np.random.default_rng(5).standard_normal(t.size)).astype(np.float32)
+            fe = GpuFrontEnd(hip, ka_, local_rank)
+            mel_gpu, mel_ms = fe.log_mel(pcm, model_filters(Path(model)))
+            fe.close()
+            if w.whisper_set_mel(ctx, mel_gpu.ctypes.data_as(C.c_void_p), mel_gpu.shape[1], mel_gpu.shape[0]) != 0:
+                raise RuntimeError("whisper_set_mel rejected the GPU spectrogram")
+            t0 = time.perf_counter()
+            chunk()
+            front_end = {"mel_ms": round(mel_ms, 3), "n_samples": int(pcm.size), "n_mel": int(mel_gpu.shape[0]), "n_len": int(mel_gpu.shape[1]),
+                         "chunk_ms_on_that_mel": round((time.perf_counter() - t0) * 1e3, 2),
+                         "path": "PCM in HBM -> mi355x_log_mel (mel.hip) -> whisper_set_mel -> encode + decode; parity: tests/test_gpu.py::test_gpu_log_mel_matches_the_reference_front_end_on_real_speech"}
+            w.whisper_set_mel(ctx, mel.ctypes.data_as(C.c_void_p), 3000, n_mels)          # back to the benchmark's input
+        except Exception as e:  # noqa: BLE001
+            front_end = {"error": str(e)}
+
     stats = (C.c_uint64 * 4)()
     p.ggml_backend_mi355x_stats(stats)
     prof = profile_chunk() if (rank == 0 and not a.no_profile) else []
@@ -485,7 +508,7 @@ def main():
         out.update({
             "encode_ms": round(encode_ms, 3), "decode_ms_per_token": round(decode_ms, 4),
             "batchd_ms_per_token": round(batchd_ms, 4), "prompt_ms_per_token": round(prompt_ms, 4),
-            "weight_broadcast": bcast, "multi_stream": multi_stream,
+            "weight_broadcast": bcast, "multi_stream": multi_stream, "front_end": front_end,
             "launch_mode": "plain launches on the backend's stream", "hip_runtime": hip_runtime,
             "backend": {"graph_computes": int(stats[0]),
                         "host_ms_in_timed_region": {"graph_compute": round(host_ms[3], 2),

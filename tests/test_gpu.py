@@ -710,10 +710,10 @@ TOL_SINGLE, TOL_BATCH, TOL_F16 = 5e-4, 2e-3, 5e-6
 N_STEPS = "128"
 
 
-def _model_parity(plugin_env, arch, qtype, exact, flash_attn=True, steps=N_STEPS):
+def _model_parity(plugin_env, arch, qtype, exact, flash_attn=True, steps=N_STEPS, extra_env=None):
     from synth_model import make_model
     m = make_model(arch, qtype)
-    env = dict(plugin_env, GGML_MI355X_STRICT="1")
+    env = dict(plugin_env, GGML_MI355X_STRICT="1", **(extra_env or {}))
     if exact:
         env["GGML_MI355X_EXACT"] = "1"
     if arch.startswith("large-v3") and "2l" not in arch:
@@ -768,6 +768,20 @@ def test_plugin_model_parity_without_flash_attn(plugin_env):
     transposed F16 mul_mat operands through the plugin, whole model, STRICT"""
     d = _model_parity(plugin_env, "base.en", "q5_0", exact=False, flash_attn=False, steps="32")
     assert d["flash_attn"] == 0
+    s = d["single"]
+    assert s["worst_nmse"] < TOL_SINGLE, s
+    for st in d["steps"]:
+        if st["tok_cpu"] != st["tok_gpu"]:
+            assert st["margin"] <= 4 * st["max_diff"], st
+    assert d["batch5"]["nmse"] < TOL_BATCH and d["batch48"]["nmse"] < TOL_BATCH, d
+
+
+@pytest.mark.parametrize("arch,qtype", [("base.en", "q5_0"), ("large-v3-2l", "q8_0"), ("base.en", "q4_k")])
+def test_plugin_model_parity_with_the_f16_gemm(plugin_env, arch, qtype):
+    """GGML_MI355X_MMQ=0 — the one kept alternative path: quantized products with more than 8 columns on the f16 MFMA ring over one-time f16
+    copies of the weights instead of the int8 tile GEMM (faster encode, f16(d*q) products instead of the CPU's integer sums) — is a TESTED
+    configuration: whole model, STRICT, same tolerances (round 5: the regression A-B ran it and found it broken by a guard added the same day)"""
+    d = _model_parity(plugin_env, arch, qtype, exact=False, steps="32", extra_env={"GGML_MI355X_MMQ": "0"})
     s = d["single"]
     assert s["worst_nmse"] < TOL_SINGLE, s
     for st in d["steps"]:
