@@ -364,6 +364,277 @@ static int mx_launch(mi355x_ctx * ctx, const MXArgs & k, bool vocab, int nu, boo
     return MI355X_E_UNSUPPORTED;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Q4_K (ggml-common.h:327-338; vec_dot q4_K x q8_K: ggml-cpu/quants.c:696-769).  k_gemv_q's unit for Q4_K is a 64-element chunk — 32 bytes whose low
+// nibbles are sub-block 2c and whose high nibbles are sub-block 2c + 1 of a 256-element super-block — against the Q8_K activations of the chunk in
+// four 16-byte planes.  That is exactly one MFMA pair: K-groups 0 / 1 = low nibbles of bytes 0..15 / 16..31 against planes 0 / 1, K-groups 2 / 3 = high
+// nibbles against planes 2 / 3, issued twice with the other sub-block's half of A masked.  Then, per (row, column), k_gemv_q's own statements:
+//     isum = sc_lo * S_lo + sc_hi * S_hi            msum = m_lo * bsum_lo + m_hi * bsum_hi          (integers: exact in f32, < 2^23)
+//     acc  = fmaf(dx * d, isum, acc)                accm = fmaf(-dx * dmin, msum, accm)             leaf = acc + accm
+// with the 6-bit sub-block scales / mins of the tile's 16 rows decoded once per unit into LDS, and the leaves summed in k_gemv_q's tree (leaf g =
+// chunks g, g + 64).  A wave owns 8 neighbouring chunks (one unit = 512 features = two super-blocks) of its 16 rows.
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+template <int CG> struct mx4k_lds {
+    static constexpr int OFF_AQ  = 0;                                  // [16 rows][8 chunks x 32 B + 16]
+    static constexpr int OFF_ASC = OFF_AQ + 16 * 272;                  // [16 rows][2 super-blocks x 12 B, padded to 32]: the packed 6-bit scales / mins
+    static constexpr int OFF_ADM = OFF_ASC + 16 * 32;                  // [16 rows][2 x (f16 d, f16 dmin)]
+    static constexpr int OFF_SC  = OFF_ADM + 16 * 8;                   // decoded: sc[16 sub-blocks][16 rows] f32 | m[16][16] | d[2][16] | dmin[2][16]
+    static constexpr int OFF_M   = OFF_SC + 16 * 16 * 4;
+    static constexpr int OFF_D   = OFF_M + 16 * 16 * 4;
+    static constexpr int OFF_DMIN = OFF_D + 2 * 16 * 4;
+    static constexpr int OFF_BQ  = OFF_DMIN + 2 * 16 * 4;              // [4 planes][16 CG columns][8 x 16 + 16]
+    static constexpr int BQ_PLANE = 16 * CG * 144;
+    static constexpr int OFF_BDX = OFF_BQ + 4 * BQ_PLANE;              // [16 CG columns][2 super-block scales] f32
+    static constexpr int OFF_BBS = OFF_BDX + 16 * CG * 8;              // [16 CG columns][16 sub-block sums + 4] i32
+    static constexpr int SIZE    = OFF_BBS + 16 * CG * 80;             // multiple of 16
+};
+
+template <int NU, int CG, bool NSEG1>
+__global__ void __launch_bounds__(512) k_gemv_mx4k(const MXArgs a) {
+    typedef mx4k_lds<CG> L;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nwt = a.nwt;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, kg = lane >> 4;
+    const int K = a.K, nch = K >> 6, nsb = K >> 8, T = a.T, ntot = a.ntot;
+    const int row0 = blockIdx.x * MX_ROWS;
+    int s = 0;
+    if constexpr (!NSEG1) {
+        if (a.nseg > 1 && row0 >= a.row_start[1]) s = 1;
+        if (a.nseg > 2 && row0 >= a.row_start[2]) s = 2;
+    }
+    const MXSeg & sgr = NSEG1 ? a.seg[0] : a.seg[s];
+    const int seg0 = NSEG1 ? 0 : a.row_start[s];
+    const int rseg = row0 - seg0;
+    const char * wbase = (const char *) sgr.w;
+    const int64_t nbt = sgr.nbt;                                          // super-blocks of the tensor
+    const int Nseg = sgr.N;
+    char * R = smem + (size_t) wave * L::SIZE;
+
+    // ---- the epilogue's operands of this thread's first outputs, requested now ----
+    typedef const MXArgs __attribute__((address_space(4))) * kargs_t;
+    const kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
+    const int nthreads = blockDim.x;
+    constexpr int NOUT = MX_ROWS * 16 * CG;
+    constexpr int EPI = 2;
+    struct epi_t { int row, t; float bias, res; void * dcol; bool ok; };
+    auto epi_prep = [&](int o) {
+        epi_t e;
+        const int r = o & 15;
+        e.t = o >> 4;
+        const int grow = row0 + r;
+        e.ok = o < NOUT && e.t < T && grow < ntot;
+        e.row = e.ok ? grow - seg0 : 0;
+        const int tc = e.ok ? e.t : 0;
+        e.dcol = ka->cols.dst[NSEG1 ? 0 : s][tc];
+        const float * rcol = ka->cols.res[NSEG1 ? 0 : s][tc];
+        e.bias = sgr.bias ? sgr.bias[e.row] : 0.0f;
+        e.res  = rcol ? rcol[e.row] : 0.0f;
+        return e;
+    };
+    epi_t ep[EPI];
+    #pragma unroll
+    for (int k = 0; k < EPI; k++) ep[k] = epi_prep(tid + k * nthreads);
+    const bool has_res = ka->cols.res[NSEG1 ? 0 : s][0] != nullptr;
+
+    // ---- per-lane addresses of the coalesced loads (unit 0) ----
+    const int c0 = 8 * wave;                                               // first chunk of the wave's unit 0
+    auto rowi = [&](int r) { const int x = rseg + r; return x < Nseg ? x : Nseg - 1; };
+    const int pc8 = lane & 7, pc16 = lane & 15, p4 = lane & 3;
+    // weights: chunk ch of row r = 32 bytes at qs + (r * nsb + ch / 4) * 128 + (ch & 3) * 32: a unit's 8 chunks = 256 contiguous bytes of the row
+    const char * aq_g[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) aq_g[k] = wbase + ((int64_t) rowi(4*k + (lane >> 4)) * nsb) * 128 + (int64_t) c0 * 32;
+    const char * asc_g = wbase + nbt * 128 + ((int64_t) rowi(lane >> 2) * nsb + (c0 >> 2)) * 12;      // 2 super-blocks x 12 bytes = 6 dwords per row
+    const char * adm_g = wbase + nbt * 140 + ((int64_t) rowi(lane >> 2) * nsb + (c0 >> 2)) * 4;
+    const size_t istride = dg_img_stride(MI355X_TYPE_Q4_K, K);
+    auto col_img = [&](int col, int & ti, int & Ti) {
+        const int tc = col < T ? col : T - 1;
+        const int gi = tc >> 3; ti = tc & 7; Ti = T - 8*gi < 8 ? T - 8*gi : 8;
+        return (const char *) a.planes + (size_t) gi * istride;
+    };
+    // Q8_K image: q[4 planes][Ti][nch] uint4 | d[Ti][nsb] f32 | bsum[Ti][nsb * 8] i32
+    const char * bq_g[8 * CG]; const char * bdx_g[CG]; const char * bbs_g[CG];
+    #pragma unroll
+    for (int k = 0; k < 8 * CG; k++) {
+        const int run = 8*k + (lane >> 3), col = run >> 2, plane = run & 3;
+        int ti, Ti; const char * img = col_img(col, ti, Ti);
+        bq_g[k] = img + (((size_t) plane * Ti + ti) * nch + c0) * 16;
+    }
+    #pragma unroll
+    for (int c = 0; c < CG; c++) {
+        int ti, Ti; const char * img = col_img(16*c + (lane >> 2), ti, Ti);
+        bdx_g[c] = img + (size_t) Ti * K + ((size_t) ti * nsb + (c0 >> 2)) * 4;
+        bbs_g[c] = img + (size_t) Ti * K + (size_t) Ti * nsb * 4 + ((size_t) ti * nsb * 8 + (size_t) (c0 >> 2) * 8) * 4;
+    }
+    char * aq_s[4];
+    #pragma unroll
+    for (int k = 0; k < 4; k++) aq_s[k] = R + L::OFF_AQ + (4*k + (lane >> 4)) * 272 + pc16 * 16;
+    char * bq_s[8 * CG];
+    #pragma unroll
+    for (int k = 0; k < 8 * CG; k++) { const int run = 8*k + (lane >> 3); bq_s[k] = R + L::OFF_BQ + (run & 3) * L::BQ_PLANE + (run >> 2) * 144 + pc8 * 16; }
+    const char * aq_l = R + L::OFF_AQ + i * 272 + (kg & 1) * 16;          // + chunk * 32: this lane's 16 bytes of the chunk (low nibbles kg < 2, high kg >= 2)
+    const char * bq_l = R + L::OFF_BQ + kg * L::BQ_PLANE + i * 144;       // + column group * 16 * 144 + chunk * 16
+
+    auto unit_chunks = [&](int u) { const int left = nch - (c0 + 64*u); return left < 0 ? 0 : (left < 8 ? left : 8); };
+    struct { u32x4 aq[4]; uint32_t asc[2]; uint32_t adm; u32x4 bq[8 * CG]; uint32_t bdx[CG]; u32x4 bbs[CG]; } G;
+    auto load_unit = [&](int u) {
+        const int nv = unit_chunks(u);                                     // > 0 (caller)
+        const int64_t uc = 64 * u;                                         // chunk offset of the unit
+        const int nsbu = (nv + 3) >> 2;                                    // super-blocks the unit touches (1 or 2)
+        const int c8 = pc8 < nv ? pc8 : nv - 1, c16 = pc16 < 2*nv ? pc16 : 2*nv - 1;
+        #pragma unroll
+        for (int k = 0; k < 4; k++) G.aq[k] = __builtin_nontemporal_load((const u32x4 *) (aq_g[k] + uc * 32 + c16 * 16));
+        // scales: dwords p4 and p4 + 4 (p4 < 2) of the row's 6; the second super-block may not exist
+        { const int d0 = p4 < 3 * nsbu ? p4 : 0, d1 = 4 + (p4 & 1) < 3 * nsbu ? 4 + (p4 & 1) : 0;
+          G.asc[0] = *(const uint32_t *) (asc_g + (uc >> 2) * 12 + d0 * 4); G.asc[1] = *(const uint32_t *) (asc_g + (uc >> 2) * 12 + d1 * 4); }
+        G.adm = *(const uint32_t *) (adm_g + (uc >> 2) * 4 + ((p4 & 1) < nsbu ? (p4 & 1) : 0) * 4);
+        #pragma unroll
+        for (int k = 0; k < 8 * CG; k++) G.bq[k] = *(const u32x4 *) (bq_g[k] + (uc + c8) * 16);
+        #pragma unroll
+        for (int c = 0; c < CG; c++) {
+            G.bdx[c] = *(const uint32_t *) (bdx_g[c] + (uc >> 2) * 4 + ((p4 & 1) < nsbu ? (p4 & 1) : 0) * 4);
+            G.bbs[c] = *(const u32x4_a4 *) (bbs_g[c] + (uc >> 2) * 32 + (p4 < 2 * nsbu ? p4 : 0) * 16);    // 16 sums = 4 pieces of 4 (dword-aligned only: the sums start T * (K + 4 nsb) bytes into the image)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto store_unit = [&]() {
+        #pragma unroll
+        for (int k = 0; k < 4; k++) *(u32x4 *) aq_s[k] = G.aq[k];
+        *(uint32_t *) (R + L::OFF_ASC + (lane >> 2) * 32 + p4 * 4) = G.asc[0];
+        if (p4 < 2) *(uint32_t *) (R + L::OFF_ASC + (lane >> 2) * 32 + (4 + p4) * 4) = G.asc[1];
+        if (p4 < 2) *(uint32_t *) (R + L::OFF_ADM + (lane >> 2) * 8 + p4 * 4) = G.adm;
+        #pragma unroll
+        for (int k = 0; k < 8 * CG; k++) *(u32x4 *) bq_s[k] = G.bq[k];
+        #pragma unroll
+        for (int c = 0; c < CG; c++) {
+            if (p4 < 2) *(uint32_t *) (R + L::OFF_BDX + (16*c + (lane >> 2)) * 8 + p4 * 4) = G.bdx[c];
+            *(u32x4 *) (R + L::OFF_BBS + (16*c + (lane >> 2)) * 80 + p4 * 16) = G.bbs[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // decode the 6-bit scales / mins of the unit's 16 sub-blocks x 16 rows (get_scale_min_k4, ggml-quants.c:880-887): lane = (row, 4 sub-blocks)
+        {
+            const int row = lane >> 2, sbk = (lane >> 1) & 1, j0 = (lane & 1) * 4;          // super-block of the unit, first sub-block of this lane's four
+            const uint32_t * rs = (const uint32_t *) (R + L::OFF_ASC + row * 32) + sbk * 3;
+            const uint32_t s0 = rs[0], s1 = rs[1], s2 = rs[2];
+            #pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                int sc, m; q4k_scale_min_w(j0 + jj, s0, s1, s2, sc, m);
+                ((float *) (R + L::OFF_SC))[(sbk * 8 + j0 + jj) * 16 + row] = (float) sc;
+                ((float *) (R + L::OFF_M))[(sbk * 8 + j0 + jj) * 16 + row]  = (float) m;
+            }
+            if ((lane & 1) == 0) {
+                const uint32_t dm = ((const uint32_t *) (R + L::OFF_ADM + row * 8))[sbk];
+                ((float *) (R + L::OFF_D))[sbk * 16 + row]    = h2f((uint16_t) (dm & 0xFFFF));
+                ((float *) (R + L::OFF_DMIN))[sbk * 16 + row] = h2f((uint16_t) (dm >> 16));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    int mg; asm volatile("v_mov_b32 %0, 0x4b400000" : "=v"(mg));
+    const i32x4_t cmagic = { mg, mg, mg, mg };
+    const f32x4_t zf = { 0.0f, 0.0f, 0.0f, 0.0f };
+    const uint32_t m_lo = kg < 2 ? 0xFFFFFFFFu : 0u, m_hi = ~m_lo;
+    const int nsh = 4 * (kg >> 1);                                         // low nibbles for K-groups 0 / 1 (sub-block 2c), high for 2 / 3 (2c + 1)
+
+    load_unit(0);
+    store_unit();
+
+    f32x4_t acc[8][CG], accm[8][CG];
+    #pragma unroll
+    for (int j = 0; j < 8; j++)
+        #pragma unroll
+        for (int c = 0; c < CG; c++) { acc[j][c] = zf; accm[j][c] = zf; }
+    #pragma nounroll
+    for (int u = 0; u < NU; u++) {
+        const int nv = unit_chunks(u);
+        if (nv <= 0) break;
+        #pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j >= nv) continue;                                         // (wave-uniform)
+            const int sbk = j >> 2, jl = 2 * (j & 3);                      // super-block of the unit; sub-blocks jl (low nibbles), jl + 1 (high)
+            const u32x4 q = *(const u32x4 *) (aq_l + j * 32);
+            const i32x4_t wv = { (int) ((q[0] >> nsh) & 0x0F0F0F0Fu), (int) ((q[1] >> nsh) & 0x0F0F0F0Fu), (int) ((q[2] >> nsh) & 0x0F0F0F0Fu), (int) ((q[3] >> nsh) & 0x0F0F0F0Fu) };
+            const i32x4_t a_lo = { (int) ((uint32_t) wv[0] & m_lo), (int) ((uint32_t) wv[1] & m_lo), (int) ((uint32_t) wv[2] & m_lo), (int) ((uint32_t) wv[3] & m_lo) };
+            const i32x4_t a_hi = { (int) ((uint32_t) wv[0] & m_hi), (int) ((uint32_t) wv[1] & m_hi), (int) ((uint32_t) wv[2] & m_hi), (int) ((uint32_t) wv[3] & m_hi) };
+            // this lane's rows 4 kg .. 4 kg + 3: sub-block scales / mins, super-block d / dmin
+            const f32x4_t sc_lo = *(const f32x4_t *) (R + L::OFF_SC + ((sbk * 8 + jl) * 16 + 4*kg) * 4), sc_hi = *(const f32x4_t *) (R + L::OFF_SC + ((sbk * 8 + jl + 1) * 16 + 4*kg) * 4);
+            const f32x4_t mn_lo = *(const f32x4_t *) (R + L::OFF_M  + ((sbk * 8 + jl) * 16 + 4*kg) * 4), mn_hi = *(const f32x4_t *) (R + L::OFF_M  + ((sbk * 8 + jl + 1) * 16 + 4*kg) * 4);
+            const f32x4_t dwv = *(const f32x4_t *) (R + L::OFF_D + (sbk * 16 + 4*kg) * 4), dmv = *(const f32x4_t *) (R + L::OFF_DMIN + (sbk * 16 + 4*kg) * 4);
+            #pragma unroll
+            for (int c = 0; c < CG; c++) {
+                const u32x4 bqv = *(const u32x4 *) (bq_l + c * 16 * 144 + j * 16);
+                const i32x4_t bq = { (int) bqv[0], (int) bqv[1], (int) bqv[2], (int) bqv[3] };
+                const i32x4_t S0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_lo, bq, cmagic, 0, 0, 0);
+                const i32x4_t S1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_hi, bq, cmagic, 0, 0, 0);
+                const float dxv = *(const float *) (R + L::OFF_BDX + (16*c + i) * 8 + sbk * 4);
+                const int * bsp = (const int *) (R + L::OFF_BBS + (16*c + i) * 80) + sbk * 8 + jl;
+                const float bs_lo = (float) bsp[0], bs_hi = (float) bsp[1];
+                const f32x4_t F0 = __builtin_bit_cast(f32x4_t, S0), F1 = __builtin_bit_cast(f32x4_t, S1);
+                #pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float isum = fmaf(sc_lo[r], F0[r] - 12582912.0f, sc_hi[r] * (F1[r] - 12582912.0f));      // exact: integers below 2^23
+                    const float msum = fmaf(mn_lo[r], bs_lo, mn_hi[r] * bs_hi);
+                    acc[j][c][r]  = fmaf(dxv * dwv[r], isum, acc[j][c][r]);            // k_gemv_q: acc = fmaf(dxv*dw, (float) isum, acc)
+                    accm[j][c][r] = fmaf(-dxv * dmv[r], msum, accm[j][c][r]);          //           accm = fmaf(-dxv*dminw, (float) msum, accm)
+                }
+            }
+        }
+        if (u + 1 < NU && unit_chunks(u + 1) > 0) {                        // (the second unit exists only at K > 4096: fetched after the first is consumed — 128 accumulators leave no room to hold it in flight)
+            load_unit(u + 1);
+            store_unit();
+        }
+    }
+    // leaf = acc + accm, then k_gemv_q's butterfly over the wave's 8 leaves (lane ^ 1, ^ 2, ^ 4)
+    f32x4_t part[CG];
+    #pragma unroll
+    for (int c = 0; c < CG; c++) {
+        f32x4_t lf[8];
+        #pragma unroll
+        for (int j = 0; j < 8; j++) lf[j] = acc[j][c] + accm[j][c];
+        part[c] = ((lf[0] + lf[1]) + (lf[2] + lf[3])) + ((lf[4] + lf[5]) + (lf[6] + lf[7]));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+    for (int c = 0; c < CG; c++) *(f32x4_t *) ((float *) R + (i + 16*c) * MX_PSTRIDE + 4*kg) = part[c];
+    __syncthreads();
+
+    auto finish = [&](const epi_t & e) {
+        if (!e.ok) return;
+        const int r = e.row & 15;
+        float P[8];
+        #pragma unroll
+        for (int w8 = 0; w8 < 8; w8++) P[w8] = w8 < nwt ? ((const float *) (smem + (size_t) w8 * L::SIZE))[e.t * MX_PSTRIDE + r] : 0.0f;
+        float v = ((P[0] + P[1]) + (P[2] + P[3])) + ((P[4] + P[5]) + (P[6] + P[7]));
+        if (sgr.bias)      v = v + e.bias;
+        if (sgr.has_scale) v = v * sgr.scale;
+        if (sgr.gelu)      v = gelu_lut(v, a.gelu_tab);
+        if (has_res)       v = v + e.res;
+        if (sgr.dst_f16) ((uint16_t *) e.dcol)[e.row] = f2h(v); else ((float *) e.dcol)[e.row] = v;
+    };
+    #pragma unroll
+    for (int k = 0; k < EPI; k++) finish(ep[k]);
+    for (int k = EPI; k * nthreads < NOUT; k++) finish(epi_prep(tid + k * nthreads));
+}
+
+template <int NU, int CG, bool NSEG1>
+static int mx4k_emit(mi355x_ctx * ctx, const MXArgs & k, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
+    static std::atomic<bool> attr_set[64];
+    const int dev = ctx->device & 63;
+    if (lds > 64 * 1024 && !attr_set[dev].load()) {
+        if (hipFuncSetAttribute((const void *) k_gemv_mx4k<NU, CG, NSEG1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
+        attr_set[dev].store(true);
+    }
+    return emit(ctx, "gemv_mx", k_gemv_mx4k<NU, CG, NSEG1>, grid, block, lds, k, bytes, flops);
+}
+
 // columns from which the matrix-core form is taken (GGML_MI355X_MX_MIN_T; 0 = never).  Below it k_gemv_q / k_vocab run.
 static int mx_min_t() {
     static const int v = getenv("GGML_MI355X_MX_MIN_T") ? atoi(getenv("GGML_MI355X_MX_MIN_T")) : 9;
@@ -377,8 +648,9 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     if (!d->x_planes || d->x || d->attn_part_o || d->has_norm || ((uintptr_t) d->x_planes % 16)) return MI355X_E_UNSUPPORTED;
     if (d->nseg < 1 || d->nseg > 3) return MI355X_E_UNSUPPORTED;
     const int wt = d->seg[0].wtype, K = d->K, T = d->T;
-    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0) return MI355X_E_UNSUPPORTED;
-    if (K <= 0 || K % 64) return MI355X_E_UNSUPPORTED;                     // pairs of blocks
+    if (wt != MI355X_TYPE_Q4_0 && wt != MI355X_TYPE_Q5_0 && wt != MI355X_TYPE_Q8_0 && wt != MI355X_TYPE_Q4_K) return MI355X_E_UNSUPPORTED;
+    const bool q4k = wt == MI355X_TYPE_Q4_K;
+    if (K <= 0 || K % 64 || (q4k && K % 256)) return MI355X_E_UNSUPPORTED;   // pairs of blocks / whole super-blocks
     const int nb = K / 32;
     MXArgs k; memset(&k, 0, sizeof(k));
     k.planes = d->x_planes; k.K = K; k.T = T; k.nseg = d->nseg; k.gelu_tab = ctx->gelu_tab;
@@ -390,7 +662,7 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         if (g.N % MX_ROWS && s + 1 < d->nseg) return MI355X_E_UNSUPPORTED; // a tile never straddles two segments
         k.row_start[s] = ntot;
         MXSeg & o = k.seg[s];
-        o.w = g.w; o.nbt = (int64_t) g.N * nb; o.bias = g.ep.bias; o.scale = g.ep.scale; o.has_scale = g.ep.has_scale; o.gelu = g.ep.gelu; o.dst_f16 = g.dst_type == MI355X_TYPE_F16; o.N = g.N;
+        o.w = g.w; o.nbt = q4k ? (int64_t) g.N * (K / 256) : (int64_t) g.N * nb; o.bias = g.ep.bias; o.scale = g.ep.scale; o.has_scale = g.ep.has_scale; o.gelu = g.ep.gelu; o.dst_f16 = g.dst_type == MI355X_TYPE_F16; o.N = g.N;
         for (int t = 0; t < T; t++) {
             if (d->cols) { k.cols.dst[s][t] = d->cols->dst[s][t]; k.cols.res[s][t] = d->cols->res[s][t]; }
             else {
@@ -406,6 +678,7 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     for (int s = d->nseg; s < 4; s++) k.row_start[s] = ntot;
     k.ntot = ntot;
     const bool vocab = ntot > 8192;
+    if (q4k && (vocab || d->planes_out)) return MI355X_E_UNSUPPORTED;      // (as k_gemv_q: Q4_K has no planes-out form and no vocabulary kernel — image by image through k_gemv8)
     bool mirror = false;
     int nu, nwt, rtp = 1;
     const bool pout = d->planes_out != nullptr;
@@ -418,26 +691,48 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         for (int t = 0; t < T; t++) { k.cols.mirror[t] = mirror ? d->cols->mirror[t] : nullptr; if (mirror && !k.cols.mirror[t]) return MI355X_E_UNSUPPORTED; }
         nu = K / 256; nwt = 1; rtp = MX_VOCAB_TILES;
     } else {
-        nu = (nb + 63) / 64;
-        if (nu > 3) return MI355X_E_UNSUPPORTED;
-        nwt = ((nb < 64 ? nb : 64) + 7) / 8;
+        const int units = q4k ? K / 64 : nb;                               // k_gemv_q's lane units: 64-element chunks (Q4_K) or 32-element blocks
+        nu = (units + 63) / 64;
+        if (nu > (q4k ? 2 : 3)) return MI355X_E_UNSUPPORTED;
+        nwt = ((units < 64 ? units : 64) + 7) / 8;
         if (pout) {
             if (d->nseg != 1 || ntot % 32 || nu != 1 || ((uintptr_t) d->planes_out % 16)) return MI355X_E_UNSUPPORTED;
             k.planes_out = d->planes_out; k.planes_only = d->planes_out_only; rtp = 2;
         }
     }
     k.nwt = nwt;
-    const int cg = T > 16 ? 2 : 1;
+    // Q4_K at K > 4096 (two units, 8 waves): two column groups do not fit the LDS — columns 16 .. T - 1 (images 2, 3) go in a second launch
+    const bool q4k_halves = q4k && nu == 2 && T > 16;
+    const int cg = T > 16 && !q4k_halves ? 2 : 1;
     const int ntiles = (ntot + MX_ROWS - 1) / MX_ROWS;              // (a single segment may end inside its last tile: the vocabulary's 51864 / 51865 / 51866 rows)
     const dim3 grid((ntiles + rtp - 1) / rtp), block(64 * nwt * rtp);
     if (pout && (int) block.x < 16 * cg * 8) return MI355X_E_UNSUPPORTED;   // the planes-out pass needs 8 threads per column
-    const size_t per_wave = wt == MI355X_TYPE_Q8_0 ? (cg == 2 ? mx_lds<MI355X_TYPE_Q8_0, 2>::SIZE : mx_lds<MI355X_TYPE_Q8_0, 1>::SIZE)
-                                                     : (cg == 2 ? mx_lds<MI355X_TYPE_Q5_0, 2>::SIZE : mx_lds<MI355X_TYPE_Q5_0, 1>::SIZE);
+    const size_t per_wave = q4k ? (cg == 2 ? mx4k_lds<2>::SIZE : mx4k_lds<1>::SIZE)
+                          : wt == MI355X_TYPE_Q8_0 ? (cg == 2 ? mx_lds<MI355X_TYPE_Q8_0, 2>::SIZE : mx_lds<MI355X_TYPE_Q8_0, 1>::SIZE)
+                                                   : (cg == 2 ? mx_lds<MI355X_TYPE_Q5_0, 2>::SIZE : mx_lds<MI355X_TYPE_Q5_0, 1>::SIZE);
     const uint32_t lds = (uint32_t) ((size_t) rtp * nwt * per_wave);
     if (lds > 160 * 1024 - 256) return MI355X_E_UNSUPPORTED;
     const double bytes = wbytes + (double) dg_planes_bytes(wt, K, T) + (double) ntot*T*4;
     const double flops = 2.0 * ntot * K * T;
     int rc;
+    if (q4k) {
+        if (ntot % MX_ROWS) return MI355X_E_UNSUPPORTED;
+        const bool n1 = d->nseg == 1;
+        if (nu == 1) rc = cg == 2 ? (n1 ? mx4k_emit<1, 2, true>(ctx, k, grid, block, lds, bytes, flops) : mx4k_emit<1, 2, false>(ctx, k, grid, block, lds, bytes, flops))
+                                  : (n1 ? mx4k_emit<1, 1, true>(ctx, k, grid, block, lds, bytes, flops) : mx4k_emit<1, 1, false>(ctx, k, grid, block, lds, bytes, flops));
+        else if (!n1) return MI355X_E_UNSUPPORTED;
+        else if (!q4k_halves) rc = mx4k_emit<2, 1, true>(ctx, k, grid, block, lds, bytes, flops);
+        else {
+            k.T = 16;
+            rc = mx4k_emit<2, 1, true>(ctx, k, grid, block, lds, bytes * 16 / T, flops * 16 / T);
+            if (rc) return rc;
+            k.T = T - 16;
+            k.planes = (const char *) d->x_planes + 2 * dg_img_stride(MI355X_TYPE_Q4_K, K);
+            for (int t = 0; t < T - 16; t++) { k.cols.dst[0][t] = k.cols.dst[0][t + 16]; k.cols.res[0][t] = k.cols.res[0][t + 16]; }
+            rc = mx4k_emit<2, 1, true>(ctx, k, grid, block, lds, bytes * (T - 16) / T, flops * (T - 16) / T);
+        }
+        return rc;
+    }
     #define MX_GO(WT_) (cg == 2 ? mx_launch<WT_, 2>(ctx, k, vocab, nu, pout, grid, block, lds, bytes, flops) : mx_launch<WT_, 1>(ctx, k, vocab, nu, pout, grid, block, lds, bytes, flops))
     switch (wt) {
         case MI355X_TYPE_Q4_0: rc = MX_GO(MI355X_TYPE_Q4_0); break;
