@@ -303,7 +303,7 @@ def test_vocabulary_projection_over_planes_with_per_state_destinations(gpu, orac
 
 
 @pytest.mark.parametrize("pinned", [False, True])
-@pytest.mark.parametrize("t,K,T", [("q5_0", 1280, 5), ("q5_0", 512, 3), ("q8_0", 1280, 5), ("q4_0", 768, 7), ("q5_0", 1280, 8), ("q5_0", 512, 2), ("q5_0", 1280, 1)])
+@pytest.mark.parametrize("t,K,T", [("q5_0", 1280, 5), ("q5_0", 512, 3), ("q8_0", 1280, 5), ("q4_0", 768, 7), ("q5_0", 1280, 8), ("q5_0", 512, 2), ("q5_0", 1280, 1), ("q4_K", 1280, 5), ("q4_K", 1280, 20), ("q4_K", 512, 11), ("q5_0", 1280, 20)])
 def test_vocabulary_projection_mirror_rows_equal_the_destination_rows(gpu, oracle, t, K, T, pinned):
     """k_vocab with a second (mirror) destination per column — the host-visible copy whisper's logits read-back is served from — for every
     column count incl. those below the kernel's built-in maximum (T = 3, 5, 7), planes form and LayerNorm form (T <= 2)"""

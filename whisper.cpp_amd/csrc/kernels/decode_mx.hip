@@ -389,7 +389,10 @@ template <int CG> struct mx4k_lds {
     static constexpr int SIZE    = OFF_BBS + 16 * CG * 80;             // multiple of 16
 };
 
-template <int NU, int CG, bool NSEG1>
+// LS = 64: k_gemv_q's tree (lane g = chunks g, g + 64; the tile's waves own 8 neighbouring chunks each).  LS = 8: k_gemv8's tree at 8 lanes per row, the
+// vocabulary projection (decode.hip: lane j = chunks j, j + 8, j + 16 chained, leaf = acc + accm, group_sum<8>): ONE wave per tile walks the whole row in
+// units of 8 chunks, RTP = 4 tiles per workgroup.
+template <int LS, int NU, int CG, int RTP, bool NSEG1>
 __global__ void __launch_bounds__(512) k_gemv_mx4k(const MXArgs a) {
     typedef mx4k_lds<CG> L;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -398,7 +401,9 @@ __global__ void __launch_bounds__(512) k_gemv_mx4k(const MXArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, kg = lane >> 4;
     const int K = a.K, nch = K >> 6, nsb = K >> 8, T = a.T, ntot = a.ntot;
-    const int row0 = blockIdx.x * MX_ROWS;
+    const int tl = LS == 8 ? wave : 0, cw = LS == 8 ? 0 : wave;        // tile of the workgroup; place of the wave in the tile's chain
+    constexpr int US = LS == 8 ? 8 : 64;                                   // chunks from one unit of a wave to its next
+    const int row0 = (blockIdx.x * RTP + tl) * MX_ROWS;
     int s = 0;
     if constexpr (!NSEG1) {
         if (a.nseg > 1 && row0 >= a.row_start[1]) s = 1;
@@ -416,18 +421,20 @@ __global__ void __launch_bounds__(512) k_gemv_mx4k(const MXArgs a) {
     typedef const MXArgs __attribute__((address_space(4))) * kargs_t;
     const kargs_t ka = (kargs_t) __builtin_amdgcn_kernarg_segment_ptr();
     const int nthreads = blockDim.x;
-    constexpr int NOUT = MX_ROWS * 16 * CG;
+    constexpr int NOUT = RTP * MX_ROWS * 16 * CG;
     constexpr int EPI = 2;
-    struct epi_t { int row, t; float bias, res; void * dcol; bool ok; };
+    struct epi_t { int row, t, tl; float bias, res; void * dcol; float * mcol; bool ok; };
     auto epi_prep = [&](int o) {
         epi_t e;
-        const int r = o & 15;
-        e.t = o >> 4;
-        const int grow = row0 + r;
+        e.tl = RTP == 1 ? 0 : o / (MX_ROWS * 16 * CG);
+        const int w = RTP == 1 ? o : o % (MX_ROWS * 16 * CG), r = w & 15;
+        e.t = w >> 4;
+        const int grow = (blockIdx.x * RTP + e.tl) * MX_ROWS + r;
         e.ok = o < NOUT && e.t < T && grow < ntot;
         e.row = e.ok ? grow - seg0 : 0;
         const int tc = e.ok ? e.t : 0;
         e.dcol = ka->cols.dst[NSEG1 ? 0 : s][tc];
+        e.mcol = LS == 8 ? (float *) ka->cols.mirror[tc] : nullptr;
         const float * rcol = ka->cols.res[NSEG1 ? 0 : s][tc];
         e.bias = sgr.bias ? sgr.bias[e.row] : 0.0f;
         e.res  = rcol ? rcol[e.row] : 0.0f;
@@ -439,7 +446,7 @@ __global__ void __launch_bounds__(512) k_gemv_mx4k(const MXArgs a) {
     const bool has_res = ka->cols.res[NSEG1 ? 0 : s][0] != nullptr;
 
     // ---- per-lane addresses of the coalesced loads (unit 0) ----
-    const int c0 = 8 * wave;                                               // first chunk of the wave's unit 0
+    const int c0 = 8 * cw;                                                 // first chunk of the wave's unit 0
     auto rowi = [&](int r) { const int x = rseg + r; return x < Nseg ? x : Nseg - 1; };
     const int pc8 = lane & 7, pc16 = lane & 15, p4 = lane & 3;
     // weights: chunk ch of row r = 32 bytes at qs + (r * nsb + ch / 4) * 128 + (ch & 3) * 32: a unit's 8 chunks = 256 contiguous bytes of the row
@@ -477,11 +484,11 @@ __global__ void __launch_bounds__(512) k_gemv_mx4k(const MXArgs a) {
     const char * aq_l = R + L::OFF_AQ + i * 272 + (kg & 1) * 16;          // + chunk * 32: this lane's 16 bytes of the chunk (low nibbles kg < 2, high kg >= 2)
     const char * bq_l = R + L::OFF_BQ + kg * L::BQ_PLANE + i * 144;       // + column group * 16 * 144 + chunk * 16
 
-    auto unit_chunks = [&](int u) { const int left = nch - (c0 + 64*u); return left < 0 ? 0 : (left < 8 ? left : 8); };
+    auto unit_chunks = [&](int u) { const int left = nch - (c0 + US*u); return left < 0 ? 0 : (left < 8 ? left : 8); };
     struct { u32x4 aq[4]; uint32_t asc[2]; uint32_t adm; u32x4 bq[8 * CG]; uint32_t bdx[CG]; u32x4 bbs[CG]; } G;
     auto load_unit = [&](int u) {
         const int nv = unit_chunks(u);                                     // > 0 (caller)
-        const int64_t uc = 64 * u;                                         // chunk offset of the unit
+        const int64_t uc = US * u;                                         // chunk offset of the unit
         const int nsbu = (nv + 3) >> 2;                                    // super-blocks the unit touches (1 or 2)
         const int c8 = pc8 < nv ? pc8 : nv - 1, c16 = pc16 < 2*nv ? pc16 : 2*nv - 1;
         #pragma unroll
@@ -611,28 +618,29 @@ __global__ void __launch_bounds__(512) k_gemv_mx4k(const MXArgs a) {
         const int r = e.row & 15;
         float P[8];
         #pragma unroll
-        for (int w8 = 0; w8 < 8; w8++) P[w8] = w8 < nwt ? ((const float *) (smem + (size_t) w8 * L::SIZE))[e.t * MX_PSTRIDE + r] : 0.0f;
-        float v = ((P[0] + P[1]) + (P[2] + P[3])) + ((P[4] + P[5]) + (P[6] + P[7]));
+        for (int w8 = 0; w8 < 8; w8++) P[w8] = w8 < nwt ? ((const float *) (smem + (size_t) (e.tl * nwt + w8) * L::SIZE))[e.t * MX_PSTRIDE + r] : 0.0f;
+        float v = LS == 8 ? P[0] : ((P[0] + P[1]) + (P[2] + P[3])) + ((P[4] + P[5]) + (P[6] + P[7]));
         if (sgr.bias)      v = v + e.bias;
         if (sgr.has_scale) v = v * sgr.scale;
         if (sgr.gelu)      v = gelu_lut(v, a.gelu_tab);
         if (has_res)       v = v + e.res;
         if (sgr.dst_f16) ((uint16_t *) e.dcol)[e.row] = f2h(v); else ((float *) e.dcol)[e.row] = v;
+        if constexpr (LS == 8) { if (e.mcol) e.mcol[e.row] = v; }
     };
     #pragma unroll
     for (int k = 0; k < EPI; k++) finish(ep[k]);
     for (int k = EPI; k * nthreads < NOUT; k++) finish(epi_prep(tid + k * nthreads));
 }
 
-template <int NU, int CG, bool NSEG1>
+template <int LS, int NU, int CG, int RTP, bool NSEG1>
 static int mx4k_emit(mi355x_ctx * ctx, const MXArgs & k, dim3 grid, dim3 block, uint32_t lds, double bytes, double flops) {
     static std::atomic<bool> attr_set[64];
     const int dev = ctx->device & 63;
     if (lds > 64 * 1024 && !attr_set[dev].load()) {
-        if (hipFuncSetAttribute((const void *) k_gemv_mx4k<NU, CG, NSEG1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
+        if (hipFuncSetAttribute((const void *) k_gemv_mx4k<LS, NU, CG, RTP, NSEG1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
         attr_set[dev].store(true);
     }
-    return emit(ctx, "gemv_mx", k_gemv_mx4k<NU, CG, NSEG1>, grid, block, lds, k, bytes, flops);
+    return emit(ctx, LS == 8 ? "vocab_mx" : "gemv_mx", k_gemv_mx4k<LS, NU, CG, RTP, NSEG1>, grid, block, lds, k, bytes, flops);
 }
 
 // columns from which the matrix-core form is taken (GGML_MI355X_MX_MIN_T; 0 = never).  Below it k_gemv_q / k_vocab run.
@@ -678,7 +686,9 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     for (int s = d->nseg; s < 4; s++) k.row_start[s] = ntot;
     k.ntot = ntot;
     const bool vocab = ntot > 8192;
-    if (q4k && (vocab || d->planes_out)) return MI355X_E_UNSUPPORTED;      // (as k_gemv_q: Q4_K has no planes-out form and no vocabulary kernel — image by image through k_gemv8)
+    if (q4k && d->planes_out) return MI355X_E_UNSUPPORTED;                 // (as k_gemv_q: Q4_K has no planes-out form)
+    // Q4_K's vocabulary projection runs k_gemv8 image by image; its tree is the 8-lanes-per-row one exactly when the launcher picks 8 lanes (decode.hip: mi355x_gemv)
+    if (q4k && vocab && (int64_t) ntot * 8 / 64 < (int64_t) ctx->n_cu * 8) return MI355X_E_UNSUPPORTED;
     bool mirror = false;
     int nu, nwt, rtp = 1;
     const bool pout = d->planes_out != nullptr;
@@ -686,6 +696,7 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
         // k_vocab's shapes and tree (decode_q.hip: mi355x_vocab): 8 lanes per row, lane j = blocks j, j + 8, ...
         const mi355x_gemv_seg & g = d->seg[0];
         if (d->nseg != 1 || pout || K % 256 || K > 2048 || K / 256 < 2 || K / 256 > 5) return MI355X_E_UNSUPPORTED;
+        if (q4k && K > 1536) return MI355X_E_UNSUPPORTED;                  // three units of 8 chunks
         if (g.ep.bias || g.ep.has_scale || g.ep.gelu || g.ep.residual || g.dst_type != MI355X_TYPE_F32) return MI355X_E_UNSUPPORTED;
         mirror = d->cols && d->cols->mirror[0];
         for (int t = 0; t < T; t++) { k.cols.mirror[t] = mirror ? d->cols->mirror[t] : nullptr; if (mirror && !k.cols.mirror[t]) return MI355X_E_UNSUPPORTED; }
@@ -702,7 +713,7 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     }
     k.nwt = nwt;
     // Q4_K at K > 4096 (two units, 8 waves): two column groups do not fit the LDS — columns 16 .. T - 1 (images 2, 3) go in a second launch
-    const bool q4k_halves = q4k && nu == 2 && T > 16;
+    const bool q4k_halves = q4k && (vocab || nu == 2) && T > 16;           // (the vocabulary form holds 128 chained accumulators across its units' loads: one column group)
     const int cg = T > 16 && !q4k_halves ? 2 : 1;
     const int ntiles = (ntot + MX_ROWS - 1) / MX_ROWS;              // (a single segment may end inside its last tile: the vocabulary's 51864 / 51865 / 51866 rows)
     const dim3 grid((ntiles + rtp - 1) / rtp), block(64 * nwt * rtp);
@@ -716,21 +727,27 @@ int mi355x_gemv_mx(mi355x_ctx * ctx, const mi355x_gemv_desc * d) {
     const double flops = 2.0 * ntot * K * T;
     int rc;
     if (q4k) {
-        if (ntot % MX_ROWS) return MI355X_E_UNSUPPORTED;
-        const bool n1 = d->nseg == 1;
-        if (nu == 1) rc = cg == 2 ? (n1 ? mx4k_emit<1, 2, true>(ctx, k, grid, block, lds, bytes, flops) : mx4k_emit<1, 2, false>(ctx, k, grid, block, lds, bytes, flops))
-                                  : (n1 ? mx4k_emit<1, 1, true>(ctx, k, grid, block, lds, bytes, flops) : mx4k_emit<1, 1, false>(ctx, k, grid, block, lds, bytes, flops));
-        else if (!n1) return MI355X_E_UNSUPPORTED;
-        else if (!q4k_halves) rc = mx4k_emit<2, 1, true>(ctx, k, grid, block, lds, bytes, flops);
+        if (d->nseg != 1 && (vocab || nu == 2)) return MI355X_E_UNSUPPORTED;
+        if (!vocab && ntot % MX_ROWS) return MI355X_E_UNSUPPORTED;
+        auto go = [&](double share) {
+            const double by = bytes * share, fl = flops * share;
+            if (vocab)   return mx4k_emit<8, 3, 1, MX_VOCAB_TILES, true>(ctx, k, grid, block, lds, by, fl);
+            if (nu == 2) return mx4k_emit<64, 2, 1, 1, true>(ctx, k, grid, block, lds, by, fl);
+            const bool n1 = d->nseg == 1;
+            return cg == 2 ? (n1 ? mx4k_emit<64, 1, 2, 1, true>(ctx, k, grid, block, lds, by, fl) : mx4k_emit<64, 1, 2, 1, false>(ctx, k, grid, block, lds, by, fl))
+                           : (n1 ? mx4k_emit<64, 1, 1, 1, true>(ctx, k, grid, block, lds, by, fl) : mx4k_emit<64, 1, 1, 1, false>(ctx, k, grid, block, lds, by, fl));
+        };
+        if (!q4k_halves) rc = go(1.0);
         else {
             k.T = 16;
-            rc = mx4k_emit<2, 1, true>(ctx, k, grid, block, lds, bytes * 16 / T, flops * 16 / T);
+            rc = go(16.0 / T);
             if (rc) return rc;
             k.T = T - 16;
             k.planes = (const char *) d->x_planes + 2 * dg_img_stride(MI355X_TYPE_Q4_K, K);
-            for (int t = 0; t < T - 16; t++) { k.cols.dst[0][t] = k.cols.dst[0][t + 16]; k.cols.res[0][t] = k.cols.res[0][t + 16]; }
-            rc = mx4k_emit<2, 1, true>(ctx, k, grid, block, lds, bytes * (T - 16) / T, flops * (T - 16) / T);
+            for (int t = 0; t < T - 16; t++) { k.cols.dst[0][t] = k.cols.dst[0][t + 16]; k.cols.res[0][t] = k.cols.res[0][t + 16]; k.cols.mirror[t] = k.cols.mirror[t + 16]; }
+            rc = go((double) (T - 16) / T);
         }
+        if (rc == 0 && mirror) ctx->last_mirrored = 1;
         return rc;
     }
     #define MX_GO(WT_) (cg == 2 ? mx_launch<WT_, 2>(ctx, k, vocab, nu, pout, grid, block, lds, bytes, flops) : mx_launch<WT_, 1>(ctx, k, vocab, nu, pout, grid, block, lds, bytes, flops))
