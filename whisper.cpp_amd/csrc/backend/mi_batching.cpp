@@ -144,6 +144,8 @@ ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     // Q5_0 (profiles/r04_stream_scaling.txt, r04_chain_split_sweep.txt): 16 states as 10 + 6: 14.2 chunks/s, 12 + 4: 13.9, 8 + 8: 11.5-12.5, one
     // chain of 16: 12.9; 32 as 20 + 12: 18.0, 16 + 16: 15.3; 8 as 5 + 3 or 6 + 2: 9.4-10.0, one chain of 8: 9.3; 6 as 4 + 2: 8.2, one chain of 6: 7.4; 7 as 5 + 2: 8.7, 6 + 1: 7.2; three or more chains
     // (40 %): 11.0 at 32; chains of 3 + 2 at 5 states: 4.9 (one chain of 4 + a solo state: 6.6).
+    // Swept again with the matrix-core mat-vecs (profiles/r05_chain_split_sweep.txt; 16 / 32 states): 34 %: 8.9 / 14.4, 40 %: 10.0 / 14.3, 50 %: 11.4 / 19.3, 60 %: 15.7 / 21.1,
+    // 70 %: 16.0 / 22.2, 80 %: 15.0 / 19.1, 90 %: 14.0 / 21.2.
     // More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still read once per chain step.
     static const int env_cols = getenv("GGML_MI355X_BATCH_COLS") ? std::max(2, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_COLS")))) : 0;
     mi_batch_group & grp = g_batch[b->device];
