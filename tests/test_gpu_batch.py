@@ -473,7 +473,7 @@ def test_multi_state_step_head_matches_get_rows_and_cast(gpu, oracle, t):
 # ---------------------------------------------------------------------------------------------------------------
 # the whole thing through the unmodified reference host: S whisper_states on one device, one C++ thread each (native harness)
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("arch,qtype,streams", [("base.en", "q5_0", 4), ("base.en", "q4_k", 8), ("large-v3-2l", "q8_0", 8), ("base.en", "q5_0", 16), ("large-v3-2l", "q8_0", 11)])
+@pytest.mark.parametrize("arch,qtype,streams", [("base.en", "q5_0", 4), ("base.en", "q4_k", 8), ("large-v3-2l", "q8_0", 8), ("base.en", "q5_0", 16), ("large-v3-2l", "q8_0", 11), ("large-v3-2l", "q4_k", 12), ("large-v3-2l", "q4_k", 30)])
 def test_cross_state_batching_is_bit_identical_to_one_launch_chain_per_state(arch, qtype, streams):
     """every stream's final logits with the plugin's cross-state batching (the states' decode steps as the columns of one launch chain)
     equal, bit for bit, the same streams run with one launch chain per state — and merged chains did carry several columns"""
