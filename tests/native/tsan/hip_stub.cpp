@@ -14,7 +14,7 @@ const char * hipGetErrorString(hipError_t) { return "stub"; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t * p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "stub gfx950"); strcpy(p->gcnArchName, "gfx950"); p->multiProcessorCount = 256; p->totalGlobalMem = (size_t) 1 << 38; return hipSuccess; }
 hipError_t hipMemGetInfo(size_t * f, size_t * t) { *f = (size_t) 1 << 37; *t = (size_t) 1 << 38; return hipSuccess; }
-hipError_t hipMalloc(void ** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipMalloc(void ** p, size_t n) { *p = nullptr; if (posix_memalign(p, 4096, n ? n : 1) != 0) return hipErrorOutOfMemory; memset(*p, 0, n ? n : 1); return hipSuccess; }      // (device allocations are at least 256-byte aligned: ggml-alloc relies on the buffer type's alignment)
 hipError_t hipFree(void * p) { free(p); return hipSuccess; }
 hipError_t hipHostMalloc(void ** p, size_t n, unsigned int) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void * p) { free(p); return hipSuccess; }
