@@ -1006,6 +1006,46 @@ def test_concurrent_streams_on_one_gpu_match_serial(arch, qtype, streams):
         assert d["batch_stats"]["chains"] == 0, d["batch_stats"]
 
 
+CONCURRENT_FULL_CASES = [("base.en", "q5_0", 4, "greedy"), ("base.en", "q5_0", 4, "beam5"), ("base.en", "q5_0", 8, "greedy"), ("base.en", "q5_0", 8, "beam5"),
+                         ("large-v3-turbo", "q8_0", 4, "beam5"), ("large-v3-turbo", "q8_0", 8, "greedy"), ("large-v3-turbo", "q8_0", 8, "beam5")]
+
+
+@pytest.mark.parametrize("arch,qtype,streams,mode", CONCURRENT_FULL_CASES)
+def test_concurrent_whisper_full_streams_match_alone_and_the_cpu(plugin_env, arch, qtype, streams, mode):
+    """BASELINE.json configs[4]'s real shape: S host threads, one whisper_state each on ONE shared context and device
+    (src/whisper.cpp:7813-7941), every thread inside whisper_full_with_state — greedy, or beam search with 5 decoders (5-column decoder
+    steps, src/whisper.cpp:7076-7100, :7264) — on signals of different lengths (6.5 .. 38 s: the long ones encode a second window while
+    the others decode) and different token budgets, so that encodes, prompt steps, beam steps and single-token steps of different states
+    interleave in the rendezvous and on the lane streams.  x-planted models (the transcript is carried by cross-attention; negative
+    controls in test_cross_attention_carried_transcript_...).  Per stream, with cross-state batching at its default (merged chains from 5
+    decoding states), forced from 2 states, and off:
+      * token ids == the same stream alone on the plugin == the reference CPU backend's;
+      * every logits row the sampler saw is BIT-identical to the row of the same decoder history in the run alone (cross-talk between
+        states would show here even though the planted transcript does not depend on the audio);
+      * no merged chain fell back."""
+    from synth_model import make_model
+    m = make_model(arch, qtype, plant="x")
+    env = dict(plugin_env, GGML_MI355X_STRICT="1", FULL_CONCURRENT_CPU_THREADS="32")
+    r = subprocess.run([str(_native("full_concurrent")), str(m), str(streams), mode, "1,2,0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=2400)
+    keep = ROOT / "gpurun_out"
+    if keep.exists():
+        (keep / f"full_concurrent_{arch}_{qtype}_{streams}_{mode}.json").write_text(r.stdout)
+    assert r.returncode in (0, 1) and r.stdout.strip().startswith("{"), r.stderr[-2000:]
+    d = json.loads(r.stdout)
+    for c in d["concurrent"]:
+        assert c["failed"] == 0 and c["streams_with_other_tokens_than_alone"] == 0 and c["histories_with_rows_not_bit_identical"] == 0 and c["fallbacks"] == 0, c
+        assert c["logit_rows_compared"] >= streams * 20, c
+    merged = {c["batching"]: c["merged_chains"] for c in d["concurrent"]}
+    assert merged[0] == 0, merged
+    if mode == "greedy":
+        assert merged[2] > 0, merged                      # single-token steps of >= 2 states did ride merged chains
+        if streams >= 5:
+            assert merged[1] > 0, merged
+    assert d["streams_differing_from_cpu"] == 0, [(s["stream"], s["identical_prefix"], s["n_cpu"], s["n_plugin"]) for s in d["per_stream"] if not s["equal"]]
+    assert all(s["n_cpu"] >= 20 for s in d["per_stream"]), [s["n_cpu"] for s in d["per_stream"]]
+    assert d["ok"] is True and r.returncode == 0
+
+
 def test_a_merged_chain_rejected_half_way_is_repeated_on_the_states_own_chains():
     """a kernel-side rejection in the MIDDLE of a merged launch chain — after the step head and half the layers have
     been launched — must not fail the streams in it.  GGML_MI355X_TEST_FAULT=reject:3 makes the third merged chain of the process report

@@ -480,6 +480,28 @@ def test_plugin_host_threading_under_tsan(tmp_path):
     assert mm and int(mm.group(1)) > 20 and int(mm.group(2)) > 2 * int(mm.group(1)), r.stdout      # the merged-chain path was what ran
 
 
+@pytest.mark.parametrize("mode", ["greedy", "beam5"])
+def test_concurrent_whisper_full_under_tsan(tmp_path, mode):
+    """tests/native/full_concurrent.cpp — S threads inside whisper_full_with_state on one shared context (greedy: single-token steps that merge;
+    beam 5: 5-column steps on the states' own chains; prompt steps, second-window encodes in between) — on the ThreadSanitizer build of the
+    plugin over the stub device.  Nothing is compared (the stub computes nothing): zero sanitizer reports, every whisper_full returns 0.
+    The GPU form of the same driver (tests/test_gpu.py) compares tokens and logits rows."""
+    from synth_model import make_model
+    exe = ROOT / "tests" / "native" / "bin" / "tsan" / "full_concurrent"
+    if not exe.exists():
+        pytest.skip("tests/native/bin/tsan not built (needs the reference tree and libtsan)")
+    m = make_model("micro", "q5_0", tmp_path)
+    env = dict(os.environ, GGML_MI355X_STRICT="1", TSAN_OPTIONS="halt_on_error=0 exitcode=66", FULL_CONCURRENT_NO_CHECK="1", FULL_CONCURRENT_TOKENS_PCT="60",
+               GGML_MI355X_PLUGIN=str(exe.parent / "libggml-mi355x.so"))
+    r = subprocess.run([str(exe), str(m), "6", mode, "2,0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    d = json.loads(r.stdout)
+    assert all(c["failed"] == 0 and c["fallbacks"] == 0 for c in d["concurrent"]), d
+    if mode == "greedy":
+        assert d["concurrent"][0]["merged_chains"] > 10, d
+
+
 def _latest(pattern):
     files = sorted((ROOT / "profiles").glob(pattern))
     assert files, f"profiles/{pattern} is missing"
