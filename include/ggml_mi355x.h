@@ -74,7 +74,7 @@ GGML_MI355X_API int  ggml_backend_mi355x_trace(uint64_t * out16);
 
 /* Cross-state batching: whisper_states of one device whose next graph is a single-token decoder step are
  * executed as the COLUMNS of one launch chain — every weight byte is read once for all of them instead of once per state — by whichever
- * of their host threads completes the set (up to 8 columns; a state alone runs the ordinary path; a state whose next graph is anything
+ * of their host threads completes the set (up to 32 columns per chain, MI355X_IMG_COLS x 4; a state alone runs the ordinary path; a state whose next graph is anything
  * else leaves the group at once).  Per state the results are bit-identical to running alone.  ON by default since round 4 (a
  * whisper_full_parallel user with 8 states otherwise gets the own-chain collapse): GGML_MI355X_BATCH=0 or
  * ggml_backend_mi355x_set_batching(0) switch it off at any time; ggml_backend_mi355x_get_batching returns the current setting.  With
@@ -98,7 +98,12 @@ GGML_MI355X_API int  ggml_backend_mi355x_debug_walk(void * cgraph, int S, int64_
  * rank 0's WEIGHTS buffers into the identically laid out buffers of the other replicas (every context allocates the same tensors in
  * the same order, src/whisper.cpp:1685-1859; buffer counts and sizes are compared first).  The reference has no such call site: it
  * re-reads the model file and uploads tensor by tensor for every context (src/whisper.cpp:1934-1938).
- *   ggml_backend_mi355x_broadcast_weights_peer   one process, several devices: hipMemcpyPeerAsync over xGMI, then checksums
+ *   ggml_backend_mi355x_broadcast_weights_rccl_group  one process, n devices (what `bench.py --gpus N` and mi355x_host_run use): one RCCL
+ *                                                communicator per device (ncclCommInitAll) and ONE grouped ncclBroadcast per weights buffer from
+ *                                                devices[0] (the reference's in-process pattern: ggml-cuda/ggml-cuda.cu:1188, :1027-1030), then
+ *                                                checksums; stats6 = the four below + seconds of communicator setup + ranks; n == 1 is valid
+ *   ggml_backend_mi355x_broadcast_weights_peer   one process, two devices: hipMemcpyPeerAsync over xGMI, then checksums (only on request:
+ *                                                mi355x_host_config.transport = 1, bench.py --transport peer)
  *   ggml_backend_mi355x_clone_weights            n contexts created one after the other on ONE device (a one-GPU machine standing in for
  *                                                n GPUs in tests): copy the first context's buffers into the others', verify the same way
  *   ggml_backend_mi355x_rccl_unique_id           rank 0 of a multi-process job: 128-byte id for the host harness to hand to every rank
@@ -113,6 +118,7 @@ GGML_MI355X_API int  ggml_backend_mi355x_debug_walk(void * cgraph, int S, int64_
 GGML_MI355X_API int  ggml_backend_mi355x_weight_buffers(int device, void ** bases, size_t * sizes, int cap);
 GGML_MI355X_API int  ggml_backend_mi355x_weights_checksum(int device, uint64_t * out_pairs, int cap);
 GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, double * stats4);
+GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_rccl_group(const int * devices, int n, double * stats6);
 GGML_MI355X_API int  ggml_backend_mi355x_clone_weights(int device, int n_replicas, double * stats4);
 GGML_MI355X_API int  ggml_backend_mi355x_rccl_unique_id(void * out128);
 GGML_MI355X_API int  ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, const void * unique_id128, double * stats4);
@@ -125,8 +131,9 @@ GGML_MI355X_API uint64_t ggml_backend_mi355x_deferred_bytes(void);
  *   GGML_MI355X_STRICT=1     abort instead of letting the scheduler fall back to the CPU backend for an unsupported op
  *   GGML_MI355X_EXACT=1      reference-exact arithmetic (test mode, slow): flash attention as the CPU dispatcher computes it
  *                            (F16 accumulation / split over n_threads / F32 tiles), integer block dots for every column count
- *   GGML_MI355X_GEMM_GROUP=0, GGML_MI355X_LN_PREP=0, GGML_MI355X_GEMM_PREP_OUT=0, GGML_MI355X_FATTN_PREP_OUT=0
- *                            encoder / prompt fusions off one by one (A-B measurements; results are bit-identical either way)
+ * (the full list of the environment switches: INTEGRATION.md section 6; kernel-shape variants that tests compare are not
+ *  environment switches but mi355x_test_option values, include/mi355x_kernels.h)
+ * The plugin sets GPU_MAX_HW_QUEUES=8 when it is loaded unless the variable is already set (one hardware queue per concurrent stream).
  */
 
 #ifdef __cplusplus

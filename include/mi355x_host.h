@@ -44,6 +44,11 @@ typedef struct mi355x_host_config {
                                     * against the host scan of the row whisper_decode returned (result: greedy_checked / greedy_mismatches) */
     int32_t batching;              /* cross-state batching in the plugin (ggml_backend_mi355x_set_batching): 1 on (merged chains from 5 states on), n >= 2 on from n states, 0 off, -1 leave as it is.  With
                                     * it the states of one device that decode at the same time run as the columns of ONE launch chain */
+    int32_t transport;             /* how the weights reach contexts r > 0 (skip_payloads = 1): 0 = RCCL — one communicator per device in this process, one grouped
+                                    * ncclBroadcast per weights buffer from first_device (ggml_backend_mi355x_broadcast_weights_rccl_group; the default, and an error
+                                    * if librccl cannot be loaded: no silent substitute); 1 = hipMemcpyPeerAsync device 0 -> device r (ggml_backend_mi355x_broadcast_
+                                    * weights_peer); 2 = RCCL also with n_devices = 1: the world-1 communicator, broadcast and checksum verification run
+                                    * (what a one-GPU box can show of the path; with 0 a single context distributes nothing).  replicas_on_one_device = 1 always uses the on-device copy (RCCL admits one rank per device) */
 } mi355x_host_config;
 
 typedef struct mi355x_host_result {
@@ -53,6 +58,9 @@ typedef struct mi355x_host_result {
     double  load_s;                /* all contexts + states */
     double  bcast_bytes, bcast_seconds;
     int32_t bcast_buffers, bcast_verified;     /* verified: every destination buffer's checksum equals device 0's */
+    int32_t bcast_transport, bcast_ranks;      /* what moved the weights: 0 nothing (one context, or every context read the file), 1 RCCL (ranks = communicator size), 2 peer copies, 3 copy on one device */
+    double  bcast_setup_seconds;               /* RCCL: ncclCommInitAll */
+    double  encode_ms, decode_ms_per_token;    /* mean over all streams and timed chunks: wall milliseconds of whisper_encode, of one whisper_decode */
     int64_t payload_bytes_read;    /* bytes the loaders actually read from the model file, summed over contexts */
     int64_t file_bytes;
     int32_t n_devices, streams_per_device;

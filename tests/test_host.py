@@ -440,6 +440,40 @@ def test_bench_gpus_flag_runs_that_many_contexts_in_one_process():
     assert d["n_gpus"] == 2 and d["config"]["streams"] == 2 and d["steps"] == 1 and d["scaling"] == "weak"
     assert d["value"] > 0 and abs(d["ms_per_step"] - 2 * d["value"]) < 1e-3 * d["ms_per_step"]      # value = whole-job aggregate over both replicas
     assert "self-test" in d["backend"] and d["weight_broadcast"] is None
+    # per-GPU figures of the N > 1 line: encode / decode split measured by the harness, step / encode / chunk fractions
+    assert d["encode_ms"] > 0 and d["decode_ms_per_token"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["step_frac"] > 0 and rf["encode_frac"] >= 0 and rf["chunk_frac"] >= 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "cpu_baseline" in d and "roofline_n1" in d
+
+
+def test_bench_n_gt_1_line_passes_the_n1_lines_kernel_roofline_and_cpu_baseline_through(tmp_path):
+    """the N = 1 run leaves its line in $WHISPER_SYNTH_DIR/bench_n1_line.json; an N > 1 run on the same box for the same workload carries that line's
+    per-kernel roofline object and cpu_baseline (properties of one GPU and of the host) — a line of another workload is ignored"""
+    import time
+    _host_api()
+    from synth_model import make_model
+    make_model("micro", "q5_0")
+    synth = os.environ.get("WHISPER_SYNTH_DIR", "/tmp/whisper_synth")
+    cache = Path(synth) / "bench_n1_line.json"
+    old = cache.read_text() if cache.exists() else None
+    try:
+        fake = {"config": {"workload": "micro Q5_0: 1 x whisper_encode + 4 x whisper_decode(1 token), 1 stream per GPU"}, "_written": time.time(),
+                "roofline": {"kernel": "k_gemv_row", "bound": "hbm", "achieved": 600.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.075, "traffic": 1},
+                "cpu_baseline": {"value": 123.0, "unit": "ms/chunk", "cores": 32, "kind": "reference", "sample": "x"}}
+        cache.write_text(json.dumps(fake))
+        d = _bench_line(_bench(["--gpus", "2", "--arch", "micro", "--steps", "1", "--warmup", "0", "--n-decode", "4"], {"BENCH_BACKEND": "cpu"}))
+        assert d["roofline_n1"]["kernel"] == "k_gemv_row" and d["cpu_baseline"]["value"] == 123.0 and "bench_n1_line.json" in d["n1_line_from"]
+        fake["config"]["workload"] = "large-v3 Q5_0: ..."
+        cache.write_text(json.dumps(fake))
+        d = _bench_line(_bench(["--gpus", "2", "--arch", "micro", "--steps", "1", "--warmup", "0", "--n-decode", "4"], {"BENCH_BACKEND": "cpu"}))
+        assert d["roofline_n1"] is None and d["cpu_baseline"]["value"] is None and d["n1_line_from"] is None
+    finally:
+        if old is None:
+            cache.unlink(missing_ok=True)
+        else:
+            cache.write_text(old)
 
 
 def test_bench_under_torchrun_prints_world_size_as_n_gpus():
@@ -450,6 +484,9 @@ def test_bench_under_torchrun_prints_world_size_as_n_gpus():
     assert d["n_gpus"] == 2 and d["config"]["streams"] == 2 and "torchrun" in d["launch"]
     r = _bench(["--gpus", "4", "--arch", "micro", "--steps", "1", "--warmup", "0", "--n-decode", "4"], {"BENCH_BACKEND": "cpu"}, torchrun=2, port=29535)
     assert r.returncode != 0 and "WORLD_SIZE is 2" in (r.stderr + r.stdout)
+    # without --gpus the world size is taken (`torchrun --nproc-per-node N bench.py` used to run, then failed on every rank)
+    d = _bench_line(_bench(["--arch", "micro", "--steps", "1", "--warmup", "0", "--n-decode", "4"], {"BENCH_BACKEND": "cpu"}, torchrun=2, port=29537))
+    assert d["n_gpus"] == 2
 
 
 def test_bench_never_shrinks_to_fewer_gpus_silently():

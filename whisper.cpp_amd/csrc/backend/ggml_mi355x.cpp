@@ -388,6 +388,7 @@ static void * mi_reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (!strcmp(name, "ggml_backend_mi355x_clone_weights"))           return (void *) ggml_backend_mi355x_clone_weights;
     if (!strcmp(name, "ggml_backend_mi355x_broadcast_weights_rccl"))  return (void *) ggml_backend_mi355x_broadcast_weights_rccl;
     if (!strcmp(name, "ggml_backend_mi355x_rccl_unique_id"))          return (void *) ggml_backend_mi355x_rccl_unique_id;
+    if (!strcmp(name, "ggml_backend_mi355x_broadcast_weights_rccl_group")) return (void *) ggml_backend_mi355x_broadcast_weights_rccl_group;
     if (!strcmp(name, "ggml_backend_mi355x_defer_weights"))           return (void *) ggml_backend_mi355x_defer_weights;
     if (!strcmp(name, "ggml_backend_mi355x_deferred_bytes"))          return (void *) ggml_backend_mi355x_deferred_bytes;
     if (!strcmp(name, "ggml_backend_mi355x_prof_enable_all")) return (void *) ggml_backend_mi355x_prof_enable_all;
@@ -418,6 +419,12 @@ void * ggml_backend_mi355x_reg(void) {
 }
 
 void * ggml_backend_init(void) { return ggml_backend_mi355x_reg(); }
+
+// One hardware queue per concurrent stream.  ROCm's default is 4 per process (incl. the upload stream): with more than 3 whisper_states decoding
+// on their own chains (whisper_full_parallel, a server with several states) two HIP streams share a queue and serialize (measured: 4 streams
+// 4.7 -> 5.8 chunks/s with 8 queues; HISTORY.md).  The runtime reads the variable when it initialises, i.e. at the first HIP call of the
+// process, which for a stock whisper.cpp host comes after this library has been loaded; a value the user has set is left alone.
+__attribute__((constructor)) static void mi_env_defaults(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 int ggml_backend_score(void) { return mi355x_device_count() > 0 ? 100 : 0; }
 

@@ -234,7 +234,8 @@ struct mi_test_fault { int layer = -2; float factor = 1.0f; int reject_chain = 0
 // member's stream and synchronize() wait for the batch's completion event.  One state alone runs exactly the non-batched path.
 // ---------------------------------------------------------------------------------------------------
 #define MI_BATCH_LANES 4
-struct mi_batch_member { mi_backend_ctx * b; ggml_cgraph * g; int state; ggml_status status; };       // state: 0 waiting, 1 being launched, 2 done
+struct mi_batch_member { mi_backend_ctx * b; ggml_cgraph * g; int state; ggml_status status;           // state: 0 waiting, 1 being launched, 2 done
+                         int sig_nodes; const void * sig_w; };                                          // which model the step belongs to: node count + the vocabulary projection's weights
 struct mi_batch_group {
     std::mutex m; std::condition_variable cv;
     std::vector<mi_batch_member *> waiting;
@@ -279,6 +280,11 @@ size_t mi_buft_get_alloc_size(ggml_backend_buffer_type_t, const ggml_tensor * te
 bool   mi_buft_is_host(ggml_backend_buffer_type_t);
 void mi_span_drain(mi_backend_ctx * b);
 void mi_io_order_stream(int device, mi_io_marks & mk, hipStream_t cs);
+// the deferred uploads that wait in the ring and whose destination lies in one of `n` address ranges (a merged chain's members' compute buffers), records + bytes:
+// what mi_io_replay stages again when the chain is rejected half-way and its members repeat the step (their inputs' memory may have been reused by then)
+struct mi_io_saved { std::vector<mi_io_rec> recs; std::vector<char> data; };
+void mi_io_snapshot(int device, const char * const * base, const size_t * size, int n, mi_io_saved & out);
+void mi_io_replay(int device, const mi_io_saved & s);
 char * mi_mirror_dev(mi_backend_ctx * b);
 void mi_mirror_invalidate(int device, const void * p, size_t n);
 bool mi_mirror_read(int device, const void * src, void * dst, size_t size);

@@ -104,6 +104,18 @@ bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi_batch_
         // (graph_compute is an asynchronous entry point)
         if (b->batch_wait_stream) (void) hipStreamWaitEvent(bs, b->batch_wait_stream, 0);
     }
+    // the members' graph inputs (token id, position, mask: a few hundred bytes per state), kept until the chain is out: ggml's graph allocator may hand an
+    // input's memory to a later node of the same graph, so a step that is repeated after a partial chain must find its inputs staged again
+    mi_io_saved inputs;
+    {
+        const char * base[MI355X_MAX_COLS]; size_t size[MI355X_MAX_COLS]; int nr = 0;
+        for (int c = 0; c < n; c++) {
+            const ggml_tensor * t0 = cs.g[c]->nodes[0];
+            ggml_backend_buffer_t buf = t0->view_src ? t0->view_src->buffer : t0->buffer;
+            if (buf) { base[nr] = (const char *) ggml_backend_buffer_get_base(buf); size[nr] = ggml_backend_buffer_get_size(buf); nr++; }
+        }
+        mi_io_snapshot(b0->device, base, size, nr, inputs);
+    }
     mi_io_order_stream(b0->device, ln.io, bs);                // every member's graph inputs leave with one scatter launch at the head of the chain
     const int rc = mi_walk_batch(ln.k, cs);
     if (rc != 0) {
@@ -116,10 +128,12 @@ bool mi_compute_batch(mi_batch_group & grp, mi_batch_group::lane & ln, mi_batch_
             return false;
         }
         // a kernel rejected the chain half-way (a shape or alignment only its launch code knows): what was launched has written nothing a
-        // repeat would not write again (activations, this position's KV rows), so every member runs its step again on its own chain
+        // repeat would not write again (activations, this position's KV rows) — except, possibly, over the memory of graph inputs the allocator
+        // reuses for later nodes: those are staged again from the copy taken above.  Every member then runs its step again on its own chain
         // once the partial chain has drained, and this graph shape stops batching for these states
         GGML_LOG_WARN("ggml-mi355x: cross-state batch rejected mid-chain (rc=%d %s): %d states repeat the step on their own chains\n", rc, mi355x_last_error(), n);
         { std::lock_guard<std::mutex> sl(grp.sig_m); grp.sig_nodes = 0; grp.sig_w = nullptr; }
+        mi_io_replay(b0->device, inputs);                     // (pending again: the first member's own chain scatters them at its head, the others' streams wait for that flush)
         for (int c = 0; c < n; c++) {
             mem[c]->b->no_batch_nodes = mem[c]->g->n_nodes; mem[c]->b->sig_nodes = 0;
             mem[c]->status = mi_compute_own(mem[c]->b, mem[c]->g);
@@ -149,7 +163,9 @@ ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     // More than 8 columns travel as images of 8 (mi355x_kernels.h: MI355X_IMG_COLS): the weights are still read once per chain step.
     static const int env_cols = getenv("GGML_MI355X_BATCH_COLS") ? std::max(2, std::min(MI355X_MAX_COLS, atoi(getenv("GGML_MI355X_BATCH_COLS")))) : 0;
     mi_batch_group & grp = g_batch[b->device];
-    mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS };
+    // two whisper_contexts on one device (two copies of the weights, or two different models) never share a chain: the waiting set is partitioned by
+    // this signature when a leader gathers its columns (a mixed set used to fall back to one chain per state on EVERY step)
+    mi_batch_member me = { b, cgraph, 0, GGML_STATUS_SUCCESS, cgraph->n_nodes, cgraph->nodes[cgraph->n_nodes - 1]->src[0]->data };
     std::unique_lock<std::mutex> lk(grp.m);
     if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
     constexpr int split_pct = 60, split_min = 4;
@@ -202,7 +218,11 @@ ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
         mi_batch_member * mem[MI355X_MAX_COLS];
         int n = 0;
         const int max_cols = cols_cap();
-        while (n < max_cols && !grp.waiting.empty()) { mem[n] = grp.waiting.front(); mem[n]->state = 1; mem[n]->b->in_flight = true; grp.waiting.erase(grp.waiting.begin()); n++; }
+        for (size_t i = 0; n < max_cols && i < grp.waiting.size(); ) {
+            mi_batch_member * w = grp.waiting[i];
+            if (n > 0 && (w->sig_nodes != mem[0]->sig_nodes || w->sig_w != mem[0]->sig_w)) { i++; continue; }      // another model: it leads (or joins) a chain of its own
+            mem[n] = w; w->state = 1; w->b->in_flight = true; grp.waiting.erase(grp.waiting.begin() + i); n++;
+        }
         mi_batch_group::lane & ln = grp.lanes[lane];
         ln.busy = true; grp.lane_cols[lane] = n;
         lk.unlock();

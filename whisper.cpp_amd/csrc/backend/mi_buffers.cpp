@@ -336,6 +336,24 @@ void mi_span_drain(mi_backend_ctx * b) {          // all pending pairs must have
     b->span_pending = 0;
 }
 
+void mi_io_snapshot(int device, const char * const * base, const size_t * size, int n, mi_io_saved & out) {
+    out.recs.clear(); out.data.clear();
+    mi_io_ctx & io = g_io[device];
+    if (!io.ok) return;
+    std::lock_guard<std::mutex> lk(io.mtx);
+    for (const mi_io_rec & r : io.pending) {
+        bool mine = false;
+        for (int i = 0; i < n && !mine; i++) mine = (const char *) r.dst >= base[i] && (const char *) r.dst + r.size <= base[i] + size[i];
+        if (!mine) continue;
+        out.recs.push_back({ r.dst, (uint32_t) out.data.size(), r.size });
+        out.data.insert(out.data.end(), io.pinned + r.off, io.pinned + r.off + r.size);
+    }
+}
+void mi_io_replay(int device, const mi_io_saved & s) {
+    for (const mi_io_rec & r : s.recs)
+        if (!mi_io_upload(device, r.dst, s.data.data() + r.off, r.size)) GGML_ABORT("ggml-mi355x: re-staging the graph inputs of a rejected chain failed");
+}
+
 void mi_io_order_stream(int device, mi_io_marks & mk, hipStream_t cs) {
     mi_io_ctx & io = g_io[device];
     const uint64_t seq = io.ok ? io.seq.load() : 0;

@@ -5,7 +5,10 @@
 // multi-GPU weight distribution: replicas are independent streams, the only exchange is the ONE-TIME copy
 // of rank 0's WEIGHTS buffers into the identically laid out buffers of the other replicas (every context allocates the same
 // tensors in the same order, src/whisper.cpp:1685-1859, so buffer i has the same size everywhere — checked).  Two transports:
-//   * one process, several devices   : hipMemcpyPeerAsync (xGMI peer copy)                  ggml_backend_mi355x_broadcast_weights_peer
+//   * one process, several devices   : RCCL — one communicator per device (ncclCommInitAll), ONE grouped ncclBroadcast per weights
+//     buffer from the first device (the reference's own in-process pattern: ggml-cuda.cu:1188 ncclCommInitAll, :1027-1030 grouped
+//     collectives)                                                                           ggml_backend_mi355x_broadcast_weights_rccl_group
+//     or, only when asked for, hipMemcpyPeerAsync (xGMI peer copy)                           ggml_backend_mi355x_broadcast_weights_peer
 //   * one process per device (torchrun): RCCL ncclBroadcast on a communicator built here from a 128-byte unique id that the host
 //     harness hands to every rank (librccl.so is dlopen()ed: the plugin does not link it)   ggml_backend_mi355x_broadcast_weights_rccl
 // Either way every buffer is then check-summed on the device (mi355x_checksum) and compared with the source's: a replica that does
@@ -48,6 +51,9 @@ struct mi_rccl_api {
     void * h = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*GroupStart)(void) = nullptr;
+    ncclResult_t (*GroupEnd)(void) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -61,11 +67,14 @@ static mi_rccl_api * mi_rccl() {
         if (!api.h) return;
         api.GetUniqueId    = (decltype(api.GetUniqueId))    dlsym(api.h, "ncclGetUniqueId");
         api.CommInitRank   = (decltype(api.CommInitRank))   dlsym(api.h, "ncclCommInitRank");
+        api.CommInitAll    = (decltype(api.CommInitAll))    dlsym(api.h, "ncclCommInitAll");
+        api.GroupStart     = (decltype(api.GroupStart))     dlsym(api.h, "ncclGroupStart");
+        api.GroupEnd       = (decltype(api.GroupEnd))       dlsym(api.h, "ncclGroupEnd");
         api.CommDestroy    = (decltype(api.CommDestroy))    dlsym(api.h, "ncclCommDestroy");
         api.Broadcast      = (decltype(api.Broadcast))      dlsym(api.h, "ncclBroadcast");
         api.AllReduce      = (decltype(api.AllReduce))      dlsym(api.h, "ncclAllReduce");
         api.GetErrorString = (decltype(api.GetErrorString)) dlsym(api.h, "ncclGetErrorString");
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.Broadcast || !api.AllReduce) { dlclose(api.h); api.h = nullptr; }
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommInitAll || !api.GroupStart || !api.GroupEnd || !api.CommDestroy || !api.Broadcast || !api.AllReduce) { dlclose(api.h); api.h = nullptr; }
     });
     return api.h ? &api : nullptr;
 }
@@ -122,6 +131,63 @@ int ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, d
     if (src_device == dst_device) return -2;
     mi_shadows_drop(dst_device, nullptr);
     return mi_copy_verify(src_device, dst_device, mi_weight_list(src_device), mi_weight_list(dst_device), stats);
+}
+
+// ONE process, n devices (the form `python bench.py --gpus N` and mi355x_host_run use): one RCCL communicator per device from
+// ncclCommInitAll, then per weights buffer ONE grouped ncclBroadcast (ncclGroupStart .. one call per rank .. ncclGroupEnd) from
+// devices[0] into the same-index buffer of every other device, each rank on its own non-blocking stream; afterwards every buffer of every
+// device is check-summed on its device and compared with devices[0]'s.  n == 1 is a valid world (communicator, broadcast and verification
+// all run; nothing moves).  stats[0..5] = bytes delivered (size x (n - 1)), seconds of the broadcasts alone, buffers, verified (1/0),
+// seconds of ncclCommInitAll, ranks.  Returns 0, -1 RCCL unavailable / failed, -2 layout differs between devices, -4 checksum mismatch.
+int ggml_backend_mi355x_broadcast_weights_rccl_group(const int * devices, int n, double * stats) {
+    if (stats) for (int i = 0; i < 6; i++) stats[i] = 0;
+    mi_rccl_api * r = mi_rccl();
+    if (!r || n < 1 || n > MI_MAX_DEVICES || !devices) return -1;
+    for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (devices[a] == devices[b]) return -2;      // RCCL: one rank per device
+    std::vector<std::vector<mi_weight_rec>> B(n);
+    for (int k = 0; k < n; k++) {
+        mi_shadows_drop(devices[k], nullptr);
+        if (hipSetDevice(devices[k]) != hipSuccess) return -1;
+        mi_io_drain(devices[k]); (void) hipDeviceSynchronize();
+        B[k] = mi_weight_list(devices[k]);
+    }
+    if (B[0].empty()) return -2;
+    for (int k = 1; k < n; k++) {
+        if (B[k].size() != B[0].size()) return -2;
+        for (size_t i = 0; i < B[0].size(); i++) if (B[k][i].size != B[0][i].size) return -2;
+    }
+    std::vector<ncclComm_t> comms(n, nullptr);
+    std::vector<hipStream_t> st(n, nullptr);
+    const double ti = now_ms();
+    if (r->CommInitAll(comms.data(), n, devices) != ncclSuccess) return -1;
+    const double init_s = (now_ms() - ti) * 1e-3;
+    int rc = 0;
+    for (int k = 0; k < n && rc == 0; k++) if (hipSetDevice(devices[k]) != hipSuccess || hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) != hipSuccess) rc = -1;
+    double bytes = 0, secs = 0;
+    if (rc == 0) {
+        const double t0 = now_ms();
+        for (size_t i = 0; i < B[0].size() && rc == 0; i++) {
+            if (r->GroupStart() != ncclSuccess) { rc = -1; break; }
+            for (int k = 0; k < n; k++) if (r->Broadcast(B[k][i].base, B[k][i].base, B[0][i].size, ncclUint8, 0, comms[k], st[k]) != ncclSuccess) rc = -1;
+            if (r->GroupEnd() != ncclSuccess) rc = -1;
+            bytes += (double) B[0][i].size * (n - 1);
+        }
+        for (int k = 0; k < n; k++) if (hipSetDevice(devices[k]) != hipSuccess || hipStreamSynchronize(st[k]) != hipSuccess) rc = -1;
+        secs = (now_ms() - t0) * 1e-3;
+    }
+    bool verified = false;
+    if (rc == 0) {
+        std::vector<uint64_t> c0;
+        verified = mi_checksums(devices[0], B[0], c0) == 0;
+        for (int k = 1; k < n && verified; k++) { std::vector<uint64_t> ck; verified = mi_checksums(devices[k], B[k], ck) == 0 && ck == c0; }
+        if (!verified) rc = -4;
+    }
+    for (int k = 0; k < n; k++) {
+        if (st[k]) { (void) hipSetDevice(devices[k]); (void) hipStreamDestroy(st[k]); }
+        if (comms[k]) (void) r->CommDestroy(comms[k]);
+    }
+    if (stats) { stats[0] = bytes; stats[1] = secs; stats[2] = (double) B[0].size(); stats[3] = verified ? 1 : 0; stats[4] = init_s; stats[5] = n; }
+    return rc;
 }
 
 // n_replicas contexts created one after the other on ONE device (a one-GPU machine standing in for n GPUs, so that the

@@ -97,6 +97,7 @@ std::vector<float> g_last_logits;
 std::mutex g_last_mtx;
 
 typedef int  (*bcast_peer_fn)(int, int, double *);
+typedef int  (*bcast_rccl_group_fn)(const int *, int, double *);
 typedef void (*defer_fn)(int);
 typedef int  (*clone_fn)(int, int, double *);
 typedef void (*set_batching_fn)(int);
@@ -224,11 +225,23 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
         double st[4] = { 0, 0, 0, 0 };
         const int rc = cl(cfg->first_device, nd, st);
         out->bcast_bytes = st[0]; out->bcast_seconds = st[1]; out->bcast_buffers = (int) st[2]; out->bcast_verified = rc == 0 && st[3] == 1;
+        out->bcast_transport = 3; out->bcast_ranks = 1;
         if (!out->bcast_verified) { cleanup(); return fail(4, "weight copy between the replicas of one device failed or could not be verified (rc " + std::to_string(rc) + ")"); }
+    } else if (cfg->use_gpu && cfg->skip_payloads && !one_dev && ((cfg->transport == 0 && nd > 1) || cfg->transport == 2)) {
+        // RCCL; transport = 2 also with ONE context (a world of one): the communicator, the grouped broadcast and the verification run on whatever hardware there is
+        bcast_rccl_group_fn bc = (bcast_rccl_group_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_broadcast_weights_rccl_group");
+        if (!bc) { cleanup(); return fail(4, "plugin has no ggml_backend_mi355x_broadcast_weights_rccl_group"); }
+        std::vector<int> devs(nd);
+        for (int r = 0; r < nd; r++) devs[r] = device_of(r);
+        double st[6] = { 0, 0, 0, 0, 0, 0 };
+        const int rc = bc(devs.data(), nd, st);
+        out->bcast_bytes = st[0]; out->bcast_seconds = st[1]; out->bcast_buffers = (int) st[2]; out->bcast_verified = rc == 0 && st[3] == 1;
+        out->bcast_setup_seconds = st[4]; out->bcast_ranks = (int) st[5]; out->bcast_transport = 1;
+        if (!out->bcast_verified) { cleanup(); return fail(4, "RCCL weight broadcast failed or could not be verified (rc " + std::to_string(rc) + (rc == -1 ? ": librccl not loadable or a collective failed; transport = 1 selects peer copies" : "") + ")"); }
     } else if (skip) {
         bcast_peer_fn bc = (bcast_peer_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_broadcast_weights_peer");
         if (!bc) { cleanup(); return fail(4, "plugin has no ggml_backend_mi355x_broadcast_weights_peer"); }
-        out->bcast_verified = 1;
+        out->bcast_verified = 1; out->bcast_transport = 2; out->bcast_ranks = nd;
         for (int r = 1; r < nd; r++) {
             double st[4] = { 0, 0, 0, 0 };
             const int rc = bc(cfg->first_device, cfg->first_device + r, st);
@@ -248,7 +261,8 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
     const int total = nd * ns;
     gate g; g.n = total + 1;
     std::atomic<int> errors{0};
-    std::vector<double> t_end(total, 0.0);
+    std::vector<double> t_end(total, 0.0), t_enc(total, 0.0), t_dec(total, 0.0);
+    std::atomic<bool> timed{false};
     std::vector<std::vector<float>> last(total);
     std::vector<std::thread> th;
     for (int r = 0; r < nd; r++) for (int s = 0; s < ns; s++) {
@@ -261,7 +275,11 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
             if (whisper_set_mel_with_state(ctx, st, mel.data(), n_len, n_mels) != 0) errors++;
             std::vector<whisper_token> tok(8, 0);
             auto chunk = [&] {
+                const double te0 = now_s();
                 if (whisper_encode_with_state(ctx, st, 0, cfg->n_threads) != 0) { errors++; return; }
+                const double te1 = now_s();
+                struct dec_timer { double & acc; double t0; bool on; ~dec_timer() { if (on) acc += now_s() - t0; } } dt{ t_dec[id], te1, timed.load() };
+                if (dt.on) t_enc[id] += te1 - te0;
                 whisper_token cur = 0;
                 for (int i = 0; i < cfg->n_decode; i++) {
                     if (cfg->device_greedy) tok[0] = cur;
@@ -281,12 +299,13 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
                 }
             };
             for (int i = 0; i < cfg->warmup; i++) chunk();
-            g.arrive_and_wait();                       // everybody warm: start together
+            g.arrive_and_wait();                       // everybody warm: start together (the main thread has set `timed` before it arrived)
             for (int i = 0; i < cfg->steps; i++) chunk();
             t_end[id] = now_s();
             if (cfg->n_decode > 0) { const float * l = whisper_get_logits_from_state(st); if (l) last[id].assign(l, l + n_vocab); }
         });
     }
+    timed.store(true);
     g.arrive_and_wait();
     const double t0 = now_s();
     for (auto & t : th) t.join();
@@ -304,5 +323,9 @@ extern "C" int mi355x_host_run(const mi355x_host_config * cfg, mi355x_host_resul
     out->wall_s = t1 - t0;
     out->chunks_per_s = (double) total * cfg->steps / out->wall_s;
     out->ms_per_chunk_per_stream = out->wall_s * 1e3 / cfg->steps;
+    double se = 0, sd = 0;
+    for (int i = 0; i < total; i++) { se += t_enc[i]; sd += t_dec[i]; }
+    out->encode_ms = se * 1e3 / ((double) total * cfg->steps);
+    out->decode_ms_per_token = cfg->n_decode > 0 ? sd * 1e3 / ((double) total * cfg->steps * cfg->n_decode) : 0.0;
     return 0;
 }

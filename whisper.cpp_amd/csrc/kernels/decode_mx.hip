@@ -334,7 +334,8 @@ static int mx_emit(mi355x_ctx * ctx, const MXArgs & k, dim3 grid, dim3 block, ui
     static std::atomic<bool> attr_set[64];
     const int dev = ctx->device & 63;
     if (lds > 64 * 1024 && !attr_set[dev].load()) {
-        if (hipFuncSetAttribute((const void *) k_gemv_mx<WT, LS, NU, CG, RTP, NSEG1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
+        // the ceiling, not this launch's size: `lds` grows with K (68.8 KB at K = 1280 ... 110 KB at 2048) and the attribute is set once per instantiation and device
+        if (hipFuncSetAttribute((const void *) k_gemv_mx<WT, LS, NU, CG, RTP, NSEG1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess) { (void) hipGetLastError(); return MI355X_E_UNSUPPORTED; }
         attr_set[dev].store(true);
     }
     return emit(ctx, LS == 8 ? "vocab_mx" : "gemv_mx", k_gemv_mx<WT, LS, NU, CG, RTP, NSEG1>, grid, block, lds, k, bytes, flops);

@@ -29,15 +29,31 @@ class GpuFrontEnd:
         hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         hip.hipFree.argtypes = [C.c_void_p]
+        self._set_device()
         self.ctx = ka.Ctx(device)
-        self.bufs = []
+        self.bufs = {}                     # role -> (pointer, bytes): reused by later calls, grown when a call needs more
 
-    def _dev(self, nbytes: int) -> C.c_void_p:
+    def _set_device(self):
+        if self.hip.hipSetDevice(self.device) != 0:
+            raise RuntimeError(f"hipSetDevice({self.device}) failed")
+
+    def _dev(self, role: str, nbytes: int) -> C.c_void_p:
+        have = self.bufs.get(role)
+        if have and have[1] >= nbytes:
+            return have[0]
+        if have:
+            self.hip.hipFree(have[0])
+            del self.bufs[role]
         p = C.c_void_p()
         if self.hip.hipMalloc(C.byref(p), nbytes) != 0:
-            raise RuntimeError("hipMalloc failed")
-        self.bufs.append(p)
+            raise RuntimeError(f"hipMalloc({nbytes}) failed")
+        self.bufs[role] = (p, nbytes)
         return p
+
+    def _copy(self, dst, src, nbytes: int, kind: int, what: str):
+        rc = self.hip.hipMemcpy(dst, src, nbytes, kind)
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpy ({what}, {nbytes} bytes) failed: hipError {rc}")
 
     def log_mel(self, pcm: np.ndarray, filters: np.ndarray, reps: int = 3):
         """(mel [n_mel, n_len] float32 on the host, best-of-`reps` milliseconds of the device pass: kernel launches + synchronize)"""
@@ -45,10 +61,10 @@ class GpuFrontEnd:
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         filters = np.ascontiguousarray(filters, dtype=np.float32)
         n_mel, n_len = filters.shape[0], int(L.mi355x_log_mel_n_len(len(pcm)))
-        d_pcm, d_f, d_mel = self._dev(pcm.nbytes), self._dev(filters.nbytes), self._dev(n_mel * n_len * 4)
-        self.hip.hipSetDevice(self.device)
-        self.hip.hipMemcpy(d_pcm, pcm.ctypes.data, pcm.nbytes, 1)            # hipMemcpyHostToDevice: the PCM is resident in HBM when the timed pass starts
-        self.hip.hipMemcpy(d_f, filters.ctypes.data, filters.nbytes, 1)
+        self._set_device()                                                   # before any allocation: the buffers must live on self.device
+        d_pcm, d_f, d_mel = self._dev("pcm", pcm.nbytes), self._dev("filters", filters.nbytes), self._dev("mel", n_mel * n_len * 4)
+        self._copy(d_pcm, pcm.ctypes.data, pcm.nbytes, 1, "PCM to device")   # hipMemcpyHostToDevice: the PCM is resident in HBM when the timed pass starts
+        self._copy(d_f, filters.ctypes.data, filters.nbytes, 1, "filters to device")
         best = None
         for _ in range(reps):
             self.ctx.sync()
@@ -58,11 +74,11 @@ class GpuFrontEnd:
             dt = (time.perf_counter() - t0) * 1e3
             best = dt if best is None else min(best, dt)
         mel = np.empty((n_mel, n_len), dtype=np.float32)
-        self.hip.hipMemcpy(mel.ctypes.data, d_mel, mel.nbytes, 2)             # hipMemcpyDeviceToHost (whisper_set_mel takes host memory: include/whisper.h)
+        self._copy(mel.ctypes.data, d_mel, mel.nbytes, 2, "mel to host")      # hipMemcpyDeviceToHost (whisper_set_mel takes host memory: include/whisper.h)
         return mel, best
 
     def close(self):
-        for p in self.bufs:
+        for p, _ in self.bufs.values():
             self.hip.hipFree(p)
-        self.bufs = []
+        self.bufs = {}
         self.ctx.close()
