@@ -776,12 +776,14 @@ def test_plugin_model_parity_without_flash_attn(plugin_env):
     assert d["batch5"]["nmse"] < TOL_BATCH and d["batch48"]["nmse"] < TOL_BATCH, d
 
 
+@pytest.mark.parametrize("mmq", ["0", "2"])
 @pytest.mark.parametrize("arch,qtype", [("base.en", "q5_0"), ("large-v3-2l", "q8_0"), ("base.en", "q4_k")])
-def test_plugin_model_parity_with_the_f16_gemm(plugin_env, arch, qtype):
-    """GGML_MI355X_MMQ=0 — the one kept alternative path: quantized products with more than 8 columns on the f16 MFMA ring over one-time f16
-    copies of the weights instead of the int8 tile GEMM (faster encode, f16(d*q) products instead of the CPU's integer sums) — is a TESTED
-    configuration: whole model, STRICT, same tolerances (round 5: the regression A-B ran it and found it broken by a guard added the same day)"""
-    d = _model_parity(plugin_env, arch, qtype, exact=False, steps="32", extra_env={"GGML_MI355X_MMQ": "0"})
+def test_plugin_model_parity_with_the_other_gemm_families(plugin_env, arch, qtype, mmq):
+    """GGML_MI355X_MMQ selects which GEMM family takes quantized weights x wide activations.  The default (1, round 6) is by width: k_gemm_dq —
+    quantized planes unpacked per workgroup into LDS, f16 MFMA — from 1024 columns on (encoder, cross-K/V), the int8 tile GEMM below.  The two kept
+    alternatives are TESTED configurations, whole model, STRICT, same tolerances: 0 = f16 copies of the weights through the LDS-DMA ring (rounds 2-3),
+    2 = the int8 tile GEMM at every width (rounds 4-5: the CPU's own integer sums also in the encoder)."""
+    d = _model_parity(plugin_env, arch, qtype, exact=False, steps="32", extra_env={"GGML_MI355X_MMQ": mmq})
     s = d["single"]
     assert s["worst_nmse"] < TOL_SINGLE, s
     for st in d["steps"]:
@@ -1066,7 +1068,9 @@ def test_bench_smoke():
                         "--gpus", "1", "--transport", "rccl"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines[:3]                  # ONE line on stdout, the JSON object (RCCL's own banner is kept off the host's stdout by the plugin)
+    d = json.loads(lines[-1])
     # --gpus 1 --transport rccl: the one-process distribution path as a world of one — in-process communicator, grouped
     # ncclBroadcast of every weights buffer, device-side checksums; the N > 1 line carries the same object with ranks = N
     wb = d["weight_broadcast"]

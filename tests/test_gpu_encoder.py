@@ -181,3 +181,113 @@ def test_gemm_with_an_f16_destination_equals_the_rounded_f32_result(gpu, M, K, T
     want = y32.cpu().numpy().astype(np.float16)
     got = y16.cpu().numpy()
     assert np.abs(want.astype(np.float32)).max() > 0.1 and np.array_equal(got.view(np.uint16), want.view(np.uint16))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# k_gemm_dq (round 6): quantized weight planes unpacked per workgroup into LDS + f16 activations by LDS-DMA, f16 MFMA
+# ---------------------------------------------------------------------------------------------------------------
+DQ_GEMM, DQ_BN = 4, 5          # mi355x_kernels.h: mi355x_test_option values
+QT = {"q4_0": 2, "q5_0": 6, "q8_0": 8, "q4_K": 12}
+
+
+def _rand_planar(torch, ka, tid, N, K, seed):
+    """random weight planes (any bit pattern with finite scales is a legal block) in the kernel library's planar layout"""
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    nbytes = N * ka.row_bytes(tid, K)
+    w = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda:0", generator=g)
+    if tid == 12:
+        nsb = N * K // 256
+        w[nbytes - nsb * 4:] = (torch.rand(nsb * 2, device="cuda:0", generator=g) * 0.02 + 0.001).half().view(torch.uint8)
+    else:
+        nblk = N * K // 32
+        w[nbytes - nblk * 2:] = ((torch.rand(nblk, device="cuda:0", generator=g) - 0.5) * 0.04).half().view(torch.uint8)
+    return w
+
+
+@pytest.mark.parametrize("t", list(QT))
+@pytest.mark.parametrize("K,N,T", [(1280, 1280, 1500), (1280, 320, 333), (5120, 256, 130), (512, 384, 64)])
+def test_dequant_to_lds_gemm_equals_the_register_staged_kernel_and_the_ring_on_the_f16_copy(gpu, t, K, N, T):
+    """k_gemm_dq against (a) k_gemm_mfma, the register-staged kernel that dequantizes the same planes in its loop (MI355X_OPT_DQ_GEMM = 0) and
+    (b) k_gemm_f16_ring on mi355x_dequant_f16's copy of the weight: the same f16 values, the same fragment layout, MFMA and K order — every
+    output word equal, for both token-tile widths (128 / 256 columns: 4 / 8 waves), ragged last tiles in both dimensions (T = 1500, 333, 130;
+    N = 320), bias + scale + residual epilogues and F16 destinations.  That the values ARE the reference's dequantized weights is
+    tests/test_gpu.py::test_f16_weight_copy_is_bit_identical_to_fused_dequant; against the oracle's mul_mat: test_mul_mat_vs_oracle."""
+    ctx, ka, torch = gpu
+    tid = QT[t]
+    if tid == 12 and K % 256:
+        pytest.skip("Q4_K needs K % 256 == 0")
+    L = ka.lib()
+    w = _rand_planar(torch, ka, tid, N, K, 5 + tid + K)
+    g = torch.Generator(device="cuda:0").manual_seed(99)
+    act = torch.randn((T, K), device="cuda:0", generator=g).half()
+    bias = torch.randn(N, device="cuda:0", generator=g)
+    res = torch.randn((T, N), device="cuda:0", generator=g)
+    sh = torch.zeros((N, K), dtype=torch.float16, device="cuda:0")
+    tw = ka.tensor(w.data_ptr(), tid, [K, N])
+    ctx.check(L.mi355x_dequant_f16(ctx.h, C.byref(tw), sh.data_ptr()), "dequant")
+    ts = ka.tensor(sh.data_ptr(), ka.F16, [K, N])
+    ep = ka.Epilogue(bias.data_ptr(), 0.5, 1, 0, res.data_ptr(), N * 4)
+
+    def run(tens, f16_dst):
+        y = torch.zeros((T, N), dtype=torch.float16 if f16_dst else torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.check(L.mi355x_gemm_f16act(ctx.h, C.byref(tens), act.data_ptr(), K, T, y.data_ptr(), N * (2 if f16_dst else 4), ka.F16 if f16_dst else ka.F32,
+                                       None if f16_dst else C.byref(ep)), "gemm")
+        ctx.sync()
+        return y.cpu().numpy()
+
+    for f16_dst in (False, True):
+        ring = run(ts, f16_dst)
+        with opt(ka, DQ_GEMM, 0):
+            staged = run(tw, f16_dst)
+        assert np.isfinite(ring.astype(np.float32)).all() and np.abs(ring.astype(np.float32)).max() > 1e-3
+        view = np.uint16 if f16_dst else np.uint32
+        assert np.array_equal(staged.view(view), ring.view(view))
+        for bn in (128, 256):
+            with opt(ka, DQ_BN, bn):
+                got = run(tw, f16_dst)
+            bad = np.argwhere(got.view(view) != ring.view(view))
+            assert bad.size == 0, (bn, f16_dst, bad[:4].tolist(), len(bad))
+
+
+def test_grouped_dequant_to_lds_gemm_and_its_activation_writing_epilogue(gpu):
+    """the Q / K / V group of an encoder layer at full size (three members on the same activations, one launch, 8-wave tiles) equals the
+    three single launches word for word; fc1 + bias + GELU whose epilogue leaves fc2's f16(d*q) activations equals the two-pass form
+    (mi355x_gemm_f16act + mi355x_prep_act) — both through k_gemm_dq"""
+    ctx, ka, torch = gpu
+    L = ka.lib()
+    tid, K, N, T = 6, 1280, 1280, 1500
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    ws = [_rand_planar(torch, ka, tid, N, K, 40 + i) for i in range(3)]
+    act = torch.randn((T, K), device="cuda:0", generator=g).half()
+    bias = torch.randn(N, device="cuda:0", generator=g)
+
+    def launch(i, y):
+        ep = ka.Epilogue(bias.data_ptr() if i != 1 else None, 0.25, 1 if i == 1 else 0)
+        ctx.check(L.mi355x_gemm_f16act(ctx.h, C.byref(ka.tensor(ws[i].data_ptr(), tid, [K, N])), act.data_ptr(), K, T, y.data_ptr(), N * 4, ka.F32, C.byref(ep)), "gemm")
+
+    single = [torch.zeros((T, N), device="cuda:0") for _ in range(3)]
+    grouped = [torch.zeros((T, N), device="cuda:0") for _ in range(3)]
+    torch.cuda.synchronize()
+    for i in range(3):
+        launch(i, single[i]); ctx.sync()
+    n0 = L.mi355x_eager_count(ctx.h)
+    for i in range(3):
+        launch(i, grouped[i])
+    ctx.sync()
+    assert L.mi355x_eager_count(ctx.h) - n0 == 1
+    for a, b in zip(single, grouped):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 1e-3 and torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # fc1 -> fc2's activations
+    M = 5120
+    w1 = _rand_planar(torch, ka, tid, M, K, 77)
+    b1 = torch.randn(M, device="cuda:0", generator=g) * 0.1
+    ep = ka.Epilogue(b1.data_ptr(), 0.0, 0, 1)
+    y = torch.zeros((T, M), device="cuda:0"); p2 = torch.zeros((T, M), dtype=torch.float16, device="cuda:0"); p1 = torch.zeros_like(p2)
+    torch.cuda.synchronize()
+    tw = ka.tensor(w1.data_ptr(), tid, [K, M])
+    ctx.check(L.mi355x_gemm_f16act(ctx.h, C.byref(tw), act.data_ptr(), K, T, y.data_ptr(), M * 4, ka.F32, C.byref(ep)), "fc1")
+    ctx.check(L.mi355x_prep_act(ctx.h, y.data_ptr(), M * 4, 0, p1.data_ptr(), M, T, 1), "prep")
+    ctx.check(L.mi355x_gemm_f16act_prep(ctx.h, C.byref(tw), act.data_ptr(), K, T, None, M * 4, C.byref(ep), p2.data_ptr()), "fc1 + prep")
+    ctx.sync()
+    assert float(p1.float().abs().max()) > 1e-3 and torch.equal(p1.view(torch.int16), p2.view(torch.int16))

@@ -299,7 +299,8 @@ int next_real(const ggml_cgraph * g, int i);
 bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c);
 int mode_for(ggml_type t);
 bool mi_mmq_on();
-int rows_mode_for(const ggml_tensor * w, int64_t K);
+int mi_mmq_mode();
+int rows_mode_for(const ggml_tensor * w, int64_t K, int64_t T);
 const void * mi_shadow_get(mi_backend_ctx * b, const ggml_tensor * w, const mi355x_tensor & mw);
 int mi_act_reserve(mi_backend_ctx * b, size_t need, bool alt = false);
 bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, const ggml_tensor * x, int & mode_out);

@@ -35,6 +35,7 @@ static int mi_checksums(int device, const std::vector<mi_weight_rec> & bufs, std
 }
 
 #include <dlfcn.h>
+#include <unistd.h>
 // RCCL is dlopen()ed; only a handful of its types are needed here.  With the RCCL headers installed they come from there, on a ROCm
 // install without them the same (ABI-stable, nccl.h) declarations are made locally so that the plugin still builds.
 #if defined(__has_include) && __has_include(<rccl/rccl.h>)
@@ -46,6 +47,14 @@ typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5 } ncclDataType_t;
 typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
 #endif
+
+// RCCL announces itself on STDOUT when a communicator is created ("Librccl path : ..."): a plugin must not write into its host's stdout
+// (bench.py's one JSON line, whisper-cli's transcript).  While a communicator is being set up, file descriptor 1 points at stderr.
+struct mi_stdout_to_stderr {
+    int saved = -1;
+    mi_stdout_to_stderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void) dup2(2, 1); }
+    ~mi_stdout_to_stderr() { if (saved >= 0) { fflush(stdout); (void) dup2(saved, 1); close(saved); } }
+};
 
 struct mi_rccl_api {
     void * h = nullptr;
@@ -59,22 +68,32 @@ struct mi_rccl_api {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char * (*GetErrorString)(ncclResult_t) = nullptr;
 };
+static std::string g_rccl_why;           // why no usable librccl was found (written once, under the call_once)
 static mi_rccl_api * mi_rccl() {
     static mi_rccl_api api;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char * n : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) { api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.h) break; }
-        if (!api.h) return;
-        api.GetUniqueId    = (decltype(api.GetUniqueId))    dlsym(api.h, "ncclGetUniqueId");
-        api.CommInitRank   = (decltype(api.CommInitRank))   dlsym(api.h, "ncclCommInitRank");
-        api.CommInitAll    = (decltype(api.CommInitAll))    dlsym(api.h, "ncclCommInitAll");
-        api.GroupStart     = (decltype(api.GroupStart))     dlsym(api.h, "ncclGroupStart");
-        api.GroupEnd       = (decltype(api.GroupEnd))       dlsym(api.h, "ncclGroupEnd");
-        api.CommDestroy    = (decltype(api.CommDestroy))    dlsym(api.h, "ncclCommDestroy");
-        api.Broadcast      = (decltype(api.Broadcast))      dlsym(api.h, "ncclBroadcast");
-        api.AllReduce      = (decltype(api.AllReduce))      dlsym(api.h, "ncclAllReduce");
-        api.GetErrorString = (decltype(api.GetErrorString)) dlsym(api.h, "ncclGetErrorString");
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommInitAll || !api.GroupStart || !api.GroupEnd || !api.CommDestroy || !api.Broadcast || !api.AllReduce) { dlclose(api.h); api.h = nullptr; }
+        // (a host that already loaded an RCCL — PyTorch bundles one under the same soname — gets that one back from the first name: one RCCL per process)
+        for (const char * n : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so" }) {
+            (void) dlerror();
+            void * h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) { const char * e = dlerror(); g_rccl_why += std::string(n) + ": " + (e ? e : "dlopen failed") + "; "; continue; }
+            mi_rccl_api a; a.h = h;
+            const char * missing = nullptr;
+            auto sym = [&](const char * name) { void * p = dlsym(h, name); if (!p && !missing) missing = name; return p; };
+            a.GetUniqueId    = (decltype(a.GetUniqueId))    sym("ncclGetUniqueId");
+            a.CommInitRank   = (decltype(a.CommInitRank))   sym("ncclCommInitRank");
+            a.CommInitAll    = (decltype(a.CommInitAll))    sym("ncclCommInitAll");
+            a.GroupStart     = (decltype(a.GroupStart))     sym("ncclGroupStart");
+            a.GroupEnd       = (decltype(a.GroupEnd))       sym("ncclGroupEnd");
+            a.CommDestroy    = (decltype(a.CommDestroy))    sym("ncclCommDestroy");
+            a.Broadcast      = (decltype(a.Broadcast))      sym("ncclBroadcast");
+            a.AllReduce      = (decltype(a.AllReduce))      sym("ncclAllReduce");
+            a.GetErrorString = (decltype(a.GetErrorString)) dlsym(h, "ncclGetErrorString");
+            if (missing) { g_rccl_why += std::string(n) + ": no symbol " + missing + "; "; dlclose(h); continue; }
+            api = a;
+            break;
+        }
     });
     return api.h ? &api : nullptr;
 }
@@ -142,7 +161,9 @@ int ggml_backend_mi355x_broadcast_weights_peer(int src_device, int dst_device, d
 int ggml_backend_mi355x_broadcast_weights_rccl_group(const int * devices, int n, double * stats) {
     if (stats) for (int i = 0; i < 6; i++) stats[i] = 0;
     mi_rccl_api * r = mi_rccl();
-    if (!r || n < 1 || n > MI_MAX_DEVICES || !devices) return -1;
+    if (!r) { GGML_LOG_ERROR("ggml-mi355x: no usable librccl: %s\n", g_rccl_why.c_str()); return -1; }
+    if (n < 1 || n > MI_MAX_DEVICES || !devices) return -1;
+    auto nccl_fail = [&](const char * what, ncclResult_t e) { GGML_LOG_ERROR("ggml-mi355x: %s failed: %s\n", what, r->GetErrorString ? r->GetErrorString(e) : "?"); };
     for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (devices[a] == devices[b]) return -2;      // RCCL: one rank per device
     std::vector<std::vector<mi_weight_rec>> B(n);
     for (int k = 0; k < n; k++) {
@@ -159,7 +180,11 @@ int ggml_backend_mi355x_broadcast_weights_rccl_group(const int * devices, int n,
     std::vector<ncclComm_t> comms(n, nullptr);
     std::vector<hipStream_t> st(n, nullptr);
     const double ti = now_ms();
-    if (r->CommInitAll(comms.data(), n, devices) != ncclSuccess) return -1;
+    {
+        mi_stdout_to_stderr quiet;
+        const ncclResult_t e = r->CommInitAll(comms.data(), n, devices);
+        if (e != ncclSuccess) { nccl_fail("ncclCommInitAll", e); return -1; }
+    }
     const double init_s = (now_ms() - ti) * 1e-3;
     int rc = 0;
     for (int k = 0; k < n && rc == 0; k++) if (hipSetDevice(devices[k]) != hipSuccess || hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking) != hipSuccess) rc = -1;
@@ -167,12 +192,13 @@ int ggml_backend_mi355x_broadcast_weights_rccl_group(const int * devices, int n,
     if (rc == 0) {
         const double t0 = now_ms();
         for (size_t i = 0; i < B[0].size() && rc == 0; i++) {
-            if (r->GroupStart() != ncclSuccess) { rc = -1; break; }
-            for (int k = 0; k < n; k++) if (r->Broadcast(B[k][i].base, B[k][i].base, B[0][i].size, ncclUint8, 0, comms[k], st[k]) != ncclSuccess) rc = -1;
-            if (r->GroupEnd() != ncclSuccess) rc = -1;
+            ncclResult_t e = r->GroupStart();
+            if (e != ncclSuccess) { nccl_fail("ncclGroupStart", e); rc = -1; break; }
+            for (int k = 0; k < n; k++) if ((e = r->Broadcast(B[k][i].base, B[k][i].base, B[0][i].size, ncclUint8, 0, comms[k], st[k])) != ncclSuccess) { nccl_fail("ncclBroadcast", e); rc = -1; }
+            if ((e = r->GroupEnd()) != ncclSuccess) { nccl_fail("ncclGroupEnd", e); rc = -1; }
             bytes += (double) B[0][i].size * (n - 1);
         }
-        for (int k = 0; k < n; k++) if (hipSetDevice(devices[k]) != hipSuccess || hipStreamSynchronize(st[k]) != hipSuccess) rc = -1;
+        for (int k = 0; k < n; k++) if (hipSetDevice(devices[k]) != hipSuccess || hipStreamSynchronize(st[k]) != hipSuccess) { GGML_LOG_ERROR("ggml-mi355x: synchronizing the broadcast stream of device %d failed\n", devices[k]); rc = -1; }
         secs = (now_ms() - t0) * 1e-3;
     }
     bool verified = false;
@@ -212,7 +238,7 @@ int ggml_backend_mi355x_rccl_unique_id(void * out128) {
     mi_rccl_api * r = mi_rccl();
     if (!r) return -1;
     ncclUniqueId id;
-    if (r->GetUniqueId(&id) != ncclSuccess) return -1;
+    { mi_stdout_to_stderr quiet; if (r->GetUniqueId(&id) != ncclSuccess) return -1; }
     memcpy(out128, &id, sizeof(id));
     return 0;
 }
@@ -239,7 +265,9 @@ int ggml_backend_mi355x_broadcast_weights_rccl(int device, int rank, int world, 
     bool local_ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
     if (hipMalloc((void **) &d64, cap_words * 8) != hipSuccess) { d64 = nullptr; local_ok = false; (void) hipGetLastError(); }
     ncclComm_t comm = nullptr;
-    if (r->CommInitRank(&comm, world, id, rank) != ncclSuccess) {
+    ncclResult_t init_rc;
+    { mi_stdout_to_stderr quiet; init_rc = r->CommInitRank(&comm, world, id, rank); }
+    if (init_rc != ncclSuccess) {
         if (d64) (void) hipFree(d64);
         if (st) (void) hipStreamDestroy(st);
         return -1;

@@ -109,13 +109,20 @@ bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c) {
 }
 
 int mode_for(ggml_type t) { return t == GGML_TYPE_Q4_K ? 2 : (is_quant_type(t) ? 1 : 0); }
-// The int8 tile GEMM over the quantized operands (csrc/kernels/mmq.hip) takes every product of a quantized weight with more than 8
-// columns whose K it can tile: its activations are the reference's Q8_0 / Q8_K blocks as integers ("rows", prep modes 3 / 4) and its
-// A operand the planar quantized weight itself — no f16 copy of a weight is made or read.  GGML_MI355X_MMQ=0 brings back the f16 MFMA
-// path (f16(d*q) activations, f16 weight copies).
-bool mi_mmq_on() { static const bool on = env_flag("GGML_MI355X_MMQ", true); return on; }
-int rows_mode_for(const ggml_tensor * w, int64_t K) {
+// Which GEMM family takes a quantized weight x wide activations (GGML_MI355X_MMQ, default 1):
+//   1  by width: T >= MI_DQ_MIN_T columns (the encoder and the cross-K/V products: 1500) run k_gemm_dq — the weight's quantized planes unpacked
+//      per workgroup into LDS, f16(d*q) activations, f16 MFMA (gemm_mfma.hip; BASELINE.json north_star: "per-warp dequant into LDS tiles feeding
+//      MFMA fp16/bf16 where the GEMM is genuinely dense") — and narrower products (prompt, beam / batch steps beyond the mat-vec range) the int8
+//      tile GEMM over the quantized operands (mmq.hip: the CPU's own integer sums; its per-block fix-up is VALU work that costs the encoder 1-2.5 ms
+//      per chunk, profiles/r05_regress_ab.txt, and nothing at these widths).  No f16 copy of a weight is made either way.
+//   2  the int8 tile GEMM at every width (rounds 4-5; activations = the reference's Q8_0 / Q8_K blocks as integers: "rows", prep modes 3 / 4)
+//   0  f16 copies of the weights through the LDS-DMA ring (rounds 2-3)
+int mi_mmq_mode() { static const int m = [] { const char * e = getenv("GGML_MI355X_MMQ"); return e ? std::max(0, std::min(2, atoi(e))) : 1; }(); return m; }
+bool mi_mmq_on() { return mi_mmq_mode() != 0; }
+#define MI_DQ_MIN_T 1024
+int rows_mode_for(const ggml_tensor * w, int64_t K, int64_t T) {
     if (!mi_mmq_on() || !is_quant_type(w->type) || K % 128 != 0) return 0;
+    if (mi_mmq_mode() == 1 && T >= MI_DQ_MIN_T) return 0;
     return w->type == GGML_TYPE_Q4_K ? (K % 256 == 0 ? 4 : 0) : 3;
 }
 
@@ -169,7 +176,7 @@ bool mm_takes_prepared(const mi_backend_ctx * b, const ggml_tensor * mm, const g
     if (!((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && w->nb[0] == 2 && w->nb[1] % 16 == 0))) return false;
     const int mode = mode_for(w->type);
     if ((mode == 1 && K % 32) || (mode == 2 && K % 256)) return false;
-    int rmode = rows_mode_for(w, K);
+    int rmode = rows_mode_for(w, K, T);
     if (rmode && ((uintptr_t) w->data % 16)) rmode = 0;                   // (mi355x_gemm_q8act's own precondition: never promise rows it would refuse)
     mode_out = rmode ? rmode : mode;
     return true;
@@ -216,7 +223,7 @@ int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgraph * g) 
         (x->type == GGML_TYPE_F32 || x->type == GGML_TYPE_F16) &&
         ((is_quant_type(w->type) && ggml_is_contiguous(w)) || (w->type == GGML_TYPE_F16 && w->nb[0] == 2 && w->nb[1] % 16 == 0))) {
         const int mode = mode_for(w->type);
-        const int rmode = rows_mode_for(w, K);
+        const int rmode = rows_mode_for(w, K, T);
         if (rmode && ggml_is_contiguous(w)) {
             // the int8 tile GEMM on the quantized weight and the activation rows
             const int rr = mi_act_reserve(b, (size_t) T * K * 2);          // (rows need 1.25 bytes per element: the f16 size covers them)
@@ -295,7 +302,7 @@ int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgraph * g) 
             };
             // wide activations: run the GEMM on the weight's f16 copy (same values, no dequantization in the loop)
             constexpr int shadow_min_t = 128;
-            if (mode != 0 && T >= shadow_min_t) {
+            if (mode != 0 && T >= shadow_min_t && !mi_mmq_on()) {
                 if (const void * f16 = mi_shadow_get(b, w, mw)) {
                     mi355x_tensor ms = mw;
                     ms.data = (void *) f16; ms.type = MI355X_TYPE_F16;

@@ -141,6 +141,9 @@ struct GemmArgs {
     const uint16_t * gelu_tab;
     int mt, nt, per, m_major;                           // k_gemm_f16_ring: tile counts and the XCD-aware tile order (launch_ring)
     uint16_t * prep; int prep_only;                     // epilogue also writes k_prep_act(mode 1) of the result, f16 [T][M]; prep_only: no dst store
+    int ablate;                                         // k_gemm_dq, timing experiments only (MI355X_OPT_DQ_ABLATE): 1 no unpack, 2 no B DMA, 4 no MFMA, 8 no A loads
+    int lds_bytes;                                      // k_gemm_dq: dynamic LDS of this launch (the GELU table moves into LDS when it fits behind the transposition regions)
+    unsigned long long * dbg;                           // GGML_MI355X_KTIME=1: s_memtime stamps of workgroup 0, waves 0 and NW-1 (kernel anatomy, scripts/gemm_kbench.py)
 };
 
 #define BM 128
@@ -410,6 +413,94 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs & a, floatx16 (&acc
     }
 }
 
+// The same epilogue through a wave-private LDS transposition (round 6).  The MFMA's C layout gives a lane ONE token and 16 features in four runs of 4:
+// stored straight from the registers, a wave instruction touches 32 token rows with 32 contiguous bytes each (and reads the residual the same way) —
+// the stores, not the products, were 20-30 us of a 45-55 us encoder product (profiles/r06_gemm_dq_ablation.txt).  Here a wave writes each 32-feature strip
+// of its piece into its own [tokens][36 floats] LDS region and reads it back with 8 lanes per token row: bias, residual, destination and the next GEMM's
+// activations all move as whole 128-byte (64-byte for f16) lines, and a 32-feature quantization block of a token is 8 neighbouring lanes (three shuffles).
+// Per element the operations and their order are gemm_epilogue's: results are bit-identical.  Needs M % 4 == 0 and 16-byte aligned operands (caller checks).
+// `tw`: this wave's region, NT * 32 * 36 floats; LDS operations of one wave execute in order, so no barrier separates the writes from the reads.
+__device__ __forceinline__ bool gemm_epilogue_vec_ok(const GemmArgs & a) {
+    return (a.M % 4 == 0) && ((uintptr_t) a.dst % 16 == 0) && (a.dst_nb1 % 16 == 0) &&
+           (!a.residual || (((uintptr_t) a.residual % 16 == 0) && (a.res_nb1 % 16 == 0))) && (!a.bias || a.bias_t || ((uintptr_t) a.bias % 16 == 0));
+}
+__device__ __forceinline__ float gelu_win(float x, const uint16_t * __restrict__ win, const uint16_t * __restrict__ tab);
+template <int NT>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmArgs & a, floatx16 (&acc)[2][NT], int m0, int64_t n0, int wm, int wn, int WN, int lane, float * tw, const uint16_t * gelu_window = nullptr) {
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+    // the residual rows of both strips are requested before anything else: the loads may alias the stores below (an in-place residual is allowed), so
+    // left inside the loop every one of them waits for its own round trip to memory (16 dependent trips = the 16 k cycles of the fc2 / O epilogues)
+    float4 res[2][NT*4];
+    const int abl = a.ablate;
+    if (a.residual && !(abl & 256)) {
+        #pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int m = m0 + wm*64 + i*32 + c4;
+            #pragma unroll
+            for (int it = 0; it < NT*4; it++) {
+                const int64_t t = n0 + wn*WN + it*8 + rr;
+                res[i][it] = (m < a.M && t < a.T) ? *(const float4 *) (a.residual + t*a.res_nb1 + (int64_t) m*4) : make_float4(0, 0, 0, 0);
+            }
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int mb = m0 + wm*64 + i*32;
+        if (mb >= a.M) continue;                                    // wave-uniform
+        #pragma unroll
+        for (int j = 0; j < NT; j++)
+            #pragma unroll
+            for (int g = 0; g < 4; g++)
+                *(float4 *) (tw + (j*32 + l31)*36 + 8*g + 4*hf) = make_float4(acc[i][j][4*g], acc[i][j][4*g+1], acc[i][j][4*g+2], acc[i][j][4*g+3]);
+        const int m = mb + c4;
+        const bool m_ok = m < a.M;                                  // M % 4 == 0  =>  m + 3 < M
+        float4 b4 = make_float4(0, 0, 0, 0);
+        if (a.bias && !a.bias_t && m_ok) b4 = *(const float4 *) (a.bias + m);
+        if (abl & 512) continue;
+        #pragma unroll
+        for (int it = 0; it < NT*4; it++) {
+            const int row = it*8 + rr;
+            const int64_t t = n0 + wn*WN + row;
+            const float4 v4 = *(const float4 *) (tw + row*36 + c4);
+            const bool ok = m_ok && t < a.T;
+            float x[4] = { v4.x, v4.y, v4.z, v4.w };
+            if (ok) {
+                if (a.bias) {
+                    if (a.bias_t) { const float b = a.bias[t]; x[0] += b; x[1] += b; x[2] += b; x[3] += b; }
+                    else { x[0] += b4.x; x[1] += b4.y; x[2] += b4.z; x[3] += b4.w; }
+                }
+                if (a.has_scale) { x[0] *= a.scale; x[1] *= a.scale; x[2] *= a.scale; x[3] *= a.scale; }
+                if (a.gelu && !(abl & 32)) {
+                    if (gelu_window) { x[0] = gelu_win(x[0], gelu_window, a.gelu_tab); x[1] = gelu_win(x[1], gelu_window, a.gelu_tab); x[2] = gelu_win(x[2], gelu_window, a.gelu_tab); x[3] = gelu_win(x[3], gelu_window, a.gelu_tab); }
+                    else { x[0] = gelu_lut(x[0], a.gelu_tab); x[1] = gelu_lut(x[1], a.gelu_tab); x[2] = gelu_lut(x[2], a.gelu_tab); x[3] = gelu_lut(x[3], a.gelu_tab); }
+                }
+                if (a.residual && !(abl & 256)) { const float4 r4 = res[i][it]; x[0] += r4.x; x[1] += r4.y; x[2] += r4.z; x[3] += r4.w; }
+                if (!a.prep_only && !(abl & 128)) {
+                    if (a.dst_f16) *(uint2 *) (a.dst + t*a.dst_nb1 + (int64_t) m*2) = make_uint2(pack_h2(x[0], x[1]), pack_h2(x[2], x[3]));
+                    else           *(float4 *) (a.dst + t*a.dst_nb1 + (int64_t) m*4) = make_float4(x[0], x[1], x[2], x[3]);
+                }
+            }
+            if (a.prep && !(abl & 64)) {
+                // k_prep_act (mode 1) of the result: the 32 features of this token's block are this lane's four and those of the 7 lanes beside it
+                // (host: M % 32 == 0, so a block is complete or absent)
+                float amax = ok ? fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))) : 0.0f;
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+                if (ok) {
+                    const float d  = round_f16(amax / 127.0f);
+                    const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+                    float q[4];
+                    #pragma unroll
+                    for (int e = 0; e < 4; e++) q[e] = fminf(fmaxf(d * rintf(x[e]*id), -65504.0f), 65504.0f);
+                    *(uint2 *) (a.prep + t*a.M + m) = make_uint2(pack_h2(q[0], q[1]), pack_h2(q[2], q[3]));
+                }
+            }
+        }
+    }
+}
+
 template <int AT, int BN>
 __global__ void __launch_bounds__(256) k_gemm_mfma(const GemmArgs a) {
     constexpr int WN = BN / 2;            // wave tile width (tokens)
@@ -673,8 +764,336 @@ static int launch_ring_group(mi355x_ctx * ctx, const GemmArgs * members, int n, 
     return emit(ctx, "gemm_f16_ring_group", k_gemm_f16_ring_group<BN, NST, TM>, dim3((uint32_t) (8 * per)), dim3(TM * 2), lds, ga, bytes, flops);
 }
 
+// -------------------------------------------------------------------------------------------------
+// k_gemm_dq (round 6): the product of a QUANTIZED weight with wide activations — "per-warp dequant into LDS tiles feeding MFMA" without an
+// f16 copy of the weight anywhere.  What bounds a K-step of these products on a CU is not the matrix pipe but the vector-memory path that
+// fills LDS (64 B/clk per CU at best): a 128 x 128 tile of two f16 operands needs 32 KB per 64 MFMAs (= 512 matrix-pipe cycles per SIMD:
+// exactly the path's peak — the ring kernel above runs at 28-34 % of the MFMA rate, r03b_gemm_fixed_cost.txt).  So
+//   * A travels in its block-quantized planar form (0.56 - 1.06 B/weight instead of 2) through registers: waves 0..3 hold one (row, 32-element
+//     block) pair per thread, fetched one K-step ahead, unpacked to f16 (a_unpack: the values of mi355x_dequant_f16, bit for bit) and written
+//     into the XOR-swizzled A stage that the NEXT step reads — one such wave per SIMD, so its unpack VALU runs beside the MFMAs of the SIMD's
+//     other wave;
+//   * B (prepared f16 activations [T][K]) arrives by LDS-DMA, 8 rows x 128 B per instruction, swizzle on the global side (as the ring);
+//   * the tile is 128 (weights rows) x BN tokens with BN = 256 where the product has enough tiles (8 waves, 2 x 4; 37.6 KB per 128 MFMAs for
+//     Q5_0) and 128 otherwise (4 waves, two workgroups per CU); every wave owns a 64 x 64 piece: fragments, MFMA order and epilogue are the
+//     ring kernel's, so results are bit-identical to it on the weight's f16 copy (tests/test_gpu.py).
+// Two stages of each operand, ONE barrier per K-step: wait (own DMA + own A stores) -> barrier -> write A(k+1), request A(k+2), B(k+1) -> MFMAs(k).
+// -------------------------------------------------------------------------------------------------
+// ---- unpack of one 32-element block to f16 without a float in sight ----------------------------------------------------------------
+// a_unpack computes f16(float(q) * d) per weight (extract, int -> float, multiply, float -> f16: 5-6 VALU operations per weight, ~1000 cycles per
+// K-step of a staging wave, profiles/r06_gemm_dq_anatomy.txt).  The same values from packed f16 arithmetic: a 4..8-bit unsigned u placed in the
+// mantissa of 1024.0 (bits 0x6400 | u) IS the f16 number 1024 + u; subtracting 1024 + offset is exact; one v_pk_mul_f16 by d rounds the product
+// (exact in f32: <= 8 x 11 bits) once, to nearest even, denormals kept — f16(float(q) * d) bit for bit (tests: k_gemm_dq == k_gemm_mfma == ring
+// on mi355x_dequant_f16's copy).  Two weights per v_perm_b32 / v_pk_add_f16 / v_pk_mul_f16.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t h2_bits(half2_t v) { return __builtin_bit_cast(uint32_t, v); }
+// bytes b0..b3 of x (each < 256) -> (0x6400 | b0, 0x6400 | b1) and (0x6400 | b2, 0x6400 | b3), minus `off`, times d
+__device__ __forceinline__ void dq_pairs(uint32_t x, half2_t off, half2_t d2, uint32_t & o01, uint32_t & o23) {
+    const uint32_t p01 = __builtin_amdgcn_perm(0x64646464u, x, 0x04010400u);
+    const uint32_t p23 = __builtin_amdgcn_perm(0x64646464u, x, 0x04030402u);
+    o01 = h2_bits((__builtin_bit_cast(half2_t, p01) - off) * d2);
+    o23 = h2_bits((__builtin_bit_cast(half2_t, p23) - off) * d2);
+}
+template <int AT>
+__device__ __forceinline__ void a_unpack_fast(const a_regs<AT> & r, int k, uint4 (&out)[4], const uint32_t * lut) {
+    if constexpr (AT == MI355X_TYPE_Q8_0) {
+        const half_t dh = __builtin_bit_cast(half_t, r.d);
+        const half2_t d2 = { dh, dh }, off = { (half_t) 1152.0f, (half_t) 1152.0f };          // u = q + 128
+        const uint32_t w[8] = { r.q0.x, r.q0.y, r.q0.z, r.q0.w, r.q1.x, r.q1.y, r.q1.z, r.q1.w };
+        uint32_t o[16];
+        #pragma unroll
+        for (int i = 0; i < 8; i++) dq_pairs(w[i] ^ 0x80808080u, off, d2, o[2*i], o[2*i+1]);
+        #pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = make_uint4(o[4*i], o[4*i+1], o[4*i+2], o[4*i+3]);
+    } else if constexpr (AT == MI355X_TYPE_Q4_0 || AT == MI355X_TYPE_Q5_0) {
+        const half_t dh = __builtin_bit_cast(half_t, r.d);
+        const half2_t d2 = { dh, dh };
+        const half2_t off = AT == MI355X_TYPE_Q5_0 ? half2_t{ (half_t) 1040.0f, (half_t) 1040.0f } : half2_t{ (half_t) 1032.0f, (half_t) 1032.0f };
+        const uint32_t w[4] = { r.q.x, r.q.y, r.q.z, r.q.w };
+        uint32_t o[16];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t lo = w[i] & 0x0F0F0F0Fu, hi = (w[i] >> 4) & 0x0F0F0F0Fu;                   // elements 4i .. 4i+3 and 16+4i .. 16+4i+3
+            if constexpr (AT == MI355X_TYPE_Q5_0) { lo |= lut[(r.qh >> (4*i)) & 0xFu]; hi |= lut[(r.qh >> (16 + 4*i)) & 0xFu]; }      // the fifth bits (table: bit k -> 0x10 in byte k)
+            dq_pairs(lo, off, d2, o[2*i], o[2*i+1]);
+            dq_pairs(hi, off, d2, o[8 + 2*i], o[8 + 2*i+1]);
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = make_uint4(o[4*i], o[4*i+1], o[4*i+2], o[4*i+3]);
+    } else a_unpack<AT>(r, k, out);                    // Q4_K: d * sc * q - dmin * m is an f32 fma (kept as it is)
+}
+
+// f16-table GELU with the table in LDS: the entries of every f16 value with |x| < 16 (exponent fields 0 .. 18: 19 x 1024 values x 2 signs = 76 KB;
+// |x| >= 10 never reaches the table: gelu_lut).  A wave's 64 look-ups in global memory are 64 different cache lines for the texture path
+// (~64 cycles per instruction, and a dependent round trip each: the 36-45 k cycles of fc1's epilogue, profiles/r06_gemm_dq_anatomy.txt) and a few LDS cycles here.
+#define GELU_WIN_N     (19 * 1024)
+#define GELU_WIN_BYTES (2 * GELU_WIN_N * 2)
+__device__ __forceinline__ float gelu_win(float x, const uint16_t * __restrict__ win, const uint16_t * __restrict__) {
+    if (x <= -10.0f) return 0.0f;
+    if (x >=  10.0f) return x;
+    const uint32_t h = f2h(x);                         // |x| < 10: (h & 0x7FFF) < 0x4900 < GELU_WIN_N
+    return h2f(win[(h & 0x7FFFu) + ((h >> 15) ? GELU_WIN_N : 0)]);
+}
+
+// ---- the weight planes of one K-step as they lie in memory, through LDS-DMA (the "raw" stage) --------------------------------------
+// staging thread t = (tile row t >> 1, block t & 1 of the K-step), 256 of them (waves 0..3).  Every field of a_regs<AT> is a plane [256][field bytes]
+// that the thread's OWN wave fills (lane-linear LDS destination = thread-linear plane); Q4_K: the super-block's dm / 12 scale bytes once per ROW
+// ([128][4], [128][12]; rows 64 (w & 1) .. by wave w: waves 0 / 1 fetch dm, waves 2 / 3 the scales).  NA = LDS-DMA instructions per staging wave and K-step.
+template <int AT> struct dq_raw;
+// (only 4- and 16-byte DMA pieces: the two f16 scales of a row's K-step are ONE aligned dword — the blocks-per-row count is even — which both of the row's
+//  threads fetch; the 12 scale bytes of a Q4_K super-block travel as 16, the four extra ones still inside the tensor: the dm plane follows the scales)
+template <> struct dq_raw<MI355X_TYPE_Q4_0> { static constexpr int NA = 2, BYTES = 256 * 16 + 256 * 4; };
+template <> struct dq_raw<MI355X_TYPE_Q5_0> { static constexpr int NA = 3, BYTES = 256 * 16 + 256 * 4 + 256 * 4; };
+template <> struct dq_raw<MI355X_TYPE_Q8_0> { static constexpr int NA = 3, BYTES = 256 * 32 + 256 * 4; };
+template <> struct dq_raw<MI355X_TYPE_Q4_K> { static constexpr int NA = 3, BYTES = 256 * 32 + 128 * 4 + 128 * 16; };
+#define DQ_GLDS(gptr, lptr, SZ) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (gptr), (__attribute__((address_space(3))) void *) (lptr), SZ, 0, 0)
+
+template <int AT>
+__device__ __forceinline__ void dq_raw_issue(const GemmArgs & a, char * raw, int wave, int lane, int m0, int kt) {
+    const int t = wave * 64 + lane, half = t & 1;
+    const int am = m0 + (t >> 1) < a.M ? m0 + (t >> 1) : a.M - 1;          // rows past the edge are clamped (never stored)
+    if constexpr (AT == MI355X_TYPE_Q4_K) {
+        const qplanes<MI355X_TYPE_Q4_K> p(a.A, a.nbt);
+        const int k = kt * BK + half * 32;                                   // both blocks of a K-step lie in ONE 64-element chunk: low / high nibbles of the same 32 bytes
+        const int64_t sb = (int64_t) am * (a.K >> 8) + (k >> 8);
+        const uint8_t * qs = p.qs + sb*128 + (((k & 255) >> 5) >> 1) * 32;
+        DQ_GLDS(qs,      raw + wave * 1024,        16);
+        DQ_GLDS(qs + 16, raw + 4096 + wave * 1024, 16);
+        const int r = (wave & 1) * 64 + lane;
+        const int rm = m0 + r < a.M ? m0 + r : a.M - 1;
+        const int64_t sbr = (int64_t) rm * (a.K >> 8) + ((kt * BK) >> 8);
+        if (wave < 2) DQ_GLDS(p.dm + sbr, raw + 8192 + (wave & 1) * 256, 4);
+        else          DQ_GLDS(p.sc + sbr*12, raw + 8704 + (wave & 1) * 1024, 16);
+    } else {
+        const qplanes<AT> p(a.A, a.nbt);
+        const int64_t ib = (int64_t) am * (a.K >> 5) + kt * 2 + half;
+        const uint16_t * dpair = p.d + (ib - half);                           // both scales of the row's K-step (host: K % 64 == 0, so the pair is dword-aligned)
+        if constexpr (AT == MI355X_TYPE_Q8_0) {
+            DQ_GLDS(p.qs + ib*32,      raw + wave * 1024,        16);
+            DQ_GLDS(p.qs + ib*32 + 16, raw + 4096 + wave * 1024, 16);
+            DQ_GLDS(dpair,             raw + 8192 + wave * 256,  4);
+        } else {
+            DQ_GLDS(p.qs + ib*16, raw + wave * 1024, 16);
+            if constexpr (AT == MI355X_TYPE_Q5_0) { DQ_GLDS(p.qh + ib, raw + 4096 + wave * 256, 4); DQ_GLDS(dpair, raw + 5120 + wave * 256, 4); }
+            else DQ_GLDS(dpair, raw + 4096 + wave * 256, 4);
+        }
+    }
+}
+template <int AT>
+__device__ __forceinline__ void dq_raw_read(a_regs<AT> & r, const char * raw, int t) {
+    if constexpr (AT == MI355X_TYPE_Q4_K) {
+        r.q0 = *(const uint4 *) (raw + t*16); r.q1 = *(const uint4 *) (raw + 4096 + t*16);
+        r.dm = *(const uint32_t *) (raw + 8192 + (t >> 1)*4);
+        const uint32_t * sc = (const uint32_t *) (raw + 8704 + (t >> 1)*16);
+        r.sc[0] = sc[0]; r.sc[1] = sc[1]; r.sc[2] = sc[2];
+    } else if constexpr (AT == MI355X_TYPE_Q8_0) {
+        r.q0 = *(const uint4 *) (raw + t*16); r.q1 = *(const uint4 *) (raw + 4096 + t*16); r.d = (uint16_t) (*(const uint32_t *) (raw + 8192 + t*4) >> (16 * (t & 1)));
+    } else if constexpr (AT == MI355X_TYPE_Q5_0) {
+        r.q = *(const uint4 *) (raw + t*16); r.qh = *(const uint32_t *) (raw + 4096 + t*4); r.d = (uint16_t) (*(const uint32_t *) (raw + 5120 + t*4) >> (16 * (t & 1)));
+    } else {
+        r.q = *(const uint4 *) (raw + t*16); r.d = (uint16_t) (*(const uint32_t *) (raw + 4096 + t*4) >> (16 * (t & 1)));
+    }
+}
+
+template <int N> __device__ __forceinline__ void dq_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory"); }
+
+template <int AT, int BN>
+__device__ __forceinline__ void gemm_dq_tile(const GemmArgs & a, const int tile, char * lds) {
+    constexpr int NW = BN / 32;                        // waves: 4 or 8
+    constexpr int WN = 64, NT = 2;
+    constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128, NSB = 3, NSR = 3;
+    constexpr int RAW = (dq_raw<AT>::BYTES + 255) & ~255, NA = dq_raw<AT>::NA;
+    constexpr int OFF_B = 2 * A_STAGE;
+    constexpr int OFF_RAW = OFF_B + NSB * B_STAGE;
+    constexpr int OFF_LUT = OFF_RAW + NSR * RAW;       // Q5_0: 16 x u32
+    constexpr int GB = BN / NW / 8;                    // LDS-DMA instructions per wave and stage of B (4)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const bool stager = tid < 256;                     // waves 0..3: one per SIMD
+    const int mi = a.m_major ? tile / a.nt : tile % a.mt;
+    const int ni = a.m_major ? tile % a.nt : tile / a.mt;
+    const int m0 = mi * BM;
+    const int64_t n0 = (int64_t) ni * BN;
+    const int nk = a.K / BK;
+
+    const int arow = (tid & 255) >> 1, ahalf = tid & 1;
+    const char * gb[GB];
+    #pragma unroll
+    for (int i = 0; i < GB; i++) {
+        const int r = wave * (BN / NW) + i * 8 + (lane >> 3);
+        const int64_t tr = n0 + r < a.T ? n0 + r : a.T - 1;
+        gb[i] = (const char *) (a.B + tr * a.ldb) + ((((lane & 7) ^ ((r >> 1) & 7))) << 4);
+    }
+    auto issue_b = [&](int kt) {
+        char * st = lds + OFF_B + (kt % NSB) * B_STAGE;
+        const int koff = kt * BK * 2;
+        #pragma unroll
+        for (int i = 0; i < GB; i++) DQ_GLDS(gb[i] + koff, st + (wave * (BN / NW) + i * 8) * 128, 16);
+    };
+    auto issue_a = [&](int kt) { dq_raw_issue<AT>(a, lds + OFF_RAW + (kt % NSR) * RAW, wave, lane, m0, kt); };
+    const uint32_t * lut = (const uint32_t *) (lds + OFF_LUT);
+    // raw planes of A(kt) -> f16 -> the A stage that step kt reads
+    auto stage_a = [&](int kt) {
+        a_regs<AT> r;
+        dq_raw_read<AT>(r, lds + OFF_RAW + (kt % NSR) * RAW, tid);
+        uint4 out[4];
+        a_unpack_fast<AT>(r, kt * BK + ahalf*32, out, lut);
+        char * st = lds + (kt & 1) * A_STAGE;
+        #pragma unroll
+        for (int i = 0; i < 4; i++) *(uint4 *) (st + lds_off(arow, ahalf*4 + i)) = out[i];
+    };
+
+    floatx16 acc[2][NT];
+    #pragma unroll
+    for (int i = 0; i < 2; i++)
+        #pragma unroll
+        for (int j = 0; j < NT; j++)
+            #pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int abl = a.ablate;
+    // anatomy stamps: [0] entry, [1] loop entered, [2] loop left, [3] epilogue done, [4] cycles between the top of a step and its barrier's release (summed),
+    // [5] staging section, [6] MFMA section — wave 0 of workgroup 0 in slots 0..7, its last wave in 8..15
+    unsigned long long * dbg = (a.dbg && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NW - 1)) ? a.dbg + (wave ? 8 : 0) : nullptr;
+    unsigned long long t_wait = 0, t_stage = 0, t_mma = 0, ts = 0;
+    if (dbg) dbg[0] = __builtin_amdgcn_s_memtime();
+    if constexpr (AT == MI355X_TYPE_Q5_0) {
+        if (tid < 16) ((uint32_t *) (lds + OFF_LUT))[tid] = ((tid & 1) ? 0x10u : 0u) | ((tid & 2) ? 0x1000u : 0u) | ((tid & 4) ? 0x100000u : 0u) | ((tid & 8) ? 0x10000000u : 0u);
+    }
+    // Every operand arrives by LDS-DMA, so every wait is an exact count (an ordinary register load beside a DMA makes hipcc drain the queue).  A wave's
+    // requests in step s, in this order: raw A(s+3) [staging waves], B(s+2) — one "batch".  At the top of step s+1 everything but the newest batch has
+    // landed: B(s+1) and raw A(s+2), which that step unpacks into the A stage step s+2 reads.  B and raw A are three stages deep, f16 A two.
+    if (stager) issue_a(0);
+    if (stager && nk > 1) issue_a(1);
+    issue_b(0);
+    if (stager && nk > 2) issue_a(2);
+    if (nk > 1) issue_b(1);
+    // the batch before the loop: raw A(2) + B(1) — raw A(0) (unpacked here), raw A(1), B(0) are older
+    if (nk > 1) { if (stager && nk > 2) dq_wait<NA + GB>(); else dq_wait<GB>(); } else dq_wait<0>();
+    __syncthreads();                                                       // (Q5_0: the bit table; Q4_K: the rows' dm / scales fetched by the neighbouring wave)
+    if (stager) stage_a(0);
+
+    if (dbg) dbg[1] = __builtin_amdgcn_s_memtime();
+    for (int kt = 0; kt < nk; kt++) {
+        if (dbg) ts = __builtin_amdgcn_s_memtime();
+        // the batch of step kt-1: raw A(kt+2) [staging waves, if it exists] + B(kt+1) [if it exists]; own stores of A(kt) done (lgkmcnt)
+        if (kt == 0) dq_wait<NA + GB + NA + GB>();                          // (nothing new to wait for: the prologue's wait covered B(0))
+        else if (kt + 1 < nk) { if (stager && kt + 2 < nk) dq_wait<NA + GB>(); else dq_wait<GB>(); }
+        else dq_wait<0>();
+        __builtin_amdgcn_s_barrier();                                      // ... everybody's; and everybody has finished reading the stages of step kt-1
+        if (dbg) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_wait += t - ts; ts = t; }
+        if (stager && kt + 3 < nk && !(abl & 8)) issue_a(kt + 3);
+        if (kt + 2 < nk && !(abl & 2)) issue_b(kt + 2);
+        if (stager && kt + 1 < nk && !(abl & 1)) stage_a(kt + 1);
+        if (dbg) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_stage += t - ts; ts = t; }
+        const char * ldsA = lds + (kt & 1) * A_STAGE;
+        const char * ldsB = lds + OFF_B + (kt % NSB) * B_STAGE;
+        if (!(abl & 4))
+        #pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            half8_t af[2], bf[NT];
+            const int slot = kk*2 + (lane >> 5);
+            #pragma unroll
+            for (int i = 0; i < 2; i++) af[i] = *(const half8_t *) (ldsA + lds_off(wm*64 + i*32 + (lane & 31), slot));
+            #pragma unroll
+            for (int j = 0; j < NT; j++) bf[j] = *(const half8_t *) (ldsB + lds_off(wn*WN + j*32 + (lane & 31), slot));
+            #pragma unroll
+            for (int i = 0; i < 2; i++)
+                #pragma unroll
+                for (int j = 0; j < NT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (dbg) { asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][NT-1])); const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mma += t - ts; }
+    }
+    if (dbg) { dbg[2] = __builtin_amdgcn_s_memtime(); dbg[4] = t_wait; dbg[5] = t_stage; dbg[6] = t_mma; }
+    if (gemm_epilogue_vec_ok(a) && !(abl & 16)) {
+        __syncthreads();                                                   // every wave has finished reading the last stage: the staging area becomes the transposition buffer
+        const uint16_t * win = nullptr;
+        if (a.gelu && a.lds_bytes >= NW * (NT*32*36*4) + GELU_WIN_BYTES) {
+            // the GELU table's 2 x 38 KB behind the transposition regions
+            uint16_t * wdst = (uint16_t *) (lds + NW * (NT*32*36*4));
+            for (int e = tid; e < GELU_WIN_BYTES / 16; e += BN * 2) {
+                const int neg = e >= GELU_WIN_N * 2 / 16;
+                ((uint4 *) wdst)[e] = ((const uint4 *) (a.gelu_tab + (neg ? 0x8000 : 0)))[e - neg * (GELU_WIN_N * 2 / 16)];
+            }
+            __syncthreads();
+            win = wdst;
+        }
+        gemm_epilogue_lds<NT>(a, acc, m0, n0, wm, wn, WN, lane, (float *) lds + wave * (NT*32*36), win);
+    } else gemm_epilogue<NT>(a, acc, m0, n0, wm, wn, WN, lane);
+    if (dbg) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[3] = __builtin_amdgcn_s_memtime(); }
+}
+
+template <int AT, int BN>
+__global__ void __launch_bounds__(BN * 2) k_gemm_dq(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dq_lds[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tile = xcd * a.per + idx;
+    if (tile >= a.mt * a.nt) return;
+    gemm_dq_tile<AT, BN>(a, tile, dq_lds);
+}
+
+template <int AT, int BN>
+__global__ void __launch_bounds__(BN * 2) k_gemm_dq_group(const GemmGroupArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) char dq_lds_g[];
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t = xcd * ga.per + idx;
+    if (t >= ga.n * ga.tiles_per_member) return;
+    const int gi = t / ga.tiles_per_member;
+    gemm_dq_tile<AT, BN>(ga.g[gi], t - gi * ga.tiles_per_member, dq_lds_g);
+}
+
+// token-tile width: 256 when that still gives (nearly) every CU a tile, else 128 (test option MI355X_OPT_DQ_BN forces one)
+static int dq_pick_bn(mi355x_ctx * ctx, const GemmArgs & k, int n) {
+    const int force = mi355x_opt(MI355X_OPT_DQ_BN, 0);
+    if (force == 128 || force == 256) return force;
+    const int64_t t256 = (int64_t) n * ((k.M + BM - 1) / BM) * ((k.T + 255) / 256);
+    return t256 * 10 >= (int64_t) ctx->n_cu * 6 ? 256 : 128;
+}
+
+template <int AT, int BN>
+static int launch_dq(mi355x_ctx * ctx, const GemmArgs * members, int n, double bytes, double flops) {
+    // two f16 A stages, three B stages, three raw A stages, the Q5_0 bit table; with a GELU epilogue at least the transposition regions + the table's 76 KB
+    constexpr uint32_t staging = 2u * BM * 128 + 3u * BN * 128 + 3u * ((dq_raw<AT>::BYTES + 255) & ~255) + 64u;
+    constexpr uint32_t with_gelu = (BN / 32) * (2*32*36*4) + GELU_WIN_BYTES;
+    static_assert(staging <= 160 * 1024 && with_gelu <= 160 * 1024, "LDS budget of one CU");
+    static_assert((BN / 32) * (2*32*36*4) <= 2 * BM * 128 + 3 * BN * 128, "the transposition regions fit the staging area");
+    const uint32_t lds = members[0].gelu && with_gelu > staging ? with_gelu : staging;
+    const int64_t tiles = (int64_t) ((members[0].M + BM - 1) / BM) * ((members[0].T + BN - 1) / BN);
+    const int64_t per = (n * tiles + 7) / 8;
+    // (the attribute is set to the ceiling once per instantiation and device: `lds` depends on the epilogue)
+    if (n == 1) {
+        GemmArgs k = members[0];
+        ring_tiling<BM, BN>(k, per);
+        k.per = (int) per;
+        k.ablate = mi355x_opt(MI355X_OPT_DQ_ABLATE, 0);
+        k.dbg = (unsigned long long *) mi355x_debug_stamps(ctx);
+        k.lds_bytes = (int) lds;
+        static std::atomic<bool> attr_set[64];
+        if (ring_lds_attr(ctx, k_gemm_dq<AT, BN>, 160 * 1024, attr_set) != 0) return MI355X_E_UNSUPPORTED;
+        return emit(ctx, "gemm_dq", k_gemm_dq<AT, BN>, dim3((uint32_t) (8 * per)), dim3(BN * 2), lds, k, bytes, flops);
+    }
+    GemmGroupArgs ga; memset(&ga, 0, sizeof(ga));
+    for (int i = 0; i < n; i++) { ga.g[i] = members[i]; ring_tiling<BM, BN>(ga.g[i], per); ga.g[i].lds_bytes = (int) lds; }
+    ga.n = n; ga.tiles_per_member = (int) tiles; ga.per = (int) per;
+    static std::atomic<bool> attr_set_g[64];
+    if (ring_lds_attr(ctx, k_gemm_dq_group<AT, BN>, 160 * 1024, attr_set_g) != 0) return MI355X_E_UNSUPPORTED;
+    return emit(ctx, "gemm_dq_group", k_gemm_dq_group<AT, BN>, dim3((uint32_t) (8 * per)), dim3(BN * 2), lds, ga, bytes, flops);
+}
+
+template <int AT>
+static int launch_dq_any(mi355x_ctx * ctx, const GemmArgs * members, int n, double bytes, double flops) {
+    return dq_pick_bn(ctx, members[0], n) == 256 ? launch_dq<AT, 256>(ctx, members, n, bytes, flops) : launch_dq<AT, 128>(ctx, members, n, bytes, flops);
+}
+
+static bool dq_eligible(const GemmArgs & k, int at) {
+    if (at != MI355X_TYPE_Q4_0 && at != MI355X_TYPE_Q5_0 && at != MI355X_TYPE_Q8_0 && at != MI355X_TYPE_Q4_K) return false;
+    return k.K % BK == 0 && k.K >= 2*BK && (at != MI355X_TYPE_Q4_K || k.K % 256 == 0) && (k.ldb % 8) == 0 && ((uintptr_t) k.B % 16) == 0 && k.T >= 64 && k.M >= 64 &&
+           (k.T + 127) / 128 <= 65535;
+}
+
 // ---- held-back ring GEMMs (mi355x_ctx::pending_*) ---------------------------------------------------------------------------
-struct PendingGemms { GemmArgs k[GEMM_GROUP_MAX]; double bytes, flops; };
+struct PendingGemms { GemmArgs k[GEMM_GROUP_MAX]; double bytes, flops; int at; };     // at: MI355X_TYPE_F16 (ring) or the quantized type (k_gemm_dq)
 static_assert(sizeof(PendingGemms) <= sizeof(((mi355x_ctx *) nullptr)->pending_store), "pending_store too small");
 
 static bool mem_overlap(const void * a, int64_t na, const void * b, int64_t nb) {
@@ -684,9 +1103,9 @@ static int64_t gemm_dst_bytes(const GemmArgs & k) { return (k.T - 1) * k.dst_nb1
 static int64_t gemm_res_bytes(const GemmArgs & k) { return k.residual ? (k.T - 1) * k.res_nb1 + (int64_t) k.M * 4 : 0; }
 
 // may `k` join the held-back members?  Same B and shape, and no member reads or writes what another member writes.
-static bool gemm_mergeable(const PendingGemms & P, int n, const GemmArgs & k) {
+static bool gemm_mergeable(const PendingGemms & P, int n, const GemmArgs & k, int at) {
     const GemmArgs & f = P.k[0];
-    if (k.prep || f.prep) return false;                                   // a product that also writes prepared activations goes alone
+    if (k.prep || f.prep || at != P.at) return false;                                   // a product that also writes prepared activations goes alone
     if (n >= GEMM_GROUP_MAX || k.B != f.B || k.ldb != f.ldb || k.K != f.K || k.T != f.T || k.M != f.M) return false;
     const int64_t kd = gemm_dst_bytes(k);
     if (mem_overlap(k.dst, kd, k.B, k.T * k.ldb * 2)) return false;
@@ -719,6 +1138,16 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
     const GemmArgs & k = P.k[0];
     const int64_t mt = (k.M + BM - 1) / BM, nt128 = (k.T + 127) / 128;
     int rc;
+    if (P.at != MI355X_TYPE_F16) {
+        switch (P.at) {
+            case MI355X_TYPE_Q4_0: rc = launch_dq_any<MI355X_TYPE_Q4_0>(ctx, P.k, n, P.bytes, P.flops); break;
+            case MI355X_TYPE_Q5_0: rc = launch_dq_any<MI355X_TYPE_Q5_0>(ctx, P.k, n, P.bytes, P.flops); break;
+            case MI355X_TYPE_Q8_0: rc = launch_dq_any<MI355X_TYPE_Q8_0>(ctx, P.k, n, P.bytes, P.flops); break;
+            default:               rc = launch_dq_any<MI355X_TYPE_Q4_K>(ctx, P.k, n, P.bytes, P.flops); break;
+        }
+        ctx->in_flush = false;
+        return rc;
+    }
     if (n == 1) {
         // stages: measured on large-v3 encode — 64-wide tiles (one block per CU): 2 -> 13.0 ms, 3 -> 11.3, 4 -> 10.9, 5/6 no better;
         // 128-wide tiles (FC1, ~2 blocks per CU): 2 stages (64 KB, two blocks co-resident) 10.6-10.8 vs 3 -> 10.9, 4 -> 11.0
@@ -743,14 +1172,14 @@ static int flush_pending_gemms(mi355x_ctx * ctx) {
 }
 
 // hold a ring GEMM back; it leaves with the next flush (mi355x_flush_pending: any other launch, synchronize, end of the graph range)
-static int hold_ring_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, double flops) {
+static int hold_ring_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, double flops, int at = MI355X_TYPE_F16) {
     PendingGemms * P = (PendingGemms *) ctx->pending_store;
     // (the pending store may hold another kernel family's launches — mmq.hip groups its products the same way: those leave first)
-    if (ctx->pending_n > 0 && (ctx->pending_flush != flush_pending_gemms || !gemm_mergeable(*P, ctx->pending_n, k))) {
+    if (ctx->pending_n > 0 && (ctx->pending_flush != flush_pending_gemms || !gemm_mergeable(*P, ctx->pending_n, k, at))) {
         const int rc = mi355x_flush_pending(ctx);
         if (rc) return rc;
     }
-    if (ctx->pending_n == 0) { P->bytes = 0; P->flops = 0; }
+    if (ctx->pending_n == 0) { P->bytes = 0; P->flops = 0; P->at = at; }
     P->k[ctx->pending_n++] = k;
     P->bytes += bytes; P->flops += flops;
     ctx->pending_flush = flush_pending_gemms;
@@ -767,6 +1196,9 @@ static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, doubl
         if (k.K % BK == 0 && k.K >= 2*BK && (k.a_nb1 % 16) == 0 && ((uintptr_t) k.A % 16) == 0 && (k.ldb % 8) == 0 && nt64 <= 65535) {
             return hold_ring_gemm(ctx, k, bytes, flops);
         }
+    } else if (dq_eligible(k, AT) && mi355x_opt(MI355X_OPT_DQ_GEMM, 1) != 0) {
+        // quantized weight x wide f16 activations: dequantized per workgroup on its way into LDS (k_gemm_dq)
+        return hold_ring_gemm(ctx, k, bytes, flops, AT);
     }
     if (mt * nt128 >= ctx->n_cu || k.T > 64*65535LL) {
         if (nt128 > 65535) return MI355X_E_UNSUPPORTED;
