@@ -394,7 +394,7 @@ enum mi355x_test_opt {
     MI355X_OPT_MMQ_SCALE_MFMA,     /* 0: scale products dw * dx on the VALU instead of the rank-1 f16 MFMA */
     MI355X_OPT_MMQ_TILE,           /* 12864: 128 x 64 tiles instead of 64 x 128 */
     MI355X_OPT_FATTN_NG,           /* 1..4: key groups per workgroup of the MFMA attention kernel instead of the n_kv-dependent choice */
-    MI355X_OPT_DQ_GEMM,            /* 0: quantized weight x f16 activations on the register-staged k_gemm_mfma instead of k_gemm_dq (bit-identical) */
+    MI355X_OPT_DQ_GEMM,            /* 1: quantized weight x f16 activations on k_gemm_dq (planes unpacked per workgroup into LDS) instead of the register-staged k_gemm_mfma (bit-identical; the plugin sets it for GGML_MI355X_MMQ=3) */
     MI355X_OPT_DQ_BN,              /* 128 / 256: token-tile width of k_gemm_dq instead of the tile-count-dependent choice (bit-identical) */
     MI355X_OPT_DQ_ABLATE,          /* timing experiments on k_gemm_dq (results are garbage): bit 0 no unpack, 1 no activation DMA, 2 no MFMA, 3 no weight loads */
     MI355X_OPT_COUNT

@@ -94,6 +94,7 @@ def main():
             ys = [torch.zeros((T, M), dtype=torch.float32, device="cuda:0") for _ in range(nm)]
             torch.cuda.synchronize()
             L.mi355x_test_option(OPT_DQ_BN, 0, 0)
+            L.mi355x_test_option(OPT_DQ_GEMM, 1 if family.startswith("dq") else 0, 1 if family.startswith("dq") else 0)
             if family in ("dq128", "dq256"):
                 L.mi355x_test_option(OPT_DQ_BN, int(family[2:]), 1)
 

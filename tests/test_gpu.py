@@ -776,13 +776,13 @@ def test_plugin_model_parity_without_flash_attn(plugin_env):
     assert d["batch5"]["nmse"] < TOL_BATCH and d["batch48"]["nmse"] < TOL_BATCH, d
 
 
-@pytest.mark.parametrize("mmq", ["0", "2"])
+@pytest.mark.parametrize("mmq", ["0", "2", "3"])
 @pytest.mark.parametrize("arch,qtype", [("base.en", "q5_0"), ("large-v3-2l", "q8_0"), ("base.en", "q4_k")])
 def test_plugin_model_parity_with_the_other_gemm_families(plugin_env, arch, qtype, mmq):
-    """GGML_MI355X_MMQ selects which GEMM family takes quantized weights x wide activations.  The default (1, round 6) is by width: k_gemm_dq —
-    quantized planes unpacked per workgroup into LDS, f16 MFMA — from 1024 columns on (encoder, cross-K/V), the int8 tile GEMM below.  The two kept
-    alternatives are TESTED configurations, whole model, STRICT, same tolerances: 0 = f16 copies of the weights through the LDS-DMA ring (rounds 2-3),
-    2 = the int8 tile GEMM at every width (rounds 4-5: the CPU's own integer sums also in the encoder)."""
+    """GGML_MI355X_MMQ selects which GEMM family takes quantized weights x more than 8 columns.  The default (1, round 6) is by width: from 1024 columns on
+    (encoder, cross-K/V) the f16 MFMA ring on one-time f16 copies of the weights, below that the int8 tile GEMM on the quantized operands.  The kept alternatives
+    are TESTED configurations, whole model, STRICT, same tolerances: 0 = the f16 ring at every width (rounds 2-3), 2 = the int8 tile GEMM at every width (rounds
+    4-5: the CPU's own integer sums also in the encoder), 3 = like 1 with the wide products on k_gemm_dq (quantized planes unpacked per workgroup into LDS, no copy)."""
     d = _model_parity(plugin_env, arch, qtype, exact=False, steps="32", extra_env={"GGML_MI355X_MMQ": mmq})
     s = d["single"]
     assert s["worst_nmse"] < TOL_SINGLE, s

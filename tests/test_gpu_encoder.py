@@ -184,7 +184,7 @@ def test_gemm_with_an_f16_destination_equals_the_rounded_f32_result(gpu, M, K, T
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# k_gemm_dq (round 6): quantized weight planes unpacked per workgroup into LDS + f16 activations by LDS-DMA, f16 MFMA
+# k_gemm_dq (round 6, GGML_MI355X_MMQ=3): quantized weight planes unpacked per workgroup into LDS + f16 activations by LDS-DMA, f16 MFMA
 # ---------------------------------------------------------------------------------------------------------------
 DQ_GEMM, DQ_BN = 4, 5          # mi355x_kernels.h: mi355x_test_option values
 QT = {"q4_0": 2, "q5_0": 6, "q8_0": 8, "q4_K": 12}
@@ -238,13 +238,12 @@ def test_dequant_to_lds_gemm_equals_the_register_staged_kernel_and_the_ring_on_t
 
     for f16_dst in (False, True):
         ring = run(ts, f16_dst)
-        with opt(ka, DQ_GEMM, 0):
-            staged = run(tw, f16_dst)
+        staged = run(tw, f16_dst)                      # (MI355X_OPT_DQ_GEMM unset: the register-staged kernel)
         assert np.isfinite(ring.astype(np.float32)).all() and np.abs(ring.astype(np.float32)).max() > 1e-3
         view = np.uint16 if f16_dst else np.uint32
         assert np.array_equal(staged.view(view), ring.view(view))
         for bn in (128, 256):
-            with opt(ka, DQ_BN, bn):
+            with opt(ka, DQ_GEMM, 1), opt(ka, DQ_BN, bn):
                 got = run(tw, f16_dst)
             bad = np.argwhere(got.view(view) != ring.view(view))
             assert bad.size == 0, (bn, f16_dst, bad[:4].tolist(), len(bad))
@@ -269,6 +268,7 @@ def test_grouped_dequant_to_lds_gemm_and_its_activation_writing_epilogue(gpu):
     single = [torch.zeros((T, N), device="cuda:0") for _ in range(3)]
     grouped = [torch.zeros((T, N), device="cuda:0") for _ in range(3)]
     torch.cuda.synchronize()
+    L.mi355x_test_option(DQ_GEMM, 1, 1)
     for i in range(3):
         launch(i, single[i]); ctx.sync()
     n0 = L.mi355x_eager_count(ctx.h)
@@ -290,4 +290,5 @@ def test_grouped_dequant_to_lds_gemm_and_its_activation_writing_epilogue(gpu):
     ctx.check(L.mi355x_prep_act(ctx.h, y.data_ptr(), M * 4, 0, p1.data_ptr(), M, T, 1), "prep")
     ctx.check(L.mi355x_gemm_f16act_prep(ctx.h, C.byref(tw), act.data_ptr(), K, T, None, M * 4, C.byref(ep), p2.data_ptr()), "fc1 + prep")
     ctx.sync()
+    L.mi355x_test_option(DQ_GEMM, 0, 0)
     assert float(p1.float().abs().max()) > 1e-3 and torch.equal(p1.view(torch.int16), p2.view(torch.int16))

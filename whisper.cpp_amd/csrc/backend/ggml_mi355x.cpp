@@ -142,6 +142,7 @@ ggml_backend_t mi_dev_init_backend(ggml_backend_dev_t dev, const char *) {
     b->fuse = env_flag("GGML_MI355X_FUSE", true); b->prof = env_flag("GGML_MI355X_PROF", false);
     b->exact = env_flag("GGML_MI355X_EXACT", false);
     if (b->prof) mi355x_prof_enable(k, 1);
+    if (mi_mmq_mode() == 3) mi355x_test_option(MI355X_OPT_DQ_GEMM, 1, 1);      // GGML_MI355X_MMQ=3: quantized weight x wide f16 activations on k_gemm_dq (process-wide kernel-library switch)
     { std::lock_guard<std::mutex> lk(g_weights_mtx); std::unique_lock<std::shared_mutex> wl(g_backends_rw); g_backends.push_back(b); }
     return new ggml_backend{ mi_guid(), mi_backend_iface, dev, b };
 }

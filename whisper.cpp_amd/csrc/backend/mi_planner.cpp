@@ -109,20 +109,23 @@ bool parse_mm_chain(const ggml_cgraph * g, int i, bool fuse, mm_chain & c) {
 }
 
 int mode_for(ggml_type t) { return t == GGML_TYPE_Q4_K ? 2 : (is_quant_type(t) ? 1 : 0); }
-// Which GEMM family takes a quantized weight x wide activations (GGML_MI355X_MMQ, default 1):
-//   1  by width: T >= MI_DQ_MIN_T columns (the encoder and the cross-K/V products: 1500) run k_gemm_dq — the weight's quantized planes unpacked
-//      per workgroup into LDS, f16(d*q) activations, f16 MFMA (gemm_mfma.hip; BASELINE.json north_star: "per-warp dequant into LDS tiles feeding
-//      MFMA fp16/bf16 where the GEMM is genuinely dense") — and narrower products (prompt, beam / batch steps beyond the mat-vec range) the int8
-//      tile GEMM over the quantized operands (mmq.hip: the CPU's own integer sums; its per-block fix-up is VALU work that costs the encoder 1-2.5 ms
-//      per chunk, profiles/r05_regress_ab.txt, and nothing at these widths).  No f16 copy of a weight is made either way.
-//   2  the int8 tile GEMM at every width (rounds 4-5; activations = the reference's Q8_0 / Q8_K blocks as integers: "rows", prep modes 3 / 4)
-//   0  f16 copies of the weights through the LDS-DMA ring (rounds 2-3)
-int mi_mmq_mode() { static const int m = [] { const char * e = getenv("GGML_MI355X_MMQ"); return e ? std::max(0, std::min(2, atoi(e))) : 1; }(); return m; }
+// Which GEMM family takes a quantized weight x more than 8 columns (GGML_MI355X_MMQ, default 1):
+//   1  by width.  T >= MI_WIDE_MIN_T columns (the encoder and the cross-K/V products: 1500): f16 MFMA on a one-time f16 copy of the weight through the LDS-DMA
+//      ring (gemm_mfma.hip: k_gemm_f16_ring), f16(d*q) activations that keep the reference's Q8_0 / Q8_K rounding decisions.  Narrower products (prompt, beam /
+//      batch steps beyond the mat-vec range): the int8 tile GEMM over the quantized operands (mmq.hip: the CPU's own integer sums, activations = the reference's
+//      blocks as integers: "rows", prep modes 3 / 4).  Why by width: the int8 GEMM's per-block fix-up is VALU work that costs the encoder 1.0 (Q5_0) .. 2.5 ms
+//      (Q4_K) per chunk for a kernel-level 1e-10 that buys nothing at model level (profiles/r05_regress_ab.txt), and costs nothing at the
+//      narrow widths; the f16 copies are 2 bytes per encoder / cross-attention weight (1.4 GB of 288 for large-v3), made on first use.
+//   2  the int8 tile GEMM at every width (rounds 4-5)        0  the f16 ring at every width (rounds 2-3)
+//   3  like 1, but the wide products on k_gemm_dq: the weight's quantized planes unpacked per workgroup into LDS, no f16 copy (round 6; bit-identical to the ring
+//      on the copy, measured 10-150 % slower: profiles/r06_gemm_dq_anatomy.txt — the vector-memory path serves ~0.2 cache lines per clock and CU, and the
+//      row-scattered block planes cost more line requests than the copy's contiguous rows)
+int mi_mmq_mode() { static const int m = [] { const char * e = getenv("GGML_MI355X_MMQ"); return e ? std::max(0, std::min(3, atoi(e))) : 1; }(); return m; }
 bool mi_mmq_on() { return mi_mmq_mode() != 0; }
-#define MI_DQ_MIN_T 1024
+#define MI_WIDE_MIN_T 1024
+static bool mi_wide_f16(int64_t T) { const int m = mi_mmq_mode(); return m == 0 || ((m == 1 || m == 3) && T >= MI_WIDE_MIN_T); }
 int rows_mode_for(const ggml_tensor * w, int64_t K, int64_t T) {
-    if (!mi_mmq_on() || !is_quant_type(w->type) || K % 128 != 0) return 0;
-    if (mi_mmq_mode() == 1 && T >= MI_DQ_MIN_T) return 0;
+    if (mi_wide_f16(T) || !is_quant_type(w->type) || K % 128 != 0) return 0;
     return w->type == GGML_TYPE_Q4_K ? (K % 256 == 0 ? 4 : 0) : 3;
 }
 
@@ -302,7 +305,7 @@ int run_mm_chain(mi_backend_ctx * b, const mm_chain & c, const ggml_cgraph * g) 
             };
             // wide activations: run the GEMM on the weight's f16 copy (same values, no dequantization in the loop)
             constexpr int shadow_min_t = 128;
-            if (mode != 0 && T >= shadow_min_t && !mi_mmq_on()) {
+            if (mode != 0 && T >= shadow_min_t && mi_wide_f16(T) && mi_mmq_mode() != 3) {
                 if (const void * f16 = mi_shadow_get(b, w, mw)) {
                     mi355x_tensor ms = mw;
                     ms.data = (void *) f16; ms.type = MI355X_TYPE_F16;

@@ -1196,7 +1196,7 @@ static int launch_gemm(mi355x_ctx * ctx, const GemmArgs & k, double bytes, doubl
         if (k.K % BK == 0 && k.K >= 2*BK && (k.a_nb1 % 16) == 0 && ((uintptr_t) k.A % 16) == 0 && (k.ldb % 8) == 0 && nt64 <= 65535) {
             return hold_ring_gemm(ctx, k, bytes, flops);
         }
-    } else if (dq_eligible(k, AT) && mi355x_opt(MI355X_OPT_DQ_GEMM, 1) != 0) {
+    } else if (dq_eligible(k, AT) && mi355x_opt(MI355X_OPT_DQ_GEMM, 0) != 0) {
         // quantized weight x wide f16 activations: dequantized per workgroup on its way into LDS (k_gemm_dq)
         return hold_ring_gemm(ctx, k, bytes, flops, AT);
     }
