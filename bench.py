@@ -493,6 +493,7 @@ def main():
             if a.multi_stream == 8:
                 legs.append(("batched_16_streams", 1, 16))        # chains of 10 + 6 columns per step: from 9 columns on the mat-vecs run on the matrix cores (decode_mx.hip)
                 legs.append(("batched_32_streams", 1, 32))        # chains of 20 + 12 columns
+                legs.append(("batched_64_streams", 1, 64))        # more states than one chain carries: chains of equal width, 32 + 32 (round 6)
             for label, batching, ns in legs:
                 r = host_api.run(model, use_gpu=True, n_devices=1, streams=ns, n_decode=a.n_decode, steps=2, warmup=1, batching=batching)
                 if r["rc"] != 0:

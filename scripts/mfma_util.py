@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""MFMA utilisation per kernel from ONE rocprofv3 --pmc pass that collected SQ_VALU_MFMA_BUSY_CYCLES, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE and the
+SQ_INSTS_VALU_MFMA_MOPS_* counters (VERDICT r05 missing #4: "MFMA utilisation as a percentage").
+
+  util = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE)       per dispatch, then the mean over a kernel's dispatches
+       (MFMA-busy cycles are summed over every SIMD of the chip; GRBM_GUI_ACTIVE = cycles the dispatch kept the GPU busy)
+  ops  = MOPS counter x 512 (one unit = 512 matrix operations on this family) per dispatch; ops / duration against the dense peak of the type when the
+         kernel-trace of the same run is present (rocprofv3 --pmc with --kernel-trace writes both).
+
+usage: mfma_util.py <rocprofv3 output dir> [kernel name filter ...]"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+PEAK = {"F16": 2500e12, "BF16": 2500e12, "I8": 5000e12}
+
+
+def main(d, filters):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        print("no counter_collection.csv under", d)
+        return 1
+    disp = defaultdict(dict)
+    names = {}
+    for f in files:
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                key = (f, r.get("Dispatch_Id"))
+                names[key] = r.get("Kernel_Name", "?").split("(")[0]
+                disp[key][r.get("Counter_Name")] = float(r.get("Counter_Value") or 0)
+    dur = {}
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for r in csv.DictReader(fh):
+                dur[r.get("Dispatch_Id")] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+    agg = defaultdict(lambda: defaultdict(list))
+    for key, c in disp.items():
+        n = names[key]
+        if filters and not any(x in n for x in filters):
+            continue
+        gui = c.get("GRBM_GUI_ACTIVE", 0)
+        if gui <= 0:
+            continue
+        a = agg[n]
+        a["util"].append(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * 256 * gui))
+        a["sq_busy"].append(c.get("SQ_BUSY_CYCLES", 0) / gui)
+        a["gui"].append(gui)
+        for t in ("F16", "BF16", "I8"):
+            m = c.get(f"SQ_INSTS_VALU_MFMA_MOPS_{t}", 0)
+            if m:
+                a["ops_" + t].append(m * 512)
+                s = dur.get(key[1])
+                if s:
+                    a["frac_" + t].append(m * 512 / s / PEAK[t])
+    print(f"{'kernel':64s} {'n':>5s} {'MFMA busy % of 4x256 SIMD-cycles':>34s} {'GUI cycles':>11s}  matrix ops per launch (and fraction of the dense peak over the traced duration)")
+    for n in sorted(agg, key=lambda k: -sum(agg[k]["gui"])):
+        a = agg[n]
+        if not any(k.startswith("ops_") for k in a):
+            continue
+        mean = lambda v: sum(v) / max(len(v), 1)
+        extra = []
+        for t in ("F16", "BF16", "I8"):
+            if a.get("ops_" + t):
+                e = f"{t}: {mean(a['ops_' + t]):.3g}"
+                if a.get("frac_" + t):
+                    e += f" ({100 * mean(a['frac_' + t]):.1f} % of {PEAK[t] / 1e12:.0f} T)"
+                extra.append(e)
+        print(f"{n[:64]:64s} {len(a['util']):5d} {100 * mean(a['util']):33.1f}% {mean(a['gui']):11.0f}  " + "; ".join(extra))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1], sys.argv[2:]))

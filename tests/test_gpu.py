@@ -986,7 +986,7 @@ def test_layer_bisect_locates_the_difference(plugin_env):
 
 
 @pytest.mark.parametrize("arch,qtype,streams", [("base.en", "q5_0", 4), ("large-v3-2l", "q8_0", 3), ("base.en", "q5_0", 8), ("large-v3", "q5_0", 8),
-                                                ("base.en", "q4_k", 12), ("large-v3-2l", "q4_k", 8), ("large-v3", "q5_0", 16)])
+                                                ("base.en", "q4_k", 12), ("large-v3-2l", "q4_k", 8), ("large-v3", "q5_0", 16), ("base.en", "q5_0", 48)])
 def test_concurrent_streams_on_one_gpu_match_serial(arch, qtype, streams):
     """several whisper_states on one context, one host thread each (the whisper_full_parallel arrangement, W:7848-7869):
     each stream's logits — the row of EVERY decode step — must be bit-identical to the same stream running alone.  With 8 streams
@@ -994,7 +994,8 @@ def test_concurrent_streams_on_one_gpu_match_serial(arch, qtype, streams):
     is BASELINE.json configs[3] at full size, batched versus own chain over all steps; 12 and 16 streams run with the default chain widths
     (60 % of the states on one chain — 8 and 10 columns, the latter two images of 8 columns, mi355x_kernels.h: MI355X_IMG_COLS — the rest
     on a second chain beside it); 16 streams of large-v3 Q5_0 is the verdict's configuration; large-v3-2l Q4_K covers the Q8_K planes and the
-    k_gemv8 vocabulary projection at K = 1280 (round 4: its LayerNorm summed in another tree than the batched form's)."""
+    k_gemv8 vocabulary projection at K = 1280 (round 4: its LayerNorm summed in another tree than the batched form's); 48 streams = more decoding states
+    than one chain carries (round 6: chains of equal width, 24 + 24)."""
     r = subprocess.run([sys.executable, str(ROOT / "scripts" / "stream_check.py"), arch, qtype, str(streams), "12"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=str(ROOT))
     assert r.returncode == 0, r.stderr[-2000:]
@@ -1088,7 +1089,7 @@ def test_bench_smoke():
     # every instantiation of the family carries its own (algorithmic bytes, counter bytes) pair per launch
     inst = d["roofline"]["instantiations"]
     assert isinstance(inst, list) and inst and all("algorithmic_per_launch" in e and "traffic" in e and e["launches"] > 0 for e in inst)
-    assert "batched_16_streams" in ms and "batched_32_streams" in ms and ms["batched_32_streams"]["chunks_per_s"] > 0
+    assert "batched_16_streams" in ms and "batched_32_streams" in ms and ms["batched_32_streams"]["chunks_per_s"] > 0 and ms["batched_64_streams"]["chunks_per_s"] > 0
 
 
 def test_bench_under_torchrun_exercises_the_native_weight_distribution():

@@ -169,9 +169,14 @@ ggml_status mi_batch_join(mi_backend_ctx * b, ggml_cgraph * cgraph) {
     std::unique_lock<std::mutex> lk(grp.m);
     if (!b->in_group) { b->in_group = true; grp.members.push_back(b); }
     constexpr int split_pct = 60, split_min = 4;
+    // More decoding states than one chain can carry (round 6, profiles/r06_streams_over_32.txt): the 60 % rule then cuts the set into one full chain and an odd rest
+    // (48 states = 29 + 19: 11.7 chunks/s, 618 closed windows) — chains of EQUAL width in the smallest possible number do better: 48 = 24 + 24: 21.8, 64 = 32 + 32: 24.3
+    // (fixed widths: 64 as chains of 24: 17.7, of 16: 18.9; 48 as 32 + 16: 18.6, as 3 x 16: 21.2).
     auto cols_cap = [&]() {
         if (env_cols) return env_cols;
-        return std::min(MI355X_MAX_COLS, std::max(split_min, (split_pct * (int) grp.members.size() + 99) / 100));
+        const int n = (int) grp.members.size();
+        if (n > MI355X_MAX_COLS) { const int k = (n + MI355X_MAX_COLS - 1) / MI355X_MAX_COLS; return (n + k - 1) / k; }
+        return std::min(MI355X_MAX_COLS, std::max(split_min, (split_pct * n + 99) / 100));
     };
     if ((int) grp.members.size() < mi_batch_min_states()) {
         // too few decoding states for a merged chain to pay: this step runs on the state's own stream (it stays counted)
