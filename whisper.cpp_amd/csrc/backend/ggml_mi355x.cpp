@@ -17,7 +17,7 @@ void mi_backend_free(ggml_backend_t backend) {
     if (b->batch_wait_sync) (void) hipEventSynchronize(b->batch_wait_sync);
     if (b->own_ev) (void) hipEventDestroy(b->own_ev);
     b->mirror_state.store(0);
-    if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 "\n", b->name.c_str(), b->n_graph_compute);
+    if (g_debug()) fprintf(stderr, "ggml-mi355x: backend %s: graph_compute=%" PRIu64 "\n", b->name.c_str(), (uint64_t) b->n_graph_compute.load());
     if (b->span_pending) mi_span_drain(b);
     for (auto & e : b->span_ev) { (void) hipEventDestroy(e.first); (void) hipEventDestroy(e.second); }
     if (b->act) (void) hipFree(b->act);
@@ -86,6 +86,18 @@ ggml_status mi_backend_graph_compute(ggml_backend_t backend, ggml_cgraph * cgrap
         } else b->logits_dev = nullptr;
     }
     if (mi_batching_on() && b->fuse && !b->exact && !b->prof && cgraph->n_nodes != b->no_batch_nodes && mi_is_step_graph(cgraph)) return mi_batch_join(b, cgraph);
+    if (!mi_batching_on() && mi_is_step_graph(cgraph)) {
+        // cross-state batching switched off (GGML_MI355X_BATCH=0 / ggml_backend_mi355x_set_batching(0)): beyond four decoding states their own chains collapse
+        // (8 states: 2.1-2.5 chunks/s of large-v3 Q5_0 against 2.8 for ONE state and 10 merged) — say so once instead of silently being slow
+        static std::atomic<bool> warned{false};
+        if (!warned.load(std::memory_order_relaxed)) {
+            int live = 0;
+            { std::shared_lock<std::shared_mutex> rl(g_backends_rw); for (mi_backend_ctx * o : g_backends) if (o->device == b->device && o->n_graph_compute > 16) live++; }
+            if (live > 4 && !warned.exchange(true))
+                GGML_LOG_WARN("ggml-mi355x: %d whisper_states decode on device %d with cross-state batching OFF: beyond 4 states their launch chains serialize and throughput falls below one state's; "
+                              "leave GGML_MI355X_BATCH at its default (1) for merged chains\n", live, b->device);
+        }
+    }
     mi_batch_leave(b);                          // anything else (encoder, prompt, beam step): this state is not decoding token by token right now
     return mi_compute_own(b, cgraph);
 }

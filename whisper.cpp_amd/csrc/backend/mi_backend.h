@@ -186,7 +186,7 @@ struct mi_backend_ctx {
     std::atomic<int> mirror_state{0};                           // 0 nothing, 1 launched (not yet synchronized), 2 valid
     // where the last decoder step of this state left its logits (device): ggml_backend_mi355x_argmax_last reduces a row there
     const float * logits_dev = nullptr; int logits_n = 0, logits_rows = 0;
-    uint64_t n_graph_compute = 0;
+    std::atomic<uint64_t> n_graph_compute{0};            // (read by other states' threads: the batching-off warning)
     double   t_eager_ms = 0;                                    // host time inside graph_compute
     uint64_t trace_gc_enter = 0;                                // GGML_MI355X_TRACE: entry time of the graph_compute still waiting for its synchronize
     // GPU-side span of every graph_compute (first launch .. last kernel done), from a ring of hipEvent pairs on the stream
