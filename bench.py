@@ -128,14 +128,16 @@ def algorithmic_figures(arch: str, qtype: str):
     gemm_flop = 2.0 * n_actx * n_al * 12 * n_as * n_as + 2.0 * n_actx * n_tl * 2 * n_ts * n_ts          # encoder layers' products + cross-K/V: quantized weights -> int8 MFMA
     f16_flop = 4.0 * n_actx * n_ctx_pad * n_as * n_al + 2.0 * (2 * n_actx) * n_as * 3 * n_mels + 2.0 * n_actx * n_as * 3 * n_as      # attention + the two convolutions: f16 MFMA
     enc_flop = gemm_flop + f16_flop
-    int8 = qtype != "f16"
+    # the encoder's / cross-K/V products (1500 columns) run on the f16 matrix cores by default since round 6 (GGML_MI355X_MMQ=1: by width); =2 puts them back on the int8 tile GEMM
+    int8 = qtype != "f16" and os.environ.get("GGML_MI355X_MMQ", "1") == "2"
     # roofline time of one encode: every part at the dense peak of the matrix-core type it runs on
     enc_bound_ms = (gemm_flop / ((MFMA_I8_PEAK_TOPS if int8 else MFMA_F16_PEAK_TFLOPS) * 1e12) + f16_flop / (MFMA_F16_PEAK_TFLOPS * 1e12)) * 1e3
     return {"decode_bytes_per_token": dec_w * bpw + kv_cross, "encode_flop": enc_flop, "decode_weight_bytes": dec_w * bpw, "decode_kv_bytes_per_stream": kv_cross,
             "encode_flop_int8": gemm_flop if int8 else 0.0, "encode_flop_f16": f16_flop if int8 else enc_flop, "encode_bound_ms": enc_bound_ms}
 
 
-DTYPE = "int8 dot (decode mat-vecs) / int8 MFMA (quantized products with > 8 columns) / f16 MFMA (attention, conv), f32 accumulate"
+DTYPE = ("int8 dot (decode mat-vecs) / int8 MFMA (merged-chain mat-vecs, quantized products with 9..1023 columns) / f16 MFMA on f16(d*q) operands "
+         "(encoder and cross-K/V products from 1024 columns on, attention, conv), f32 accumulate")
 
 
 def contract_line(a, n_gpus: int, streams_per_gpu: int, ms_per_step: float, agg_ms: float, chunks_per_s: float, data="synthetic"):
