@@ -769,16 +769,21 @@ static int launch_ring_group(mi355x_ctx * ctx, const GemmArgs * members, int n, 
 // f16 copy of the weight anywhere.  What bounds a K-step of these products on a CU is not the matrix pipe but the vector-memory path that
 // fills LDS (64 B/clk per CU at best): a 128 x 128 tile of two f16 operands needs 32 KB per 64 MFMAs (= 512 matrix-pipe cycles per SIMD:
 // exactly the path's peak — the ring kernel above runs at 28-34 % of the MFMA rate, r03b_gemm_fixed_cost.txt).  So
-//   * A travels in its block-quantized planar form (0.56 - 1.06 B/weight instead of 2) through registers: waves 0..3 hold one (row, 32-element
-//     block) pair per thread, fetched one K-step ahead, unpacked to f16 (a_unpack: the values of mi355x_dequant_f16, bit for bit) and written
-//     into the XOR-swizzled A stage that the NEXT step reads — one such wave per SIMD, so its unpack VALU runs beside the MFMAs of the SIMD's
-//     other wave;
-//   * B (prepared f16 activations [T][K]) arrives by LDS-DMA, 8 rows x 128 B per instruction, swizzle on the global side (as the ring);
-//   * the tile is 128 (weights rows) x BN tokens with BN = 256 where the product has enough tiles (8 waves, 2 x 4; 37.6 KB per 128 MFMAs for
-//     Q5_0) and 128 otherwise (4 waves, two workgroups per CU); every wave owns a 64 x 64 piece: fragments, MFMA order and epilogue are the
-//     ring kernel's, so results are bit-identical to it on the weight's f16 copy (tests/test_gpu.py).
-// Two stages of each operand, ONE barrier per K-step: wait (own DMA + own A stores) -> barrier -> write A(k+1), request A(k+2), B(k+1) -> MFMAs(k).
+//   * A travels in its block-quantized planar form (0.56 - 1.06 B/weight instead of 2): the planes of a K-step reach LDS as they lie in memory, by LDS-DMA
+//     ("raw" stage, three deep), and waves 0..3 — one per SIMD — unpack one (row, 32-element block) pair per thread to f16 with packed f16 arithmetic
+//     (a_unpack_fast: the values of mi355x_dequant_f16, bit for bit) into the XOR-swizzled A stage that the NEXT step reads, beside the MFMAs of the SIMD's other wave;
+//   * B (prepared f16 activations [T][K]) arrives by LDS-DMA, 8 rows x 128 B per instruction, swizzle on the global side (as the ring), three stages deep;
+//   * every operand being a DMA, every wait is an exact vmcnt count (an ordinary register load beside a DMA makes hipcc drain the whole queue: versions 1 and 2);
+//   * the tile is 128 (weight rows) x BN tokens with BN = 256 where the product has enough tiles (8 waves, 2 x 4; 37.6 KB per 128 MFMAs for Q5_0) and 128
+//     otherwise (4 waves); every wave owns a 64 x 64 piece: fragments, MFMA order and per-element epilogue operations are the ring kernel's, so results are
+//     bit-identical to it on the weight's f16 copy (tests/test_gpu_encoder.py);
+//   * the epilogue goes through a wave-private LDS transposition (gemm_epilogue_lds above) with the GELU table in LDS.
+// Measured: correct and SLOWER than the ring on the copy — the row-scattered planes cost more cache-line requests than the copy's contiguous rows, and the vector-memory
+// path of a CU serves ~0.2 of them per clock whatever they carry (profiles/r06_gemm_dq_anatomy.txt).  Opt-in: GGML_MI355X_MMQ=3 / MI355X_OPT_DQ_GEMM.
+// ONE barrier per K-step: wait (all but the newest DMA batch + own A stores) -> barrier -> request raw A(k+3), B(k+2) -> unpack A(k+1) -> MFMAs(k).
+// (-DMI355X_RING_ONLY leaves the family out: tests/test_host.py's ISA check of the ring kernels compiles this file on the CPU suite's clock.)
 // -------------------------------------------------------------------------------------------------
+#ifndef MI355X_RING_ONLY
 // ---- unpack of one 32-element block to f16 without a float in sight ----------------------------------------------------------------
 // a_unpack computes f16(float(q) * d) per weight (extract, int -> float, multiply, float -> f16: 5-6 VALU operations per weight, ~1000 cycles per
 // K-step of a staging wave, profiles/r06_gemm_dq_anatomy.txt).  The same values from packed f16 arithmetic: a 4..8-bit unsigned u placed in the
@@ -1091,6 +1096,11 @@ static bool dq_eligible(const GemmArgs & k, int at) {
     return k.K % BK == 0 && k.K >= 2*BK && (at != MI355X_TYPE_Q4_K || k.K % 256 == 0) && (k.ldb % 8) == 0 && ((uintptr_t) k.B % 16) == 0 && k.T >= 64 && k.M >= 64 &&
            (k.T + 127) / 128 <= 65535;
 }
+
+#else
+template <int AT> static int launch_dq_any(mi355x_ctx *, const GemmArgs *, int, double, double) { return MI355X_E_UNSUPPORTED; }
+static bool dq_eligible(const GemmArgs &, int) { return false; }
+#endif
 
 // ---- held-back ring GEMMs (mi355x_ctx::pending_*) ---------------------------------------------------------------------------
 struct PendingGemms { GemmArgs k[GEMM_GROUP_MAX]; double bytes, flops; int at; };     // at: MI355X_TYPE_F16 (ring) or the quantized type (k_gemm_dq)
