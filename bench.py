@@ -179,13 +179,20 @@ def run_in_process(a, cpu_selftest: bool, hip_runtime: str):
     model = make_model(a.arch, a.qtype)
     r = host_api.run(model, use_gpu=not cpu_selftest, n_devices=a.gpus, streams=a.streams, n_decode=a.n_decode, steps=a.steps, warmup=a.warmup,
                      skip_payloads=not cpu_selftest, transport=a.transport or "rccl")
+    rccl_error = None
+    if r["rc"] == 4 and not cpu_selftest and a.transport is None:
+        # the DEFAULT transport failed (no usable librccl on this host, or a collective error): the run is repeated on peer copies and the line SAYS so —
+        # transport "peer", rccl_error = what happened.  With an explicit --transport rccl the failure is final.
+        rccl_error = r["error"]
+        print(f"bench.py: RCCL weight broadcast failed ({rccl_error}); repeating with --transport peer", file=sys.stderr)
+        r = host_api.run(model, use_gpu=True, n_devices=a.gpus, streams=a.streams, n_decode=a.n_decode, steps=a.steps, warmup=a.warmup, skip_payloads=True, transport="peer")
     if r["rc"] != 0:
         raise SystemExit(f"bench.py: mi355x_host_run failed: rc={r['rc']} {r['error']}")
     if r["n_devices"] != a.gpus:
         raise SystemExit(f"bench.py: the harness ran on {r['n_devices']} devices, {a.gpus} were asked for")
     if not cpu_selftest and r["bcast_verified"] != 1:
         raise SystemExit("bench.py: the weight distribution to the replicas could not be verified: refusing to benchmark replicas with unknown weights")
-    if not cpu_selftest and (a.transport or "rccl") == "rccl" and not (r["bcast_transport"] == "rccl" and r["bcast_ranks"] == a.gpus):
+    if not cpu_selftest and rccl_error is None and (a.transport or "rccl") == "rccl" and not (r["bcast_transport"] == "rccl" and r["bcast_ranks"] == a.gpus):
         raise SystemExit(f"bench.py: asked for an RCCL broadcast over {a.gpus} ranks, the harness reports {r['bcast_transport']} over {r['bcast_ranks']}")
     n_streams = a.gpus * a.streams
     ms_per_step = r["ms_per_chunk_per_stream"]
@@ -200,7 +207,7 @@ def run_in_process(a, cpu_selftest: bool, hip_runtime: str):
         "weight_broadcast": None if cpu_selftest else {
             "transport": r["bcast_transport"], "ranks": int(r["bcast_ranks"]), "bytes": int(r["bcast_bytes"]), "buffers": int(r["bcast_buffers"]),
             "seconds": round(r["bcast_seconds"], 4), "GBps": round(r["bcast_bytes"] / max(r["bcast_seconds"], 1e-9) / 1e9, 2), "verified": int(r["bcast_verified"]),
-            "communicator_setup_seconds": round(r["bcast_setup_seconds"], 3),
+            "communicator_setup_seconds": round(r["bcast_setup_seconds"], 3), "rccl_error": rccl_error,
             "how": {"rccl": "ONE communicator per device in this process (ncclCommInitAll), ONE grouped ncclBroadcast per weights buffer from device 0 "
                             "(ggml_backend_mi355x_broadcast_weights_rccl_group), device-side checksums of every buffer of every device compared with device 0's",
                     "peer": "hipMemcpyPeerAsync device 0 -> device r (ggml_backend_mi355x_broadcast_weights_peer, --transport peer), device-side checksums compared"}.get(r["bcast_transport"]),
