@@ -1079,6 +1079,9 @@ def test_bench_smoke():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["value"] > 0 and d["roofline"]["achieved"] > 0
+    # the default GEMM policy is by width (round 6): the encoder's 1500-column products ran on the f16 ring, nothing wide on the int8 tile GEMM's grouped form
+    names = " ".join(d["kernel_time_ms_per_chunk"])
+    assert "k_gemm_f16_ring" in names and "k_mmq_group" not in names and "k_gemm_dq" not in names, names
     ms = d["multi_stream"]
     b8, o8, o4 = ms["batched_8_streams"], ms["own_chains_8_streams"], ms["own_chains_4_streams"]
     assert ms["streams"] == 8 and b8["chunks_per_s"] > 0 and o8["chunks_per_s"] > 0 and o4["chunks_per_s"] > 0, ms
