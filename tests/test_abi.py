@@ -125,3 +125,23 @@ def test_ctypes_mirrors_have_the_layout_of_the_c_structs(tmp_path):
     assert (e.bias, e.scale, e.has_scale, e.gelu, e.bias_per_col, e.residual, e.residual_nb1) == (11, 0.5, 1, 1, 0, 22, 33)
     e = ka.Epilogue(bias=5, bias_per_col=1)
     assert e.bias == 5 and e.bias_per_col == 1 and e.residual is None
+
+
+@pytest.mark.skipif(has_gpu(), reason="the no-device failure path")
+def test_in_process_rccl_broadcast_fails_cleanly_without_a_device():
+    """ggml_backend_mi355x_broadcast_weights_rccl_group on a machine without a gfx950 device: librccl is found and bound (or reported missing), the call returns a
+    negative code with stats zeroed, nothing crashes and nothing is written to the host's stdout — the path bench.py's peer fall-back and its rccl_error field rest on."""
+    import subprocess, sys
+    code = (
+        "import ctypes as C, sys\n"
+        f"C.CDLL(r'{REFBASE}', mode=C.RTLD_GLOBAL)\n"
+        f"p = C.CDLL(r'{PLUG}')\n"
+        "p.ggml_backend_mi355x_broadcast_weights_rccl_group.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_double)]\n"
+        "dev = (C.c_int * 2)(0, 1); st = (C.c_double * 6)(*([7.0] * 6))\n"
+        "rc = p.ggml_backend_mi355x_broadcast_weights_rccl_group(dev, 2, st)\n"
+        "dup = p.ggml_backend_mi355x_broadcast_weights_rccl_group((C.c_int * 2)(0, 0), 2, st)\n"
+        "sys.stderr.write('rc=%d dup=%d stats=%s\\n' % (rc, dup, list(st)))\n"
+        "sys.exit(0 if rc < 0 and dup < 0 and not any(st) else 1)\n")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert r.stdout == "", r.stdout[:400]
